@@ -1,0 +1,302 @@
+#!/usr/bin/env python3
+"""Generate golden input/output vectors by running the *reference* itself.
+
+Runs ONLY in the build container (it imports /root/reference/src, which never
+travels to the GPU box).  Everything it writes is data: seeded inputs, the
+initial state the reference drew from the global NumPy RNG, and the reference's
+outputs after k iterations.  No reference source is copied.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+NumPy >= 2 note (caveat 1): the reference's IP update
+calls ``np.linalg.solve(WU, e_n)`` with a stack of vectors as ``b``
+(src/bss/ilrma.py:523, src/bss/iva.py:511,744).  NumPy 2 interprets that as a
+matrix and raises.  We wrap -- not edit -- the call with NumPy-1.x semantics
+before importing the reference.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+REFERENCE_SRC = os.environ.get("ASSX_REFERENCE_SRC", "/root/reference/src")
+OUT_DIR = os.path.dirname(os.path.abspath(__file__))
+
+_orig_solve = np.linalg.solve
+
+
+def _solve_numpy1(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    if b.ndim == a.ndim - 1:
+        return _orig_solve(a, b[..., None])[..., 0]
+    return _orig_solve(a, b)
+
+
+np.linalg.solve = _solve_numpy1
+sys.path.insert(0, REFERENCE_SRC)
+
+from algorithm.nmf import EUCNMF, KLNMF, ISNMF  # noqa: E402
+from algorithm.projection_back import projection_back  # noqa: E402
+from bss.iva import AuxLaplaceIVA, AuxGaussIVA  # noqa: E402
+from bss.ilrma import GaussILRMA  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+VERSIONS = np.array("numpy=%s" % np.__version__)
+SNAP_ITERS = (1, 2, 5, 20)
+
+
+# ----------------------------------------------------------------------------
+# synthetic inputs
+# ----------------------------------------------------------------------------
+def noise_mixture(M, F, T, seed):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((M, F, T)) + 1j * rng.standard_normal((M, F, T))
+
+
+def convolutive_mixture(M, F, T, seed, n_basis=3):
+    """Low-rank-variance complex Gaussian sources mixed by a random per-bin matrix."""
+    rng = np.random.default_rng(seed)
+    S = np.empty((M, F, T), dtype=np.complex128)
+    for n in range(M):
+        Tb = rng.random((F, n_basis)) ** 2
+        Vb = rng.random((n_basis, T)) ** 4  # sparse-ish activations
+        var = Tb @ Vb + 1e-3
+        S[n] = np.sqrt(var / 2) * (rng.standard_normal((F, T)) + 1j * rng.standard_normal((F, T)))
+    A = rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M))
+    X = np.einsum("fmn,nft->mft", A, S)
+    return X
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, versions=VERSIONS, **arrays)
+    print("wrote %-44s %8.1f KiB" % (os.path.basename(path), os.path.getsize(path) / 1024))
+
+
+# ----------------------------------------------------------------------------
+# G1: NMF
+# ----------------------------------------------------------------------------
+def gen_nmf():
+    cases = [
+        # name, cls, kwargs, (F, T, K), seed
+        ("euc_d2", EUCNMF, dict(domain=2), (65, 48, 4)),
+        ("euc_d1", EUCNMF, dict(domain=1), (65, 48, 4)),
+        ("euc_d15", EUCNMF, dict(domain=1.5), (33, 40, 3)),
+        ("kl_d2", KLNMF, dict(domain=2), (65, 48, 4)),
+        ("kl_d1", KLNMF, dict(domain=1), (65, 48, 4)),
+        ("kl_d15", KLNMF, dict(domain=1.5), (33, 40, 3)),
+        ("is_mm_d2", ISNMF, dict(domain=2, algorithm="mm"), (65, 48, 4)),
+        ("is_mm_d1", ISNMF, dict(domain=1, algorithm="mm"), (65, 48, 4)),
+        ("is_mm_d15", ISNMF, dict(domain=1.5, algorithm="mm"), (33, 40, 3)),
+        ("is_me_d2", ISNMF, dict(domain=2, algorithm="me"), (65, 48, 4)),
+        # config 1 of BASELINE.json: EUC-NMF F=513, T=256, K=8
+        ("euc_cfg1", EUCNMF, dict(domain=2), (513, 256, 8)),
+        ("is_k32", ISNMF, dict(domain=2), (40, 96, 32)),
+    ]
+    for idx, (name, cls, kw, (F, T, K)) in enumerate(cases):
+        rng = np.random.default_rng(100 + idx)
+        if name == "euc_cfg1":
+            X = rng.random((F, T)) ** 2
+        else:
+            # power spectrogram of a low-rank model + noise; contains a few exact zeros (eps floors)
+            X = (rng.random((F, K)) @ rng.random((K, T))) * rng.exponential(size=(F, T))
+            X[rng.random((F, T)) < 0.01] = 0.0
+        out = dict(X=X, F=F, T=T, K=K, domain=kw.get("domain", 2), algorithm=kw.get("algorithm", "mm"),
+                   kind=name.split("_")[0].upper(), seed=7 + idx)
+        iters = SNAP_ITERS if name != "euc_cfg1" else (1, 5)
+        for k in iters:
+            np.random.seed(7 + idx)
+            model = cls(n_basis=K, **kw)
+            if k == iters[0]:
+                # record the exact init the reference draws (basis first, then activation: nmf.py:42-43)
+                state = np.random.get_state()
+                out["T0"] = np.random.rand(F, K)
+                out["V0"] = np.random.rand(K, T)
+                np.random.set_state(state)
+            Tk, Vk = model(X, iteration=k)
+            out["T_%d" % k] = Tk
+            out["V_%d" % k] = Vk
+            out["loss_%d" % k] = np.asarray(model.loss, dtype=np.float64)
+        out["iters"] = np.asarray(iters)
+        save("nmf_" + name, **out)
+
+
+# ----------------------------------------------------------------------------
+# G2: AuxIVA (IP)
+# ----------------------------------------------------------------------------
+class Snapshot:
+    """Callback recording the public state the reference exposes after each iteration."""
+
+    def __init__(self, iters, with_nmf):
+        self.iters = set(iters)
+        self.with_nmf = with_nmf
+        self.count = -1
+        self.data = {}
+
+    def __call__(self, model):
+        self.count += 1  # 0 = before the loop
+        k = self.count
+        if k in self.iters:
+            self.data["W_%d" % k] = model.demix_filter.copy()
+            if self.with_nmf:
+                self.data["T_%d" % k] = model.basis.copy()
+                self.data["V_%d" % k] = model.activation.copy()
+
+
+def gen_auxiva():
+    for cls, tag in ((AuxLaplaceIVA, "laplace"), (AuxGaussIVA, "gauss")):
+        for M in (2, 3, 4):
+            F, T = 33, 64
+            X = convolutive_mixture(M, F, T, seed=200 + M)
+            snap = Snapshot(SNAP_ITERS, with_nmf=False)
+            model = cls(algorithm_spatial="IP", callbacks=snap)
+            Y = model(X, iteration=max(SNAP_ITERS))
+            save("auxiva_%s_m%d" % (tag, M), X=X, M=M, F=F, T=T, kind=tag, iters=np.asarray(SNAP_ITERS),
+                 loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter, **snap.data)
+        # no projection back, noise input, reference_id != 0
+        X = noise_mixture(3, 17, 40, seed=260)
+        model = cls(algorithm_spatial="IP", apply_projection_back=False)
+        Y = model(X, iteration=3)
+        model2 = cls(algorithm_spatial="IP1", reference_id=2)
+        Y2 = model2(X, iteration=3)
+        save("auxiva_%s_opts" % tag, X=X, kind=tag, Y_nopb=Y, loss_nopb=np.asarray(model.loss),
+             Y_ref2=Y2, loss_ref2=np.asarray(model2.loss), W_nopb=model.demix_filter, W_ref2=model2.demix_filter)
+
+
+# ----------------------------------------------------------------------------
+# G3: GaussILRMA (IP)
+# ----------------------------------------------------------------------------
+def gen_ilrma():
+    seed = 300
+    for M, K, normalize, domain in [
+        (2, 2, "power", 2), (4, 4, "power", 2), (3, 5, "power", 2),
+        (2, 4, "projection-back", 2), (4, 2, "projection-back", 2),
+        (2, 2, False, 2), (4, 4, False, 2),
+        (2, 4, "power", 1), (4, 2, "projection-back", 1), (3, 3, "power", 1.5),
+    ]:
+        seed += 1
+        F, T = 33, 64
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        T0 = np.random.rand(M, F, K)
+        V0 = np.random.rand(M, K, T)
+        np.random.set_state(state)
+        snap = Snapshot(SNAP_ITERS, with_nmf=True)
+        model = GaussILRMA(n_basis=K, domain=domain, normalize=normalize, callbacks=snap)
+        Y = model(X, iteration=max(SNAP_ITERS))
+        tag = "m%d_k%d_%s_d%s" % (M, K, {"power": "pow", "projection-back": "pb", False: "none"}[normalize],
+                                   str(domain).replace(".", ""))
+        save("ilrma_" + tag, X=X, M=M, F=F, T=T, K=K, domain=domain,
+             normalize=np.array(str(normalize)), seed=seed, T0=T0, V0=V0, iters=np.asarray(SNAP_ITERS),
+             loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter,
+             T_final=model.basis, V_final=model.activation, **snap.data)
+
+    # stage-level intermediates: one source-model step, then one spatial step, from a non-trivial state
+    M, K, F, T = 4, 4, 17, 48
+    X = convolutive_mixture(M, F, T, seed=390)
+    np.random.seed(390)
+    model = GaussILRMA(n_basis=K, recordable_loss=True)
+    model(X, iteration=3)  # warm state
+    W0, T0, V0 = model.demix_filter.copy(), model.basis.copy(), model.activation.copy()
+    stage = GaussILRMA(n_basis=K)
+    stage.input = X
+    stage._reset(demix_filter=W0.copy(), basis=T0.copy(), activation=V0.copy())
+    loss0 = stage.compute_negative_loglikelihood()
+    stage.update_source_model()
+    T1, V1 = stage.basis.copy(), stage.activation.copy()
+    # weighted covariance as the reference forms it (ilrma.py:497-511), small enough to materialise
+    R = (T1 @ V1) ** (2 / 2)
+    R[R < stage.eps] = stage.eps
+    Xt = X.transpose(1, 2, 0)[..., None]
+    XX = Xt @ Xt.transpose(0, 1, 3, 2).conj()
+    U = (XX / R[..., None, None]).mean(axis=2)
+    stage.update_spatial_model()
+    W1 = stage.demix_filter.copy()
+    Y1 = stage.estimation.copy()
+    loss1 = stage.compute_negative_loglikelihood()
+    save("ilrma_stages", X=X, W0=W0, T0=T0, V0=V0, T1=T1, V1=V1, U=U, W1=W1, Y1=Y1,
+         loss0=loss0, loss1=loss1)
+
+    # warm start across two calls + loss list continuation (ilrma.py:67-72, 44-48)
+    X = convolutive_mixture(2, 17, 40, seed=395)
+    np.random.seed(395)
+    model = GaussILRMA(n_basis=3)
+    Ya = model(X, iteration=2)
+    Yb = model(X, iteration=3)
+    save("ilrma_warm", X=X, seed=395, K=3, Y_a=Ya, Y_b=Yb, loss=np.asarray(model.loss),
+         W_final=model.demix_filter, T_final=model.basis, V_final=model.activation)
+
+
+# ----------------------------------------------------------------------------
+# G4: projection_back; G5: edge cases
+# ----------------------------------------------------------------------------
+def gen_projection_back():
+    rng = np.random.default_rng(400)
+    out = {}
+    for N in (2, 3, 4):
+        F, T = 9, 50
+        Y = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        ref = rng.standard_normal((F, T)) + 1j * rng.standard_normal((F, T))
+        refs = rng.standard_normal((N, F, T)) + 1j * rng.standard_normal((N, F, T))
+        out["Y_n%d" % N] = Y
+        out["ref_n%d" % N] = ref
+        out["scale_n%d" % N] = projection_back(Y, ref)
+        out["refs_n%d" % N] = refs
+        out["scale3_n%d" % N] = projection_back(Y, refs)
+    save("projection_back", **out)
+
+
+def gen_edge():
+    # (a) bins whose WU is numerically singular: cond(WU) >= 1e12 -> the old row must be kept
+    #     (ilrma.py:520-528).  Channel 1 = channel 0 * c + 1e-14 noise in bins 2 and 5.
+    M, F, T, K = 3, 8, 40, 2
+    X = convolutive_mixture(M, F, T, seed=500)
+    rng = np.random.default_rng(501)
+    for f in (2, 5):
+        X[1, f] = X[0, f] * (0.7 - 0.2j) + 1e-14 * rng.standard_normal(T)
+    np.random.seed(500)
+    T0 = np.random.rand(M, F, K)
+    V0 = np.random.rand(M, K, T)
+    np.random.seed(500)
+    snap = Snapshot((1, 2), with_nmf=True)
+    model = GaussILRMA(n_basis=K, callbacks=snap)
+    Y = model(X, iteration=2)
+    # recompute the cond mask of the first IP sweep exactly as the reference does
+    save("edge_cond_ilrma", X=X, K=K, seed=500, T0=T0, V0=V0, loss=np.asarray(model.loss),
+         W_final=model.demix_filter, Y_out=Y, **snap.data)
+
+    snap = Snapshot((1, 2), with_nmf=False)
+    model = AuxLaplaceIVA(callbacks=snap)
+    Y = model(X, iteration=2)
+    save("edge_cond_auxiva", X=X, loss=np.asarray(model.loss), W_final=model.demix_filter, Y_out=Y, **snap.data)
+
+    # (b) exact zeros in X: whole frames silent -> eps floors on R / TV are hit (ilrma.py:415,509; iva.py:497)
+    X = convolutive_mixture(2, 9, 48, seed=510)
+    X[:, :, 10:14] = 0.0
+    X[:, 3, :] *= 1e-9
+    np.random.seed(510)
+    T0 = np.random.rand(2, 9, 2)
+    V0 = np.random.rand(2, 2, 48)
+    np.random.seed(510)
+    model = GaussILRMA(n_basis=2)
+    Y = model(X, iteration=3)
+    save("edge_zeros_ilrma", X=X, K=2, seed=510, T0=T0, V0=V0, loss=np.asarray(model.loss),
+         W_final=model.demix_filter, T_final=model.basis, V_final=model.activation, Y_out=Y)
+    model = AuxLaplaceIVA()
+    Y = model(X, iteration=3)
+    save("edge_zeros_auxlaplace", X=X, loss=np.asarray(model.loss), W_final=model.demix_filter, Y_out=Y)
+    model = AuxGaussIVA()
+    Y = model(X, iteration=3)
+    save("edge_zeros_auxgauss", X=X, loss=np.asarray(model.loss), W_final=model.demix_filter, Y_out=Y)
+
+
+if __name__ == "__main__":
+    gen_nmf()
+    gen_auxiva()
+    gen_ilrma()
+    gen_projection_back()
+    gen_edge()
