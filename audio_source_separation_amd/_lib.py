@@ -1,0 +1,80 @@
+"""ctypes binding of libassx.so (the C-ABI declared in include/assx.h).
+
+There is deliberately NO fallback: if the HIP library is missing the import fails loudly, and
+every call checks its status code and raises with the library's own message.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libassx.so")
+
+F32, F64 = 0, 1
+W_NONE, W_NT, W_NFT = 0, 1, 2
+IVA_LAPLACE, IVA_GAUSS = 0, 1
+NMF_EUC, NMF_KL, NMF_IS_MM, NMF_IS_ME = 0, 1, 2, 3
+STATUS_SINGULAR, STATUS_COND_REJECT = 1, 2
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_d = ctypes.c_double
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes) ; must list EVERY symbol include/assx.h declares (tests check this)
+SIGNATURES = {
+    "assx_ctx_create": (_i, [_i, ctypes.POINTER(_vp)]),
+    "assx_ctx_destroy": (_i, [_vp]),
+    "assx_last_error": (ctypes.c_char_p, [_vp]),
+    "assx_version": (ctypes.c_char_p, []),
+    "assx_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "assx_demix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_cov_accumulate": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_spatial_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_demix_power": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_power_from_cov": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_normalize_power": (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_normalize_pb": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_auxiva_weights": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_auxiva_spatial_update": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_projection_back_scale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_projection_back": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_nmf_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "assx_nmf_update": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_nmf_loss": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+}
+
+
+class AssxError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "HIP library not built: %s is missing.  Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`audio_source_separation_amd/csrc/build.sh` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def version():
+    return lib.assx_version().decode()
+
+
+def check(ctx, rc, what):
+    if rc != 0:
+        msg = lib.assx_last_error(ctx).decode(errors="replace") if ctx else ""
+        kind = "invalid argument" if rc < 0 else "HIP error"
+        raise AssxError("%s failed (%s %d): %s" % (what, kind, rc, msg))

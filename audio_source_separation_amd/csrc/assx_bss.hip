@@ -1,0 +1,1359 @@
+// AuxIVA / Gauss-ILRMA hot-path kernels for gfx950 (CDNA4, wave64) and their C-ABI entry points.
+//
+// Data layout (identical to the reference's NumPy arrays, plus a leading utterance axis B):
+//   X (B,M,F,T) complex, T fastest -> a wave reads 64 consecutive frames of one (m,f) row: one
+//   fully coalesced 1 KiB (c128) / 512 B (c64) request.  Every kernel streams X exactly once and
+//   recomputes y = W x in registers; Y is never materialised inside the iteration loop.
+//
+// Work decomposition (all reductions are two-stage and atomic-free => run-to-run bit-stable):
+//   "reduce over t" kernels (covariance, basis update, power, loss, projection-back statistics):
+//       one WAVE per (utterance, bin f, t-split); per-lane register accumulators; a butterfly
+//       reduce-scatter (wave_reduce_scatter) leaves one total per lane; partials -> small finalize.
+//   "reduce over f" kernels (activation update, AuxIVA r_n(t)):
+//       lanes own 64 consecutive t; the 4 waves of a workgroup stride over an f-range; cross-wave
+//       reduction staged through LDS; partials over f-splits -> small finalize.
+//
+// Reference citations: see include/assx.h next to each entry point.
+#include "assx_common.hpp"
+#include "assx_small_linalg.hpp"
+
+using namespace assx;
+
+namespace {
+
+enum { WK_NONE = 0, WK_NT = 1, WK_NFT = 2, WK_TV = 3 };
+
+constexpr int KU = 4;        // k-unroll of the NMF contractions (K <= 4 is the single-chunk fast path)
+constexpr int REDUCE_THREADS = 256;
+
+struct Dims {
+  int B, F, T, K;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+template <typename R, int M>
+__device__ __forceinline__ void load_filter(const Cx<R>* __restrict__ W, size_t bf, Cx<R> (&w)[M][M]) {
+  const Cx<R>* p = W + bf * (M * M);
+#pragma unroll
+  for (int n = 0; n < M; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) w[n][m] = p[n * M + m];
+}
+
+template <typename R, int M>
+__device__ __forceinline__ void demix(const Cx<R> (&w)[M][M], const Cx<R> (&x)[M], Cx<R> (&y)[M]) {
+#pragma unroll
+  for (int n = 0; n < M; ++n) {
+    Cx<R> s = cmake<R>(0, 0);
+#pragma unroll
+    for (int m = 0; m < M; ++m) cfma(s, w[n][m], x[m]);
+    y[n] = s;
+  }
+}
+
+// packed Hermitian index: [0,M) diagonal (real), then pairs (m<l) as (re, im)
+template <int M>
+__host__ __device__ constexpr int herm_pair_base(int m, int l) {  // requires m < l
+  // pairs ordered (0,1),(0,2),...,(0,M-1),(1,2),...
+  return M + 2 * (m * M - m * (m + 1) / 2 + (l - m - 1));
+}
+
+// ------------------------------------------------------------------------------------------
+// (a3) demix:  Y[b,n,f,t] = scale[b,n,f] * sum_m W[b,f,n,m] X[b,m,f,t]
+// ------------------------------------------------------------------------------------------
+template <typename R, int M>
+__global__ void __launch_bounds__(256) demix_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                   const Cx<R>* __restrict__ scale, Cx<R>* __restrict__ Y, Dims d) {
+  const int f = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.T) return;
+  const size_t FT = (size_t)d.F * d.T;
+  Cx<R> w[M][M];
+  load_filter<R, M>(W, (size_t)b * d.F + f, w);
+  const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * d.T + t;
+  Cx<R> x[M], y[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
+  demix<R, M>(w, x, y);
+  Cx<R>* yb = Y + (size_t)b * M * FT + (size_t)f * d.T + t;
+#pragma unroll
+  for (int n = 0; n < M; ++n) {
+    Cx<R> v = y[n];
+    if (scale) v = cmul(v, scale[((size_t)b * M + n) * d.F + f]);
+    yb[n * FT] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// (a4) weighted covariance partials: one wave per (b, f, t-split)
+//      part[b][ts][f][n*HM + h],  HM = M*M packed-Hermitian reals (un-normalised sums)
+// ------------------------------------------------------------------------------------------
+template <typename R>
+struct CovArgs {
+  const Cx<R>* X;
+  const R* r;    // WK_NT: (B,N,T)  WK_NFT: (B,N,F,T)
+  const R* Tb;   // WK_TV: (B,N,F,K)
+  const R* V;    // WK_TV: (B,N,K,T)
+  R* part;
+  Dims d;
+  int TS, tchunk;
+  R eps;
+  PowSpec p2d;   // 2/domain
+};
+
+template <typename R, int M, int WK, bool K4>
+__global__ void __launch_bounds__(64) cov_partial_kernel(CovArgs<R> a) {
+  constexpr int N = (WK == WK_NONE) ? 1 : M;
+  constexpr int HM = M * M;
+  constexpr int NV = next_pow2_c(N * HM);
+  const int f = blockIdx.x / a.TS, ts = blockIdx.x % a.TS, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int F = a.d.F, T = a.d.T, K = a.d.K;
+  const size_t FT = (size_t)F * T;
+  const Cx<R>* xb = a.X + (size_t)b * M * FT + (size_t)f * T;
+
+  R acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0;
+
+  R tb[N][KU];
+  if (WK == WK_TV && K4) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk)
+        tb[n][kk] = (kk < K) ? a.Tb[(((size_t)b * N + n) * F + f) * K + kk] : (R)0;
+  }
+
+  const int t0 = ts * a.tchunk;
+  const int t1 = min(T, t0 + a.tchunk);
+  for (int t = t0 + lane; t < t1; t += WAVE) {
+    Cx<R> x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
+    R p[HM];
+#pragma unroll
+    for (int m = 0; m < M; ++m) p[m] = cabs2(x[m]);
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int l = m + 1; l < M; ++l) {
+        Cx<R> q = cmulc(x[m], x[l]);
+        p[herm_pair_base<M>(m, l)] = q.x;
+        p[herm_pair_base<M>(m, l) + 1] = q.y;
+      }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      R wgt;
+      if (WK == WK_NONE) {
+        wgt = 1;
+      } else {
+        R r;
+        if (WK == WK_NT) {
+          r = a.r[((size_t)b * N + n) * T + t];
+        } else if (WK == WK_NFT) {
+          r = a.r[(((size_t)b * N + n) * F + f) * T + t];
+        } else {
+          const R* vb = a.V + ((size_t)b * N + n) * K * T + t;
+          R tv = 0;
+          if (K4) {
+#pragma unroll
+            for (int kk = 0; kk < KU; ++kk) tv = fma(tb[n][kk], vb[(size_t)min(kk, K - 1) * T], tv);
+          } else {
+            const R* tbn = a.Tb + (((size_t)b * N + n) * F + f) * K;
+            for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
+          }
+          r = powspec<R>(tv, a.p2d);  // R = (T V)^(2/domain), floored AFTER the power (ilrma.py:499-509)
+        }
+        wgt = (R)1 / floor_eps<R>(r, a.eps);
+      }
+#pragma unroll
+      for (int h = 0; h < HM; ++h) acc[n * HM + h] = fma(wgt, p[h], acc[n * HM + h]);
+    }
+  }
+  R tot = wave_reduce_scatter<R, NV>(acc);
+  const int i = scatter_index<NV>();
+  if (scatter_leader<NV>() && i < N * HM)
+    a.part[(((size_t)b * a.TS + ts) * F + f) * (N * HM) + i] = tot;
+}
+
+// sum t-splits, scale by 1/T, expand packed Hermitian -> dense U (B,N,F,M,M) complex
+template <typename R, int M>
+__global__ void __launch_bounds__(256) cov_finalize_kernel(const R* __restrict__ part, Cx<R>* __restrict__ U,
+                                                          int B, int N, int F, int TS, R inv_T) {
+  constexpr int HM = M * M;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * N * F * HM;
+  if (idx >= total) return;
+  const int l = idx % M, m = (idx / M) % M;
+  const int f = (idx / HM) % F;
+  const int n = (idx / ((size_t)HM * F)) % N;
+  const int b = idx / ((size_t)HM * F * N);
+  R re = 0, im = 0;
+  for (int ts = 0; ts < TS; ++ts) {
+    const R* p = part + (((size_t)b * TS + ts) * F + f) * (N * HM) + n * HM;
+    if (m == l) {
+      re += p[m];
+    } else {
+      const int lo = min(m, l), hi = max(m, l);
+      const int base = herm_pair_base<M>(lo, hi);
+      re += p[base];
+      im += p[base + 1];
+    }
+  }
+  if (m > l) im = -im;
+  U[idx] = cmake<R>(re * inv_T, im * inv_T);
+}
+
+// ------------------------------------------------------------------------------------------
+// (a5) IP sweep: one lane per (b, f); Gauss-Seidel over sources, all linear algebra in float64
+// ------------------------------------------------------------------------------------------
+template <typename R, int M>
+__global__ void __launch_bounds__(64) ip_kernel(const Cx<R>* __restrict__ U, Cx<R>* __restrict__ W, double thr,
+                                               int32_t* __restrict__ status, int B, int F) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F) return;
+  const int b = idx / F, f = idx % F;
+  Cd w[M][M];
+  {
+    const Cx<R>* p = W + (size_t)idx * (M * M);
+#pragma unroll
+    for (int n = 0; n < M; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) w[n][m] = cmake<double>((double)p[n * M + m].x, (double)p[n * M + m].y);
+  }
+  int flags = 0;
+#pragma unroll
+  for (int n = 0; n < M; ++n) {
+    const Cx<R>* un = U + (((size_t)b * M + n) * F + f) * (M * M);
+    Cd A[M][M], A0[M][M];
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) A[i][j] = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < M; ++k)
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        Cd u = cmake<double>((double)un[k * M + j].x, (double)un[k * M + j].y);
+#pragma unroll
+        for (int i = 0; i < M; ++i) cfma(A[i][j], w[i][k], u);  // WU = W @ U_n
+      }
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = 0; j < M; ++j) A0[i][j] = A[i][j];
+    const double nA2 = frob2<M>(A);
+    const bool nonsingular = gj_inverse<M>(A, nullptr);
+    if (!nonsingular) {
+      flags |= ASSX_STATUS_SINGULAR;  // numpy.linalg.solve raises here; the host turns the flag into LinAlgError
+      continue;
+    }
+    const double nI2 = frob2<M>(A);
+    const bool ok = cond2_below<M>(nA2, nI2, thr, A0, A);
+    if (!ok) {
+      flags |= ASSX_STATUS_COND_REJECT;
+      continue;  // keep the old row (np.where(condition, ..., w_n_Hermite))
+    }
+    // w = (WU)^{-1} e_n = column n of the inverse;  den = sqrt(w^H U_n w)
+    Cd q = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int i = 0; i < M; ++i) {
+      Cd s = cmake<double>(0.0, 0.0);
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        Cd u = cmake<double>((double)un[i * M + j].x, (double)un[i * M + j].y);
+        cfma(s, u, A[j][n]);
+      }
+      cfma(q, cconj(A[i][n]), s);
+    }
+    const Cd den = csqrt_principal(q);
+#pragma unroll
+    for (int j = 0; j < M; ++j) w[n][j] = cdiv(cconj(A[j][n]), den);
+  }
+  {
+    Cx<R>* p = W + (size_t)idx * (M * M);
+#pragma unroll
+    for (int n = 0; n < M; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) p[n * M + m] = cmake<R>((R)w[n][m].x, (R)w[n][m].y);
+  }
+  if (flags && status) atomicOr(&status[b], flags);
+}
+
+// ------------------------------------------------------------------------------------------
+// (a2) ILRMA source model, basis half: one wave per (b, f, t-split)
+//      part[b][ts][f][(n*K + k)*2 + {num, den}]
+// ------------------------------------------------------------------------------------------
+template <typename R>
+struct NmfArgs {
+  const Cx<R>* X;
+  const Cx<R>* W;
+  const R* Tb;
+  const R* V;
+  R* part;
+  Dims d;
+  int S, chunk;   // number of splits and split length (t-splits for basis, f-splits for activation)
+  R eps;
+  PowSpec p1;     // (domain+2)/domain
+};
+
+template <typename R, int M, bool K4>
+__global__ void __launch_bounds__(64) ilrma_basis_partial_kernel(NmfArgs<R> a) {
+  constexpr int N = M;
+  constexpr int NV = next_pow2_c(2 * N * KU);
+  const int f = blockIdx.x / a.S, ts = blockIdx.x % a.S, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int F = a.d.F, T = a.d.T, K = a.d.K;
+  const size_t FT = (size_t)F * T;
+  const Cx<R>* xb = a.X + (size_t)b * M * FT + (size_t)f * T;
+  Cx<R> w[M][M];
+  load_filter<R, M>(a.W, (size_t)b * F + f, w);
+  const R* tbase = a.Tb + ((size_t)b * N * F + f) * K;  // + n*F*K + k
+  const int t0 = ts * a.chunk;
+  const int t1 = min(T, t0 + a.chunk);
+  R* out = a.part + (((size_t)b * a.S + ts) * F + f) * (size_t)(N * K * 2);
+
+  const int nchunks = K4 ? 1 : (K + KU - 1) / KU;
+  for (int c = 0; c < nchunks; ++c) {
+    const int k0 = c * KU;
+    R acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0;
+    R tb[N][KU];
+    if (K4) {
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) tb[n][kk] = (kk < K) ? tbase[(size_t)n * F * K + kk] : (R)0;
+    }
+    for (int t = t0 + lane; t < t1; t += WAVE) {
+      Cx<R> x[M], y[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
+      demix<R, M>(w, x, y);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const R P = cabs2(y[n]);
+        const R* vb = a.V + ((size_t)b * N + n) * K * T + t;
+        R v[KU];
+        R tv = 0;
+        if (K4) {
+#pragma unroll
+          for (int kk = 0; kk < KU; ++kk) {
+            v[kk] = vb[(size_t)min(kk, K - 1) * T];
+            tv = fma(tb[n][kk], v[kk], tv);
+          }
+        } else {
+          const R* tbn = tbase + (size_t)n * F * K;
+          for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
+#pragma unroll
+          for (int kk = 0; kk < KU; ++kk) v[kk] = (k0 + kk < K) ? vb[(size_t)(k0 + kk) * T] : (R)0;
+        }
+        tv = floor_eps<R>(tv, a.eps);
+        const R inv = (R)1 / tv;                                  // TV_inverse
+        const R D = (a.p1.mode == POW_SQUARE) ? P * inv * inv      // division = P / TV**((d+2)/d)
+                                              : P / powspec<R>(tv, a.p1);
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+          acc[(n * KU + kk) * 2 + 0] = fma(D, v[kk], acc[(n * KU + kk) * 2 + 0]);
+          acc[(n * KU + kk) * 2 + 1] = fma(inv, v[kk], acc[(n * KU + kk) * 2 + 1]);
+        }
+      }
+    }
+    R tot = wave_reduce_scatter<R, NV>(acc);
+    const int i = scatter_index<NV>();
+    if (scatter_leader<NV>() && i < 2 * N * KU) {
+      const int s = i & 1, kk = (i >> 1) % KU, n = (i >> 1) / KU;
+      const int k = k0 + kk;
+      if (k < K) out[(n * K + k) * 2 + s] = tot;
+    }
+  }
+}
+
+// T *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:417-419)
+template <typename R>
+__global__ void __launch_bounds__(256) ilrma_basis_finalize_kernel(const R* __restrict__ part, R* __restrict__ Tb,
+                                                                  int B, int N, int F, int K, int TS, R eps,
+                                                                  PowSpec p2) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * N * F * K;
+  if (idx >= total) return;
+  const int k = idx % K;
+  const int f = (idx / K) % F;
+  const int n = (idx / ((size_t)K * F)) % N;
+  const int b = idx / ((size_t)K * F * N);
+  R num = 0, den = 0;
+  for (int ts = 0; ts < TS; ++ts) {
+    const R* p = part + (((size_t)b * TS + ts) * F + f) * (size_t)(N * K * 2) + (n * K + k) * 2;
+    num += p[0];
+    den += p[1];
+  }
+  den = floor_eps<R>(den, eps);
+  Tb[idx] = Tb[idx] * powspec<R>(num / den, p2);
+}
+
+// ------------------------------------------------------------------------------------------
+// (a2) activation half: lanes own t; 4 waves stride over the f-split; LDS cross-wave reduce
+//      part[b][fs][(n*K + k)*2 + s][t]
+// ------------------------------------------------------------------------------------------
+template <typename R, int NV>
+__device__ __forceinline__ void block4_reduce_to_wave0(R (&acc)[NV], R* lds /* [2][NV][64] */) {
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = threadIdx.x >> 6;
+  if (wv >= 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[((wv - 2) * NV + i) * WAVE + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wv < 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] += lds[(wv * NV + i) * WAVE + lane];
+  }
+  __syncthreads();
+  if (wv == 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[i * WAVE + lane] = acc[i];
+  }
+  __syncthreads();
+  if (wv == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] += lds[i * WAVE + lane];
+  }
+}
+
+template <typename R, int M, bool K4>
+__global__ void __launch_bounds__(256) ilrma_act_partial_kernel(NmfArgs<R> a) {
+  constexpr int N = M;
+  constexpr int NV = 2 * N * KU;
+  __shared__ R lds[2 * NV * WAVE];
+  const int tb_ = blockIdx.x, fs = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int F = a.d.F, T = a.d.T, K = a.d.K;
+  const size_t FT = (size_t)F * T;
+  const int t = tb_ * WAVE + lane;
+  const bool valid = t < T;
+  const int tc = valid ? t : T - 1;
+  const int f0 = fs * a.chunk, f1 = min(F, f0 + a.chunk);
+  const Cx<R>* xb = a.X + (size_t)b * M * FT + tc;
+
+  const int nchunks = K4 ? 1 : (K + KU - 1) / KU;
+  for (int c = 0; c < nchunks; ++c) {
+    const int k0 = c * KU;
+    R acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0;
+    R v[N][KU];
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) {
+        const int k = K4 ? min(kk, K - 1) : min(k0 + kk, K - 1);
+        v[n][kk] = a.V[(((size_t)b * N + n) * K + k) * T + tc];
+      }
+    for (int f = f0 + wv; f < f1; f += 4) {
+      Cx<R> w[M][M];
+      load_filter<R, M>(a.W, (size_t)b * F + f, w);
+      Cx<R> x[M], y[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = xb[m * FT + (size_t)f * T];
+      demix<R, M>(w, x, y);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const R P = cabs2(y[n]);
+        const R* tbn = a.Tb + (((size_t)b * N + n) * F + f) * K;
+        R tk[KU];
+        R tv = 0;
+        if (K4) {
+#pragma unroll
+          for (int kk = 0; kk < KU; ++kk) {
+            tk[kk] = (kk < K) ? tbn[kk] : (R)0;
+            tv = fma(tk[kk], v[n][kk], tv);
+          }
+        } else {
+          const R* vb = a.V + ((size_t)b * N + n) * K * T + tc;
+          for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
+#pragma unroll
+          for (int kk = 0; kk < KU; ++kk) tk[kk] = (k0 + kk < K) ? tbn[k0 + kk] : (R)0;
+        }
+        tv = floor_eps<R>(tv, a.eps);
+        const R inv = (R)1 / tv;
+        const R D = (a.p1.mode == POW_SQUARE) ? P * inv * inv : P / powspec<R>(tv, a.p1);
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+          acc[(n * KU + kk) * 2 + 0] = fma(tk[kk], D, acc[(n * KU + kk) * 2 + 0]);
+          acc[(n * KU + kk) * 2 + 1] = fma(tk[kk], inv, acc[(n * KU + kk) * 2 + 1]);
+        }
+      }
+    }
+    block4_reduce_to_wave0<R, NV>(acc, lds);
+    if (wv == 0 && valid) {
+      R* out = a.part + ((size_t)b * a.S + fs) * (size_t)(N * K * 2) * T + t;
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+          const int k = k0 + kk;
+          if (k < K) {
+            out[(size_t)((n * K + k) * 2 + 0) * T] = acc[(n * KU + kk) * 2 + 0];
+            out[(size_t)((n * K + k) * 2 + 1) * T] = acc[(n * KU + kk) * 2 + 1];
+          }
+        }
+    }
+    __syncthreads();
+  }
+}
+
+// V *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:426-428)
+template <typename R>
+__global__ void __launch_bounds__(256) ilrma_act_finalize_kernel(const R* __restrict__ part, R* __restrict__ V,
+                                                                int B, int N, int K, int T, int FS, R eps, PowSpec p2) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)B * N * K * T;
+  if (idx >= total) return;
+  const int t = idx % T;
+  const int nk = (idx / T) % (N * K);
+  const int b = idx / ((size_t)T * N * K);
+  R num = 0, den = 0;
+  for (int fs = 0; fs < FS; ++fs) {
+    const R* p = part + (((size_t)b * FS + fs) * (size_t)(N * K * 2) + nk * 2) * T + t;
+    num += p[0];
+    den += p[T];
+  }
+  den = floor_eps<R>(den, eps);
+  V[idx] = V[idx] * powspec<R>(num / den, p2);
+}
+
+// ------------------------------------------------------------------------------------------
+// generic deterministic reduction: out[g] = scale * sum_l in[g][l]   (one workgroup per g)
+// ------------------------------------------------------------------------------------------
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(REDUCE_THREADS) sum_reduce_kernel(const TI* __restrict__ in, TO* __restrict__ out,
+                                                                   size_t L, double scale) {
+  __shared__ double sm[REDUCE_THREADS];
+  const TI* p = in + (size_t)blockIdx.x * L;
+  double s = 0.0;
+  for (size_t i = threadIdx.x; i < L; i += REDUCE_THREADS) s += (double)p[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = REDUCE_THREADS / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = (TO)(sm[0] * scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// (a6) power statistic, direct pass: part[b][n][ts*F + f] = sum_t |y_n|^2
+// ------------------------------------------------------------------------------------------
+template <typename R, int M>
+__global__ void __launch_bounds__(64) power_partial_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                          R* __restrict__ part, Dims d, int TS, int tchunk) {
+  constexpr int N = M;
+  constexpr int NV = next_pow2_c(N);
+  const int f = blockIdx.x / TS, ts = blockIdx.x % TS, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const size_t FT = (size_t)d.F * d.T;
+  const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * d.T;
+  Cx<R> w[M][M];
+  load_filter<R, M>(W, (size_t)b * d.F + f, w);
+  R acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0;
+  const int t0 = ts * tchunk, t1 = min(d.T, t0 + tchunk);
+  for (int t = t0 + lane; t < t1; t += WAVE) {
+    Cx<R> x[M], y[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
+    demix<R, M>(w, x, y);
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] += cabs2(y[n]);
+  }
+  R tot = wave_reduce_scatter<R, NV>(acc);
+  const int i = scatter_index<NV>();
+  if (scatter_leader<NV>() && i < N) part[((size_t)b * N + i) * ((size_t)TS * d.F) + (size_t)ts * d.F + f] = tot;
+}
+
+// power from the plain covariance: part[b][n][f] = Re(w_n^H-form) = sum_{m,l} W[n,m] conj(W[n,l]) C[m,l]  (x T outside)
+template <typename R, int M>
+__global__ void __launch_bounds__(256) power_cov_kernel(const Cx<R>* __restrict__ C, const Cx<R>* __restrict__ W,
+                                                       double* __restrict__ part, int B, int F) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F * M) return;
+  const int n = idx % M;
+  const int bf = idx / M;
+  const int b = bf / F, f = bf % F;
+  const Cx<R>* c = C + (size_t)bf * M * M;
+  const Cx<R>* w = W + (size_t)bf * M * M + n * M;
+  double s = 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m)
+#pragma unroll
+    for (int l = 0; l < M; ++l) {
+      // W[n,m] C[m,l] conj(W[n,l])  (real part; the sum is real because C is Hermitian)
+      const double wr = w[m].x, wi = w[m].y, vr = w[l].x, vi = w[l].y, cr = c[m * M + l].x, ci = c[m * M + l].y;
+      const double ar = wr * cr - wi * ci, ai = wr * ci + wi * cr;
+      s += ar * vr + ai * vi;
+    }
+  part[((size_t)b * M + n) * F + f] = s;
+}
+
+// 'power' normalisation (ilrma.py:304-322)
+template <typename R>
+__global__ void __launch_bounds__(256) normalize_power_kernel(Cx<R>* __restrict__ W, R* __restrict__ Tb,
+                                                             const R* __restrict__ power, int B, int M, int F, int K,
+                                                             R eps, PowSpec pd /* a**domain */) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nW = (size_t)B * F * M * M, nT = (size_t)B * M * F * K;
+  if (idx < nW) {
+    const int n = (idx / M) % M;
+    const int b = idx / ((size_t)F * M * M);
+    R a = floor_eps<R>(sqrt(power[b * M + n]), eps);
+    W[idx] = cmake<R>(W[idx].x / a, W[idx].y / a);
+  } else if (idx < nW + nT) {
+    const size_t j = idx - nW;
+    const int n = (j / ((size_t)F * K)) % M;
+    const int b = j / ((size_t)F * K * M);
+    R a = floor_eps<R>(sqrt(power[b * M + n]), eps);
+    Tb[j] = Tb[j] / powspec<R>(a, pd);
+  }
+}
+
+// 'projection-back' normalisation (ilrma.py:323-330)
+template <typename R>
+__global__ void __launch_bounds__(256) normalize_pb_kernel(Cx<R>* __restrict__ W, R* __restrict__ Tb,
+                                                          const Cx<R>* __restrict__ scale, int B, int M, int F, int K,
+                                                          PowSpec pd) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nW = (size_t)B * F * M * M, nT = (size_t)B * M * F * K;
+  if (idx < nW) {
+    const int n = (idx / M) % M;
+    const int f = (idx / ((size_t)M * M)) % F;
+    const int b = idx / ((size_t)F * M * M);
+    W[idx] = cmul(W[idx], scale[((size_t)b * M + n) * F + f]);
+  } else if (idx < nW + nT) {
+    const size_t j = idx - nW;
+    const int f = (j / K) % F;
+    const int n = (j / ((size_t)F * K)) % M;
+    const int b = j / ((size_t)F * K * M);
+    const Cx<R> s = scale[((size_t)b * M + n) * F + f];
+    const R mag = (R)hypot((double)s.x, (double)s.y);
+    Tb[j] = Tb[j] * powspec<R>(mag, pd);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// (a7) ILRMA negative log-likelihood partials: part[b][ts*F + f] (double)
+// ------------------------------------------------------------------------------------------
+template <int M, typename R>
+__device__ __forceinline__ double neg2T_logabsdet(const Cx<R>* __restrict__ W, size_t bf, int T) {
+  Cd A[M][M];
+  const Cx<R>* p = W + bf * (M * M);
+#pragma unroll
+  for (int n = 0; n < M; ++n)
+#pragma unroll
+    for (int m = 0; m < M; ++m) A[n][m] = cmake<double>((double)p[n * M + m].x, (double)p[n * M + m].y);
+  Cd det = lu_det<M>(A);
+  return -2.0 * (double)T * log(hypot(det.x, det.y));
+}
+
+template <typename R, int M, bool K4>
+__global__ void __launch_bounds__(64) ilrma_loss_partial_kernel(NmfArgs<R> a, double* __restrict__ lpart, PowSpec p2d) {
+  constexpr int N = M;
+  const int f = blockIdx.x / a.S, ts = blockIdx.x % a.S, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const int F = a.d.F, T = a.d.T, K = a.d.K;
+  const size_t FT = (size_t)F * T;
+  const Cx<R>* xb = a.X + (size_t)b * M * FT + (size_t)f * T;
+  Cx<R> w[M][M];
+  load_filter<R, M>(a.W, (size_t)b * F + f, w);
+  const R* tbase = a.Tb + ((size_t)b * N * F + f) * K;
+  double acc = 0.0;
+  const int t0 = ts * a.chunk, t1 = min(T, t0 + a.chunk);
+  for (int t = t0 + lane; t < t1; t += WAVE) {
+    Cx<R> x[M], y[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
+    demix<R, M>(w, x, y);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const R* vb = a.V + ((size_t)b * N + n) * K * T + t;
+      const R* tbn = tbase + (size_t)n * F * K;
+      R tv = 0;
+      if (K4) {
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) tv = fma((kk < K) ? tbn[kk] : (R)0, vb[(size_t)min(kk, K - 1) * T], tv);
+      } else {
+        for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
+      }
+      const R r = floor_eps<R>(powspec<R>(tv, p2d), a.eps);
+      acc += (double)(cabs2(y[n]) / r) + log((double)r);
+    }
+  }
+  acc = wave_allreduce_sum<double>(acc);
+  if (lane == 0) {
+    if (ts == 0) acc += neg2T_logabsdet<M, R>(a.W, (size_t)b * F + f, T);
+    lpart[(size_t)b * ((size_t)a.S * F) + (size_t)ts * F + f] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// AuxIVA: s[b,n,t] = sum_f |y_n(f,t)|^2 partials over f-splits: part[b][fs][n][t]
+// ------------------------------------------------------------------------------------------
+template <typename R, int M>
+__global__ void __launch_bounds__(256) auxiva_stat_partial_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                                 R* __restrict__ part, Dims d, int FS, int fchunk) {
+  constexpr int N = M;
+  __shared__ R lds[2 * N * WAVE];
+  const int tb_ = blockIdx.x, fs = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int F = d.F, T = d.T;
+  const size_t FT = (size_t)F * T;
+  const int t = tb_ * WAVE + lane;
+  const bool valid = t < T;
+  const int tc = valid ? t : T - 1;
+  const int f0 = fs * fchunk, f1 = min(F, f0 + fchunk);
+  const Cx<R>* xb = X + (size_t)b * M * FT + tc;
+  R acc[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) acc[n] = 0;
+  for (int f = f0 + wv; f < f1; f += 4) {
+    Cx<R> w[M][M];
+    load_filter<R, M>(W, (size_t)b * F + f, w);
+    Cx<R> x[M], y[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + (size_t)f * T];
+    demix<R, M>(w, x, y);
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] += cabs2(y[n]);
+  }
+  block4_reduce_to_wave0<R, N>(acc, lds);
+  if (wv == 0 && valid) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) part[(((size_t)b * FS + fs) * N + n) * T + t] = acc[n];
+  }
+}
+
+// r = sqrt(s) (Laplace, iva.py:490) | s / F (Gauss, iva.py:723); loss data term per block -> lpart[b][blk]
+template <typename R>
+__global__ void __launch_bounds__(256) auxiva_stat_finalize_kernel(const R* __restrict__ part, R* __restrict__ r,
+                                                                  double* __restrict__ lpart, int N, int F, int T,
+                                                                  int FS, int kind, R eps, int lstride) {
+  __shared__ double sm[256];
+  const int b = blockIdx.y;
+  const size_t NT = (size_t)N * T;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double term = 0.0;
+  if (idx < NT) {
+    R s = 0;
+    for (int fs = 0; fs < FS; ++fs) s += part[((size_t)b * FS + fs) * NT + idx];
+    R rv;
+    if (kind == ASSX_IVA_LAPLACE) {
+      rv = sqrt(s);
+      term = 2.0 * (double)rv;                       // iva.py:615-617
+    } else {
+      rv = s / (R)F;
+      term = (double)F * log((double)floor_eps<R>(rv, eps));  // iva.py:797-800
+    }
+    r[(size_t)b * NT + idx] = rv;
+  }
+  if (lpart) {
+    sm[threadIdx.x] = term;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) lpart[(size_t)b * lstride + blockIdx.x] = sm[0];
+  }
+}
+
+template <typename R, int M>
+__global__ void __launch_bounds__(64) logdet_kernel(const Cx<R>* __restrict__ W, double* __restrict__ lpart, int B, int F,
+                                                   int T, int lstride, int offset) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F) return;
+  const int b = idx / F, f = idx % F;
+  lpart[(size_t)b * lstride + offset + f] = neg2T_logabsdet<M, R>(W, (size_t)idx, T);
+}
+
+// ------------------------------------------------------------------------------------------
+// (a8) projection back statistics: per (b,f): G = sum_t y y^H (packed Hermitian, N*N reals) and
+//      c[j] = sum_t x_ref conj(y_j) (2N reals).  DEMIX: y = W x on the fly, x_ref = X[ref];
+//      otherwise y = Y rows and x_ref = reference row.
+// ------------------------------------------------------------------------------------------
+template <typename R, int M, bool DEMIX>
+__global__ void __launch_bounds__(64) pb_stat_partial_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                            const Cx<R>* __restrict__ refsig, int ref,
+                                                            R* __restrict__ part, Dims d, int TS, int tchunk) {
+  constexpr int N = M;
+  constexpr int HM = N * N;
+  constexpr int NS = HM + 2 * N;
+  constexpr int NV = next_pow2_c(NS);
+  const int f = blockIdx.x / TS, ts = blockIdx.x % TS, b = blockIdx.y;
+  const int lane = threadIdx.x;
+  const size_t FT = (size_t)d.F * d.T;
+  const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * d.T;
+  Cx<R> w[M][M];
+  if (DEMIX) load_filter<R, M>(W, (size_t)b * d.F + f, w);
+  R acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0;
+  const int t0 = ts * tchunk, t1 = min(d.T, t0 + tchunk);
+  for (int t = t0 + lane; t < t1; t += WAVE) {
+    Cx<R> x[M], y[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
+    Cx<R> xr;
+    if (DEMIX) {
+      demix<R, M>(w, x, y);
+      xr = xb[(size_t)ref * FT + t];
+    } else {
+#pragma unroll
+      for (int n = 0; n < N; ++n) y[n] = x[n];
+      xr = refsig[(size_t)b * FT + (size_t)f * d.T + t];
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] += cabs2(y[n]);
+#pragma unroll
+    for (int m = 0; m < N; ++m)
+#pragma unroll
+      for (int l = m + 1; l < N; ++l) {
+        Cx<R> q = cmulc(y[m], y[l]);
+        acc[herm_pair_base<N>(m, l)] += q.x;
+        acc[herm_pair_base<N>(m, l) + 1] += q.y;
+      }
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+      Cx<R> q = cmulc(xr, y[j]);
+      acc[HM + 2 * j] += q.x;
+      acc[HM + 2 * j + 1] += q.y;
+    }
+  }
+  R tot = wave_reduce_scatter<R, NV>(acc);
+  const int i = scatter_index<NV>();
+  if (scatter_leader<NV>() && i < NS) part[(((size_t)b * TS + ts) * d.F + f) * NS + i] = tot;
+}
+
+// scale[b,n,f] = (c G^{-1})[n]   (projection_back.py:18-21); one lane per (b,f), float64
+template <typename R, int M>
+__global__ void __launch_bounds__(64) pb_solve_kernel(const R* __restrict__ part, Cx<R>* __restrict__ scale,
+                                                     int32_t* __restrict__ status, int B, int F, int TS) {
+  constexpr int N = M;
+  constexpr int HM = N * N;
+  constexpr int NS = HM + 2 * N;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F) return;
+  const int b = idx / F, f = idx % F;
+  double s[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) s[i] = 0.0;
+  for (int ts = 0; ts < TS; ++ts) {
+    const R* p = part + (((size_t)b * TS + ts) * F + f) * NS;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] += (double)p[i];
+  }
+  Cd G[N][N];
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    G[m][m] = cmake<double>(s[m], 0.0);
+#pragma unroll
+    for (int l = m + 1; l < N; ++l) {
+      const int base = herm_pair_base<N>(m, l);
+      G[m][l] = cmake<double>(s[base], s[base + 1]);
+      G[l][m] = cmake<double>(s[base], -s[base + 1]);
+    }
+  }
+  const bool ok = gj_inverse<N>(G, nullptr);
+  if (!ok && status) atomicOr(&status[b], (int)ASSX_STATUS_SINGULAR);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    Cd a = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int j = 0; j < N; ++j) cfma(a, cmake<double>(s[HM + 2 * j], s[HM + 2 * j + 1]), G[j][n]);
+    scale[((size_t)b * N + n) * F + f] = cmake<R>((R)a.x, (R)a.y);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host-side launch helpers
+// ------------------------------------------------------------------------------------------
+inline int env_int(const char* name, int dflt) {
+  const char* s = getenv(name);
+  return (s && *s) ? atoi(s) : dflt;
+}
+
+// number of t-splits for the wave-per-(b,f,ts) kernels: aim at >= ~8 waves per SIMD chip-wide
+inline void t_split(int B, int F, int T, int* TS, int* tchunk) {
+  static const int target = env_int("ASSX_TARGET_WAVES", 8192);
+  static const int forced = env_int("ASSX_TS", 0);
+  int ts = forced > 0 ? forced : (int)((target + (size_t)B * F - 1) / ((size_t)B * F));
+  int max_ts = (T + 255) / 256;  // at least 4 frames per lane
+  if (ts > max_ts) ts = max_ts;
+  if (ts < 1) ts = 1;
+  int chunk = (T + ts - 1) / ts;
+  chunk = (chunk + WAVE - 1) / WAVE * WAVE;
+  ts = (T + chunk - 1) / chunk;
+  *TS = ts;
+  *tchunk = chunk;
+}
+
+inline void f_split(int B, int F, int T, int* FS, int* fchunk) {
+  static const int target = env_int("ASSX_TARGET_WGS", 1024);
+  static const int forced = env_int("ASSX_FS", 0);
+  const int TB = (T + WAVE - 1) / WAVE;
+  int fs = forced > 0 ? forced : (int)((target + (size_t)B * TB - 1) / ((size_t)B * TB));
+  int max_fs = (F + 7) / 8;  // at least 2 bins per wave
+  if (fs > max_fs) fs = max_fs;
+  if (fs < 1) fs = 1;
+  int chunk = (F + fs - 1) / fs;
+  fs = (F + chunk - 1) / chunk;
+  *FS = fs;
+  *fchunk = chunk;
+}
+
+struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte aligned
+  size_t part;     // reduction partials (largest user: activation update)
+  size_t u;        // dense U (B,N,F,M,M) complex
+  size_t lpart;    // double partials for losses / power
+  size_t small;    // (B,N) reals etc.
+  size_t total;
+};
+
+inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
+  const size_t r = dtype == ASSX_F64 ? 8 : 4;
+  const int Kc = K < 1 ? 1 : K;
+  int TS, tchunk, FS, fchunk;
+  t_split(B, F, T, &TS, &tchunk);
+  f_split(B, F, T, &FS, &fchunk);
+  size_t p_cov = (size_t)B * TS * F * (M * M * M);
+  size_t p_basis = (size_t)B * TS * F * (M * Kc * 2);
+  size_t p_act = (size_t)B * FS * (M * Kc * 2) * T;
+  size_t p_pb = (size_t)B * TS * F * (M * M + 2 * M);
+  size_t p_pow = (size_t)B * M * TS * F;
+  size_t p_aux = (size_t)B * FS * M * T;
+  size_t pmax = p_cov;
+  if (p_basis > pmax) pmax = p_basis;
+  if (p_act > pmax) pmax = p_act;
+  if (p_pb > pmax) pmax = p_pb;
+  if (p_pow > pmax) pmax = p_pow;
+  if (p_aux > pmax) pmax = p_aux;
+  WsLayout L;
+  L.part = 0;
+  size_t off = align_up(pmax * r, 256);
+  L.u = off;
+  off += align_up((size_t)B * M * F * M * M * 2 * r, 256);
+  L.lpart = off;
+  size_t nl = (size_t)B * ((size_t)TS * F + (size_t)M * F + (size_t)(M * T + 255) / 256 + F + 16);
+  off += align_up(nl * 8, 256);
+  L.small = off;
+  off += align_up((size_t)B * (M + 8) * 8, 256);
+  L.total = off;
+  return L;
+}
+
+template <typename Fn>
+int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
+  if (dtype == ASSX_F64) {
+    switch (M) {
+      case 2: return fn(double(), IntC<2>());
+      case 3: return fn(double(), IntC<3>());
+      case 4: return fn(double(), IntC<4>());
+    }
+  } else if (dtype == ASSX_F32) {
+    switch (M) {
+      case 2: return fn(float(), IntC<2>());
+      case 3: return fn(float(), IntC<3>());
+      case 4: return fn(float(), IntC<4>());
+    }
+  } else {
+    return fail(ctx, ASSX_E_ARG, "dtype must be ASSX_F32 or ASSX_F64, got %d", dtype);
+  }
+  return fail(ctx, ASSX_E_UNSUPPORTED, "only 2 <= M <= 4 channels are supported, got M=%d", M);
+}
+
+#define CHECK_COMMON(ctx, B, M, F, T)                                                        \
+  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");                              \
+  ASSX_REQUIRE(ctx, (B) >= 1 && (M) >= 1 && (F) >= 1 && (T) >= 1, ASSX_E_ARG,                 \
+               "invalid sizes B=%d M=%d F=%d T=%d", (B), (M), (F), (T))
+
+inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+// covariance (any weight kind) into dense U; returns error code
+template <typename R, int M>
+int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K, double domain,
+            double eps, void* U, void* ws, int B, int F, int T, hipStream_t st) {
+  int TS, tchunk;
+  t_split(B, F, T, &TS, &tchunk);
+  CovArgs<R> a;
+  a.X = (const Cx<R>*)X;
+  a.r = (const R*)r;
+  a.Tb = (const R*)Tb;
+  a.V = (const R*)V;
+  a.part = (R*)ws;
+  a.d = Dims{B, F, T, K};
+  a.TS = TS;
+  a.tchunk = tchunk;
+  a.eps = (R)eps;
+  a.p2d = make_pow(2.0 / domain);
+  dim3 grid((unsigned)F * TS, B), block(64);
+  const int N = (wk == WK_NONE) ? 1 : M;
+  switch (wk) {
+    case WK_NONE: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NONE, true>), grid, block, 0, st, a); break;
+    case WK_NT: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NT, true>), grid, block, 0, st, a); break;
+    case WK_NFT: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NFT, true>), grid, block, 0, st, a); break;
+    default:
+      if (K <= KU) hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_TV, true>), grid, block, 0, st, a);
+      else hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_TV, false>), grid, block, 0, st, a);
+  }
+  ASSX_LAUNCH_CHECK(ctx, "cov_partial_kernel");
+  const size_t total = (size_t)B * N * F * M * M;
+  hipLaunchKernelGGL((cov_finalize_kernel<R, M>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const R*)ws,
+                     (Cx<R>*)U, B, N, F, TS, (R)(1.0 / (double)T));
+  ASSX_LAUNCH_CHECK(ctx, "cov_finalize_kernel");
+  return 0;
+}
+
+template <typename R, int M>
+int run_ip(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int B, int F, hipStream_t st) {
+  hipLaunchKernelGGL((ip_kernel<R, M>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)U,
+                     (Cx<R>*)W, thr, status, B, F);
+  ASSX_LAUNCH_CHECK(ctx, "ip_kernel");
+  return 0;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI
+// ==========================================================================================
+extern "C" {
+
+size_t assx_workspace_bytes(int B, int M, int F, int T, int K, int dtype) {
+  if (B < 1 || M < 1 || F < 1 || T < 1) return 0;
+  return ws_layout(B, M, F, T, K, dtype).total;
+}
+
+int assx_demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y, int B, int M, int F, int T,
+               int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Y, ASSX_E_NULL, "assx_demix: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    dim3 grid(blocks_for(T, 256), F, B);
+    hipLaunchKernelGGL((demix_kernel<R, MM>), grid, dim3(256), 0, st, (const Cx<R>*)X, (const Cx<R>*)W,
+                       (const Cx<R>*)scale, (Cx<R>*)Y, Dims{B, F, T, 0});
+    ASSX_LAUNCH_CHECK(ctx, "demix_kernel");
+    return 0;
+  });
+}
+
+int assx_cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U, void* ws, int B,
+                        int M, int N, int F, int T, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && U && ws, ASSX_E_NULL, "assx_cov_accumulate: NULL array");
+  ASSX_REQUIRE(ctx, r_kind == ASSX_W_NONE || r_kind == ASSX_W_NT || r_kind == ASSX_W_NFT, ASSX_E_ARG,
+               "assx_cov_accumulate: bad r_kind %d", r_kind);
+  ASSX_REQUIRE(ctx, r_kind == ASSX_W_NONE ? (N == 1) : (N == M && r != nullptr), ASSX_E_ARG,
+               "assx_cov_accumulate: N must be 1 (unweighted) or M with weights, got N=%d M=%d", N, M);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    return run_cov<R, MM>(ctx, r_kind, X, r, nullptr, nullptr, 1, 2.0, eps, U, ws, B, F, T, st);
+  });
+}
+
+int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int32_t* status, int B, int M, int F,
+                   int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, U && W, ASSX_E_NULL, "assx_ip_update: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+  });
+}
+
+int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double domain, double eps,
+                             void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_source_update: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const PowSpec p1 = make_pow((domain + 2.0) / domain), p2 = make_pow(domain / (domain + 2.0));
+    NmfArgs<R> a;
+    a.X = (const Cx<R>*)X;
+    a.W = (const Cx<R>*)W;
+    a.Tb = (const R*)Tb;
+    a.V = (const R*)V;
+    a.part = (R*)ws;
+    a.d = Dims{B, F, T, K};
+    a.eps = (R)eps;
+    a.p1 = p1;
+    // ---- basis
+    int TS, tchunk;
+    t_split(B, F, T, &TS, &tchunk);
+    a.S = TS;
+    a.chunk = tchunk;
+    dim3 grid((unsigned)F * TS, B);
+    if (K <= KU) hipLaunchKernelGGL((ilrma_basis_partial_kernel<R, MM, true>), grid, dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((ilrma_basis_partial_kernel<R, MM, false>), grid, dim3(64), 0, st, a);
+    ASSX_LAUNCH_CHECK(ctx, "ilrma_basis_partial_kernel");
+    hipLaunchKernelGGL((ilrma_basis_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
+                       st, (const R*)ws, (R*)Tb, B, MM, F, K, TS, (R)eps, p2);
+    ASSX_LAUNCH_CHECK(ctx, "ilrma_basis_finalize_kernel");
+    // ---- activation (uses the new basis)
+    int FS, fchunk;
+    f_split(B, F, T, &FS, &fchunk);
+    a.S = FS;
+    a.chunk = fchunk;
+    dim3 grid2(blocks_for(T, WAVE), FS, B);
+    if (K <= KU) hipLaunchKernelGGL((ilrma_act_partial_kernel<R, MM, true>), grid2, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((ilrma_act_partial_kernel<R, MM, false>), grid2, dim3(256), 0, st, a);
+    ASSX_LAUNCH_CHECK(ctx, "ilrma_act_partial_kernel");
+    hipLaunchKernelGGL((ilrma_act_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
+                       (const R*)ws, (R*)V, B, MM, K, T, FS, (R)eps, p2);
+    ASSX_LAUNCH_CHECK(ctx, "ilrma_act_finalize_kernel");
+    return 0;
+  });
+}
+
+int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double domain,
+                              double eps, double threshold, void* U_out, int32_t* status, void* ws, int B, int M, int F,
+                              int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_spatial_update: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
+  hipStream_t st = (hipStream_t)stream;
+  const WsLayout L = ws_layout(B, M, F, T, K, dtype);
+  void* U = U_out ? U_out : (void*)((char*)ws + L.u);
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int rc = run_cov<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, U, ws, B, F, T, st);
+    if (rc) return rc;
+    return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+  });
+}
+
+int assx_demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* ws, int B, int M, int F, int T,
+                     int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && power && ws, ASSX_E_NULL, "assx_demix_power: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int TS, tchunk;
+    t_split(B, F, T, &TS, &tchunk);
+    hipLaunchKernelGGL((power_partial_kernel<R, MM>), dim3((unsigned)F * TS, B), dim3(64), 0, st, (const Cx<R>*)X,
+                       (const Cx<R>*)W, (R*)ws, Dims{B, F, T, 0}, TS, tchunk);
+    ASSX_LAUNCH_CHECK(ctx, "power_partial_kernel");
+    hipLaunchKernelGGL((sum_reduce_kernel<R, R>), dim3(B * MM), dim3(REDUCE_THREADS), 0, st, (const R*)ws, (R*)power,
+                       (size_t)TS * F, 1.0 / ((double)F * (double)T));
+    ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+    return 0;
+  });
+}
+
+int assx_power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power, void* ws, int B, int M, int F,
+                        int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, C && W && power && ws, ASSX_E_NULL, "assx_power_from_cov: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    double* part = (double*)ws;
+    hipLaunchKernelGGL((power_cov_kernel<R, MM>), dim3(blocks_for((size_t)B * F * MM, 256)), dim3(256), 0, st,
+                       (const Cx<R>*)C, (const Cx<R>*)W, part, B, F);
+    ASSX_LAUNCH_CHECK(ctx, "power_cov_kernel");
+    // C already carries the 1/T of the mean over frames: mean_{f,t}|y|^2 = (1/F) sum_f w^H C w
+    hipLaunchKernelGGL((sum_reduce_kernel<double, R>), dim3(B * MM), dim3(REDUCE_THREADS), 0, st, (const double*)part,
+                       (R*)power, (size_t)F, 1.0 / (double)F);
+    ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+    return 0;
+  });
+}
+
+int assx_ilrma_normalize_power(assx_ctx* ctx, void* W, void* Tb, const void* power, double domain, double eps, int B,
+                               int M, int F, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, W && Tb && power, ASSX_E_NULL, "assx_ilrma_normalize_power: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)B * F * M * M + (size_t)B * M * F * K;
+  const PowSpec pd = make_pow(domain);
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((normalize_power_kernel<double>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (Cx<double>*)W,
+                       (double*)Tb, (const double*)power, B, M, F, K, eps, pd);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((normalize_power_kernel<float>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (Cx<float>*)W,
+                       (float*)Tb, (const float*)power, B, M, F, K, (float)eps, pd);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "normalize_power_kernel");
+  return 0;
+}
+
+int assx_ilrma_normalize_pb(assx_ctx* ctx, void* W, void* Tb, const void* scale, double domain, int B, int M, int F,
+                            int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, W && Tb && scale, ASSX_E_NULL, "assx_ilrma_normalize_pb: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)B * F * M * M + (size_t)B * M * F * K;
+  const PowSpec pd = make_pow(domain);
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((normalize_pb_kernel<double>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (Cx<double>*)W,
+                       (double*)Tb, (const Cx<double>*)scale, B, M, F, K, pd);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((normalize_pb_kernel<float>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (Cx<float>*)W,
+                       (float*)Tb, (const Cx<float>*)scale, B, M, F, K, pd);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "normalize_pb_kernel");
+  return 0;
+}
+
+int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
+                    double eps, double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Tb && V && loss && ws, ASSX_E_NULL, "assx_ilrma_loss: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  hipStream_t st = (hipStream_t)stream;
+  const WsLayout L = ws_layout(B, M, F, T, K, dtype);
+  double* lpart = (double*)((char*)ws + L.lpart);
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int TS, tchunk;
+    t_split(B, F, T, &TS, &tchunk);
+    NmfArgs<R> a;
+    a.X = (const Cx<R>*)X;
+    a.W = (const Cx<R>*)W;
+    a.Tb = (const R*)Tb;
+    a.V = (const R*)V;
+    a.part = nullptr;
+    a.d = Dims{B, F, T, K};
+    a.S = TS;
+    a.chunk = tchunk;
+    a.eps = (R)eps;
+    a.p1 = make_pow(1.0);
+    const PowSpec p2d = make_pow(2.0 / domain);
+    dim3 grid((unsigned)F * TS, B);
+    if (K <= KU) hipLaunchKernelGGL((ilrma_loss_partial_kernel<R, MM, true>), grid, dim3(64), 0, st, a, lpart, p2d);
+    else hipLaunchKernelGGL((ilrma_loss_partial_kernel<R, MM, false>), grid, dim3(64), 0, st, a, lpart, p2d);
+    ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_partial_kernel");
+    hipLaunchKernelGGL((sum_reduce_kernel<double, double>), dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lpart,
+                       loss, (size_t)TS * F, 1.0);
+    ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+    return 0;
+  });
+}
+
+int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, double eps, void* r, double* loss,
+                        void* ws, int B, int M, int F, int T, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_weights: NULL array");
+  ASSX_REQUIRE(ctx, kind == ASSX_IVA_LAPLACE || kind == ASSX_IVA_GAUSS, ASSX_E_ARG, "bad AuxIVA kind %d", kind);
+  hipStream_t st = (hipStream_t)stream;
+  const WsLayout L = ws_layout(B, M, F, T, 1, dtype);
+  double* lpart = (double*)((char*)ws + L.lpart);
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int FS, fchunk;
+    f_split(B, F, T, &FS, &fchunk);
+    hipLaunchKernelGGL((auxiva_stat_partial_kernel<R, MM>), dim3(blocks_for(T, WAVE), FS, B), dim3(256), 0, st,
+                       (const Cx<R>*)X, (const Cx<R>*)W, (R*)ws, Dims{B, F, T, 0}, FS, fchunk);
+    ASSX_LAUNCH_CHECK(ctx, "auxiva_stat_partial_kernel");
+    const int nblk = (int)blocks_for((size_t)MM * T, 256);
+    const int lstride = nblk + F;
+    hipLaunchKernelGGL((auxiva_stat_finalize_kernel<R>), dim3(nblk, B), dim3(256), 0, st, (const R*)ws, (R*)r,
+                       loss ? lpart : (double*)nullptr, MM, F, T, FS, kind, (R)eps, lstride);
+    ASSX_LAUNCH_CHECK(ctx, "auxiva_stat_finalize_kernel");
+    if (loss) {
+      hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W,
+                         lpart, B, F, T, lstride, nblk);
+      ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
+      hipLaunchKernelGGL((sum_reduce_kernel<double, double>), dim3(B), dim3(REDUCE_THREADS), 0, st,
+                         (const double*)lpart, loss, (size_t)lstride, 1.0);
+      ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+    }
+    return 0;
+  });
+}
+
+int assx_auxiva_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* r, double eps, double threshold,
+                               void* U_out, int32_t* status, void* ws, int B, int M, int F, int T, int dtype,
+                               void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_spatial_update: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  const WsLayout L = ws_layout(B, M, F, T, 1, dtype);
+  void* U = U_out ? U_out : (void*)((char*)ws + L.u);
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int rc = run_cov<R, MM>(ctx, WK_NT, X, r, nullptr, nullptr, 1, 2.0, eps, U, ws, B, F, T, st);
+    if (rc) return rc;
+    return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+  });
+}
+
+int assx_projection_back_scale(assx_ctx* ctx, const void* X, const void* W, int ref, void* scale, int32_t* status,
+                               void* ws, int B, int M, int F, int T, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && scale && ws, ASSX_E_NULL, "assx_projection_back_scale: NULL array");
+  ASSX_REQUIRE(ctx, ref >= 0 && ref < M, ASSX_E_ARG, "reference_id %d out of range for %d channels", ref, M);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int TS, tchunk;
+    t_split(B, F, T, &TS, &tchunk);
+    hipLaunchKernelGGL((pb_stat_partial_kernel<R, MM, true>), dim3((unsigned)F * TS, B), dim3(64), 0, st,
+                       (const Cx<R>*)X, (const Cx<R>*)W, (const Cx<R>*)nullptr, ref, (R*)ws, Dims{B, F, T, 0}, TS,
+                       tchunk);
+    ASSX_LAUNCH_CHECK(ctx, "pb_stat_partial_kernel");
+    hipLaunchKernelGGL((pb_solve_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const R*)ws,
+                       (Cx<R>*)scale, status, B, F, TS);
+    ASSX_LAUNCH_CHECK(ctx, "pb_solve_kernel");
+    return 0;
+  });
+}
+
+int assx_projection_back(assx_ctx* ctx, const void* Y, const void* reference, void* scale, int32_t* status, void* ws,
+                         int B, int N, int F, int T, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, N, F, T);
+  ASSX_REQUIRE(ctx, Y && reference && scale && ws, ASSX_E_NULL, "assx_projection_back: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, N, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int TS, tchunk;
+    t_split(B, F, T, &TS, &tchunk);
+    hipLaunchKernelGGL((pb_stat_partial_kernel<R, MM, false>), dim3((unsigned)F * TS, B), dim3(64), 0, st,
+                       (const Cx<R>*)Y, (const Cx<R>*)nullptr, (const Cx<R>*)reference, 0, (R*)ws, Dims{B, F, T, 0}, TS,
+                       tchunk);
+    ASSX_LAUNCH_CHECK(ctx, "pb_stat_partial_kernel");
+    hipLaunchKernelGGL((pb_solve_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const R*)ws,
+                       (Cx<R>*)scale, status, B, F, TS);
+    ASSX_LAUNCH_CHECK(ctx, "pb_solve_kernel");
+    return 0;
+  });
+}
+
+}  // extern "C"

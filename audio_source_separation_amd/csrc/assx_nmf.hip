@@ -1,0 +1,406 @@
+// NMF multiplicative updates (EUC / KL / IS-mm / IS-me) for gfx950 and their C-ABI entry points.
+//
+// Reference: src/algorithm/nmf.py:182-207 (EUC), 241-266 (KL), 302-327 (IS mm), 329-356 (IS me);
+// loss: nmf.py:170-174, 229-233, 288-292 with src/criterion/divergence.py:21-45.
+//
+// One half-update =
+//   (1) terms kernel : TV = max(Tb V, eps) on the fly, writes the two (F,T) operands
+//                      A = numerator weights (X * g(TV)),  Bm = denominator weights (h(TV));
+//   (2) batched GEMM : basis  num|den = [A|Bm] V^T   (reduce over t, split-K, no atomics)
+//                      activ. num|den = Tb^T [A|Bm]  (reduce over f)
+//   (3) finalize     : sum the split-K slabs, floor the denominator, multiply-update in place.
+// The GEMM is an LDS-tiled 64x64x16 register-blocked kernel in the storage precision.
+#include "assx_common.hpp"
+
+using namespace assx;
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, TM = 4, TN = 4;
+
+struct TermSpec {
+  int kind;
+  PowSpec pa, pb;  // exponents applied to TV for the numerator / denominator weights
+};
+
+// kind/domain -> elementwise weights (only TV and the denominators are floored: nmf.py:312-316)
+inline TermSpec make_terms(int kind, double d) {
+  TermSpec s;
+  s.kind = kind;
+  switch (kind) {
+    case ASSX_NMF_EUC:  // num: X * TV^((2-d)/d)   den: TV^((4-d)/d)
+      s.pa = make_pow((2.0 - d) / d);
+      s.pb = make_pow((4.0 - d) / d);
+      break;
+    case ASSX_NMF_KL:  // num: X / TV             den: TV^((2-d)/d)
+      s.pa = make_pow(1.0);
+      s.pb = make_pow((2.0 - d) / d);
+      break;
+    default:  // IS: num: X / TV^((d+2)/d)  den: 1 / TV
+      s.pa = make_pow((d + 2.0) / d);
+      s.pb = make_pow(1.0);
+  }
+  return s;
+}
+
+inline PowSpec update_exponent(int kind, double d) {
+  switch (kind) {
+    case ASSX_NMF_EUC: return make_pow(d / (4.0 - d));
+    case ASSX_NMF_KL: return make_pow(d / 2.0);
+    case ASSX_NMF_IS_MM: return make_pow(d / (d + 2.0));
+    default: return make_pow(1.0);  // IS me: no outer power (nmf.py:345,354)
+  }
+}
+
+template <typename R>
+__device__ __forceinline__ R pow0(R x, PowSpec p) {  // x**0 == 1 exactly as numpy (domain=2 EUC/KL numerators)
+  return (p.mode == POW_GENERIC && p.e == 0.0) ? (R)1 : powspec<R>(x, p);
+}
+
+// AB (B,2,F,T): AB[b,0] = numerator weights, AB[b,1] = denominator weights
+template <typename R>
+__global__ void __launch_bounds__(256) nmf_terms_kernel(const R* __restrict__ X, const R* __restrict__ Tb,
+                                                       const R* __restrict__ V, R* __restrict__ AB, int F, int T, int K,
+                                                       R eps, TermSpec s) {
+  const int f = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const R* tb = Tb + ((size_t)b * F + f) * K;
+  const R* vb = V + (size_t)b * K * T + t;
+  R tv = 0;
+  for (int k = 0; k < K; ++k) tv = fma(tb[k], vb[(size_t)k * T], tv);
+  tv = floor_eps<R>(tv, eps);
+  const R x = X[((size_t)b * F + f) * T + t];
+  R a, bm;
+  if (s.kind == ASSX_NMF_EUC) {
+    a = x * pow0<R>(tv, s.pa);
+    bm = pow0<R>(tv, s.pb);
+  } else if (s.kind == ASSX_NMF_KL) {
+    a = x / tv;
+    bm = pow0<R>(tv, s.pb);
+  } else {
+    a = x / pow0<R>(tv, s.pa);
+    bm = (R)1 / tv;
+  }
+  const size_t FT = (size_t)F * T;
+  R* o = AB + (size_t)b * 2 * FT + (size_t)f * T + t;
+  o[0] = a;
+  o[FT] = bm;
+}
+
+// Batched tiled GEMM:  C[z][m][n] = sum_k A[z][m,k] * Bop[z][k,n]  over the k-range of this split.
+//   A element (m,k)  at A  + z_a(z) + m*sam + k*sak      Bop element (k,n) at Bm + z_b(z) + k*sbk + n*sbn
+//   Cpart[split][z][m][n]
+struct GemmArgs {
+  const void* A;
+  const void* Bm;
+  void* C;
+  int Mg, Ng, Kg;
+  long sam, sak, sbk, sbn;
+  long za_outer, za_inner, zb_outer, zb_inner;  // batch z = outer*2 + inner
+  int Z, splits, kchunk;
+};
+
+template <typename R, bool A_KCONTIG, bool B_KCONTIG>
+__global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g) {
+  __shared__ R As[BK][BM + 4];
+  __shared__ R Bs[BK][BN + 4];
+  const int z = blockIdx.z % g.Z, split = blockIdx.z / g.Z;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x;
+  const int tx = tid % (BN / TN), ty = tid / (BN / TN);  // 16 x 16 threads, each TM x TN outputs
+  const R* A = (const R*)g.A + (z / 2) * g.za_outer + (z % 2) * g.za_inner;
+  const R* Bp = (const R*)g.Bm + (z / 2) * g.zb_outer + (z % 2) * g.zb_inner;
+  const int k_begin = split * g.kchunk;
+  const int k_end = min(g.Kg, k_begin + g.kchunk);
+  R acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = 0;
+
+  for (int k0 = k_begin; k0 < k_end; k0 += BK) {
+    // stage A tile (BM x BK) and B tile (BK x BN); 1024 elements each, 4 per thread
+#pragma unroll
+    for (int e = 0; e < (BM * BK) / 256; ++e) {
+      const int i = tid + e * 256;
+      int mm, kk;
+      if (A_KCONTIG) {
+        kk = i % BK;
+        mm = i / BK;
+      } else {
+        mm = i % BM;
+        kk = i / BM;
+      }
+      const int m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < g.Mg && k < k_end) ? A[(long)m * g.sam + (long)k * g.sak] : (R)0;
+    }
+#pragma unroll
+    for (int e = 0; e < (BN * BK) / 256; ++e) {
+      const int i = tid + e * 256;
+      int nn, kk;
+      if (B_KCONTIG) {
+        kk = i % BK;
+        nn = i / BK;
+      } else {
+        nn = i % BN;
+        kk = i / BN;
+      }
+      const int n = n0 + nn, k = k0 + kk;
+      Bs[kk][nn] = (n < g.Ng && k < k_end) ? Bp[(long)k * g.sbk + (long)n * g.sbn] : (R)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      R a[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = As[kk][ty * TM + i];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[kk][tx * TN + j];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = fma(a[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  R* C = (R*)g.C + ((size_t)split * g.Z + z) * (size_t)g.Mg * g.Ng;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + ty * TM + i;
+    if (m >= g.Mg) continue;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + tx * TN + j;
+      if (n < g.Ng) C[(size_t)m * g.Ng + n] = acc[i][j];
+    }
+  }
+}
+
+// out[b][i] *= (num / max(den, eps)) ** p ;  part[split][b*2 + s][i]
+template <typename R>
+__global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__ part, R* __restrict__ out, int B,
+                                                          size_t count, int splits, R eps, PowSpec p) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * count) return;
+  const size_t b = idx / count, i = idx % count;
+  R num = 0, den = 0;
+  for (int s = 0; s < splits; ++s) {
+    const R* q = part + ((size_t)s * B * 2 + b * 2) * count + i;
+    num += q[0];
+    den += q[count];
+  }
+  den = floor_eps<R>(den, eps);
+  out[idx] = out[idx] * powspec<R>(num / den, p);
+}
+
+// loss partials: lpart[b][f*nblk_t + blk]
+template <typename R>
+__global__ void __launch_bounds__(256) nmf_loss_kernel(const R* __restrict__ X, const R* __restrict__ Tb,
+                                                      const R* __restrict__ V, double* __restrict__ lpart, int F, int T,
+                                                      int K, int kind, double eps, PowSpec p2d) {
+  __shared__ double sm[256];
+  const int f = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double term = 0.0;
+  if (t < T) {
+    const R* tb = Tb + ((size_t)b * F + f) * K;
+    const R* vb = V + (size_t)b * K * T + t;
+    R tv = 0;
+    for (int k = 0; k < K; ++k) tv = fma(tb[k], vb[(size_t)k * T], tv);
+    const double in = (double)powspec<R>(tv, p2d);      // (T V) ** (2 / domain), not floored
+    const double x = (double)X[((size_t)b * F + f) * T + t];
+    if (kind == ASSX_NMF_EUC) {
+      term = (x - in) * (x - in);
+    } else {
+      const double _in = in + eps, _tg = x + eps;       // divergence.py:26-27, 39-40
+      const double ratio = _tg / _in;
+      term = (kind == ASSX_NMF_KL) ? _tg * log(ratio) + _in - _tg : ratio - log(ratio) - 1.0;
+    }
+  }
+  sm[threadIdx.x] = term;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lpart[((size_t)b * F + f) * gridDim.x + blockIdx.x] = sm[0];
+}
+
+__global__ void __launch_bounds__(256) sum_reduce_f64_kernel(const double* __restrict__ in, double* __restrict__ out,
+                                                            size_t L) {
+  __shared__ double sm[256];
+  const double* p = in + (size_t)blockIdx.x * L;
+  double s = 0.0;
+  for (size_t i = threadIdx.x; i < L; i += 256) s += p[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = sm[0];
+}
+
+inline unsigned nblocks(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+inline int pick_splits(int tiles, int Kg) {
+  int s = (768 + tiles - 1) / tiles;  // aim at ~3 workgroups per CU
+  int max_s = (Kg + 4 * BK - 1) / (4 * BK);
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  return s;
+}
+
+struct NmfWs {
+  size_t ab, part, lpart, total;
+};
+
+inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
+  const size_t r = dtype == ASSX_F64 ? 8 : 4;
+  NmfWs w;
+  w.ab = 0;
+  size_t off = align_up((size_t)B * 2 * F * T * r, 256);
+  w.part = off;
+  // split-K slabs: basis (2B, F, K) x splits_t ; activation (2B, K, T) x splits_f  (bounded above)
+  const size_t tiles_b = (size_t)((F + BM - 1) / BM) * ((K + BN - 1) / BN) * 2 * B;
+  const size_t tiles_a = (size_t)((K + BM - 1) / BM) * ((T + BN - 1) / BN) * 2 * B;
+  const size_t sb = pick_splits((int)tiles_b, T), sa = pick_splits((int)tiles_a, F);
+  size_t pmax = sb * 2 * B * F * K;
+  if (sa * 2 * B * K * T > pmax) pmax = sa * 2 * B * K * T;
+  off += align_up(pmax * r, 256);
+  w.lpart = off;
+  off += align_up((size_t)B * F * ((T + 255) / 256) * 8, 256);
+  w.total = off;
+  return w;
+}
+
+template <typename R>
+int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
+                    int B, int F, int T, int K, int dtype, hipStream_t st) {
+  const NmfWs L = nmf_ws(B, F, T, K, dtype);
+  R* AB = (R*)((char*)ws + L.ab);
+  R* part = (R*)((char*)ws + L.part);
+  const TermSpec ts = make_terms(kind, domain);
+  const PowSpec pe = update_exponent(kind, domain);
+  const size_t FT = (size_t)F * T;
+  dim3 tgrid(nblocks(T, 256), F, B);
+
+  // ---------------- basis: num|den (F,K) = [A|Bm] (F,T) . V^T (T,K)
+  hipLaunchKernelGGL((nmf_terms_kernel<R>), tgrid, dim3(256), 0, st, (const R*)X, (const R*)Tb, (const R*)V, AB, F, T, K,
+                     (R)eps, ts);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_terms_kernel");
+  {
+    GemmArgs g;
+    g.A = AB;
+    g.Bm = V;
+    g.C = part;
+    g.Mg = F;
+    g.Ng = K;
+    g.Kg = T;
+    g.sam = T;
+    g.sak = 1;        // A[m=f][k=t]
+    g.sbk = 1;
+    g.sbn = T;        // Bop[k=t][n=kb] = V[kb][t]
+    g.za_outer = 2 * (long)FT;
+    g.za_inner = (long)FT;
+    g.zb_outer = (long)K * T;
+    g.zb_inner = 0;
+    g.Z = 2 * B;
+    const int tiles = ((F + BM - 1) / BM) * ((K + BN - 1) / BN) * g.Z;
+    g.splits = pick_splits(tiles, T);
+    g.kchunk = ((T + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+    g.splits = (T + g.kchunk - 1) / g.kchunk;
+    dim3 grid((K + BN - 1) / BN, (F + BM - 1) / BM, g.Z * g.splits);
+    hipLaunchKernelGGL((gemm_tile_kernel<R, true, true>), grid, dim3(256), 0, st, g);
+    ASSX_LAUNCH_CHECK(ctx, "gemm_tile_kernel(basis)");
+    hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 256)), dim3(256), 0, st,
+                       (const R*)part, (R*)Tb, B, (size_t)F * K, g.splits, (R)eps, pe);
+    ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
+  }
+  // ---------------- activation (new basis): num|den (K,T) = Tb^T (K,F) . [A|Bm] (F,T)
+  hipLaunchKernelGGL((nmf_terms_kernel<R>), tgrid, dim3(256), 0, st, (const R*)X, (const R*)Tb, (const R*)V, AB, F, T, K,
+                     (R)eps, ts);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_terms_kernel");
+  {
+    GemmArgs g;
+    g.A = Tb;
+    g.Bm = AB;
+    g.C = part;
+    g.Mg = K;
+    g.Ng = T;
+    g.Kg = F;
+    g.sam = 1;
+    g.sak = K;        // A[m=kb][k=f] = Tb[f][kb]
+    g.sbk = T;
+    g.sbn = 1;        // Bop[k=f][n=t] = AB[f][t]
+    g.za_outer = (long)F * K;
+    g.za_inner = 0;
+    g.zb_outer = 2 * (long)FT;
+    g.zb_inner = (long)FT;
+    g.Z = 2 * B;
+    const int tiles = ((K + BM - 1) / BM) * ((T + BN - 1) / BN) * g.Z;
+    g.splits = pick_splits(tiles, F);
+    g.kchunk = ((F + g.splits - 1) / g.splits + BK - 1) / BK * BK;
+    g.splits = (F + g.kchunk - 1) / g.kchunk;
+    dim3 grid((T + BN - 1) / BN, (K + BM - 1) / BM, g.Z * g.splits);
+    hipLaunchKernelGGL((gemm_tile_kernel<R, false, false>), grid, dim3(256), 0, st, g);
+    ASSX_LAUNCH_CHECK(ctx, "gemm_tile_kernel(activation)");
+    hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 256)), dim3(256), 0, st,
+                       (const R*)part, (R*)V, B, (size_t)K * T, g.splits, (R)eps, pe);
+    ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t assx_nmf_workspace_bytes(int B, int F, int T, int K, int dtype) {
+  if (B < 1 || F < 1 || T < 1 || K < 1) return 0;
+  return nmf_ws(B, F, T, K, dtype).total;
+}
+
+int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
+                    int B, int F, int T, int K, int dtype, void* stream) {
+  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
+  ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
+  ASSX_REQUIRE(ctx, X && Tb && V && ws, ASSX_E_NULL, "assx_nmf_update: NULL array");
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_IS_ME, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
+  ASSX_REQUIRE(ctx, kind != ASSX_NMF_IS_ME || domain == 2.0, ASSX_E_ARG, "Only domain = 2 is supported (IS me).");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == ASSX_F64) return nmf_update_impl<double>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+  if (dtype == ASSX_F32) return nmf_update_impl<float>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+  return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+}
+
+int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void* X, const void* Tb, const void* V,
+                  double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
+  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
+  ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
+  ASSX_REQUIRE(ctx, X && Tb && V && loss && ws, ASSX_E_NULL, "assx_nmf_loss: NULL array");
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_IS_ME, ASSX_E_ARG, "bad NMF kind %d", kind);
+  hipStream_t st = (hipStream_t)stream;
+  const NmfWs L = nmf_ws(B, F, T, K, dtype);
+  double* lpart = (double*)((char*)ws + L.lpart);
+  const PowSpec p2d = make_pow(2.0 / domain);
+  const int k2 = (kind == ASSX_NMF_IS_ME) ? ASSX_NMF_IS_MM : kind;
+  dim3 grid(nblocks(T, 256), F, B);
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((nmf_loss_kernel<double>), grid, dim3(256), 0, st, (const double*)X, (const double*)Tb,
+                       (const double*)V, lpart, F, T, K, k2, eps, p2d);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((nmf_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)X, (const float*)Tb,
+                       (const float*)V, lpart, F, T, K, k2, eps, p2d);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_loss_kernel");
+  hipLaunchKernelGGL(sum_reduce_f64_kernel, dim3(B), dim3(256), 0, st, (const double*)lpart, loss,
+                     (size_t)F * grid.x);
+  ASSX_LAUNCH_CHECK(ctx, "sum_reduce_f64_kernel");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,184 @@
+"""Thin, typed wrappers over the C-ABI working on batched device tensors.
+
+Shapes follow include/assx.h (leading utterance axis B):  X (B,M,F,T) complex, W (B,F,N,M) complex,
+Tb (B,N,F,K), V (B,N,K,T), U (B,N,F,M,M), Y (B,N,F,T).  Every method launches asynchronously on
+torch's current stream for the engine's device; none of them synchronises.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._device import Precision, Workspace, context, ptr, require_gpu, stream_ptr
+
+L = _lib.lib
+
+
+class Engine:
+    def __init__(self, dtype="float64", device=None):
+        self.dev = require_gpu(device)
+        self.prec = Precision(dtype)
+        self.ctx = context(self.dev)
+        self._ws = Workspace(self.dev)
+
+    # ------------------------------------------------------------------ helpers
+    def _check(self, rc, what):
+        _lib.check(self.ctx, rc, what)
+
+    def _scratch(self, B, M, F, T, K):
+        n = L.assx_workspace_bytes(B, M, F, T, max(int(K), 1), self.prec.code)
+        return self._ws.get(n)
+
+    def _st(self):
+        return stream_ptr(self.dev)
+
+    def empty(self, shape, complex_=False, dtype=None):
+        dt = dtype if dtype is not None else (self.prec.cplx if complex_ else self.prec.real)
+        return torch.empty(shape, dtype=dt, device=self.dev)
+
+    def new_status(self, B):
+        return torch.zeros(B, dtype=torch.int32, device=self.dev)
+
+    @staticmethod
+    def _dims(X):
+        B, M, F, T = X.shape
+        return int(B), int(M), int(F), int(T)
+
+    # ------------------------------------------------------------------ (a3)
+    def demix(self, X, W, scale=None, out=None):
+        B, M, F, T = self._dims(X)
+        Y = out if out is not None else self.empty((B, M, F, T), complex_=True)
+        self._check(L.assx_demix(self.ctx, ptr(X), ptr(W), ptr(scale), ptr(Y), B, M, F, T, self.prec.code, self._st()),
+                    "assx_demix")
+        return Y
+
+    # ------------------------------------------------------------------ (a4)
+    def cov_accumulate(self, X, r=None, eps=1e-12):
+        """r: None (plain covariance, returns (B,1,F,M,M)), (B,N,T) or (B,N,F,T)."""
+        B, M, F, T = self._dims(X)
+        if r is None:
+            kind, N = _lib.W_NONE, 1
+        elif r.dim() == 3:
+            kind, N = _lib.W_NT, int(r.shape[1])
+        else:
+            kind, N = _lib.W_NFT, int(r.shape[1])
+        U = self.empty((B, N, F, M, M), complex_=True)
+        ws = self._scratch(B, M, F, T, 1)
+        self._check(L.assx_cov_accumulate(self.ctx, ptr(X), ptr(r), kind, float(eps), ptr(U), ptr(ws), B, M, N, F, T,
+                                          self.prec.code, self._st()), "assx_cov_accumulate")
+        return U
+
+    # ------------------------------------------------------------------ (a5)
+    def ip_update(self, U, W, threshold=1e12, status=None):
+        B, F, N, M = (int(s) for s in W.shape)
+        self._check(L.assx_ip_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), B, M, F, self.prec.code,
+                                     self._st()), "assx_ip_update")
+        return W
+
+    # ------------------------------------------------------------------ ILRMA
+    def ilrma_source_update(self, X, W, Tb, V, domain=2, eps=1e-12):
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_ilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
+                                               ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
+                    "assx_ilrma_source_update")
+
+    def ilrma_spatial_update(self, X, W, Tb, V, domain=2, eps=1e-12, threshold=1e12, status=None, U_out=None):
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_ilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
+                                                float(threshold), ptr(U_out), ptr(status), ptr(ws), B, M, F, T, K,
+                                                self.prec.code, self._st()), "assx_ilrma_spatial_update")
+
+    def demix_power(self, X, W, out=None):
+        B, M, F, T = self._dims(X)
+        p = out if out is not None else self.empty((B, M))
+        ws = self._scratch(B, M, F, T, 1)
+        self._check(L.assx_demix_power(self.ctx, ptr(X), ptr(W), ptr(p), ptr(ws), B, M, F, T, self.prec.code,
+                                       self._st()), "assx_demix_power")
+        return p
+
+    def power_from_cov(self, C, W, T_frames, out=None):
+        B, F, N, M = (int(s) for s in W.shape)
+        p = out if out is not None else self.empty((B, M))
+        ws = self._scratch(B, M, F, int(T_frames), 1)
+        self._check(L.assx_power_from_cov(self.ctx, ptr(C), ptr(W), ptr(p), ptr(ws), B, M, F, self.prec.code,
+                                          self._st()), "assx_power_from_cov")
+        return p
+
+    def ilrma_normalize_power(self, W, Tb, power, domain=2, eps=1e-12):
+        B, F, N, M = (int(s) for s in W.shape)
+        K = int(Tb.shape[-1])
+        self._check(L.assx_ilrma_normalize_power(self.ctx, ptr(W), ptr(Tb), ptr(power), float(domain), float(eps), B, M,
+                                                 F, K, self.prec.code, self._st()), "assx_ilrma_normalize_power")
+
+    def ilrma_normalize_pb(self, W, Tb, scale, domain=2):
+        B, F, N, M = (int(s) for s in W.shape)
+        K = int(Tb.shape[-1])
+        self._check(L.assx_ilrma_normalize_pb(self.ctx, ptr(W), ptr(Tb), ptr(scale), float(domain), B, M, F, K,
+                                              self.prec.code, self._st()), "assx_ilrma_normalize_pb")
+
+    def ilrma_loss(self, X, W, Tb, V, domain=2, eps=1e-12, out=None):
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        loss = out if out is not None else self.empty((B,), dtype=torch.float64)
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_ilrma_loss(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps), ptr(loss),
+                                      ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_loss")
+        return loss
+
+    # ------------------------------------------------------------------ AuxIVA
+    def auxiva_weights(self, X, W, kind, eps=1e-12, with_loss=False, out=None):
+        B, M, F, T = self._dims(X)
+        r = out if out is not None else self.empty((B, M, T))
+        loss = self.empty((B,), dtype=torch.float64) if with_loss else None
+        ws = self._scratch(B, M, F, T, 1)
+        self._check(L.assx_auxiva_weights(self.ctx, ptr(X), ptr(W), int(kind), float(eps), ptr(r), ptr(loss), ptr(ws),
+                                          B, M, F, T, self.prec.code, self._st()), "assx_auxiva_weights")
+        return r, loss
+
+    def auxiva_spatial_update(self, X, W, r, eps=1e-12, threshold=1e12, status=None, U_out=None):
+        B, M, F, T = self._dims(X)
+        ws = self._scratch(B, M, F, T, 1)
+        self._check(L.assx_auxiva_spatial_update(self.ctx, ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
+                                                 ptr(U_out), ptr(status), ptr(ws), B, M, F, T, self.prec.code,
+                                                 self._st()), "assx_auxiva_spatial_update")
+
+    # ------------------------------------------------------------------ projection back
+    def projection_back_scale(self, X, W, ref=0, status=None):
+        B, M, F, T = self._dims(X)
+        scale = self.empty((B, M, F), complex_=True)
+        ws = self._scratch(B, M, F, T, 1)
+        self._check(L.assx_projection_back_scale(self.ctx, ptr(X), ptr(W), int(ref), ptr(scale), ptr(status), ptr(ws),
+                                                 B, M, F, T, self.prec.code, self._st()), "assx_projection_back_scale")
+        return scale
+
+    def projection_back(self, Y, reference, status=None):
+        B, N, F, T = self._dims(Y)
+        scale = self.empty((B, N, F), complex_=True)
+        ws = self._scratch(B, N, F, T, 1)
+        self._check(L.assx_projection_back(self.ctx, ptr(Y), ptr(reference), ptr(scale), ptr(status), ptr(ws), B, N, F,
+                                           T, self.prec.code, self._st()), "assx_projection_back")
+        return scale
+
+    # ------------------------------------------------------------------ NMF
+    def _nmf_scratch(self, B, F, T, K):
+        return self._ws.get(L.assx_nmf_workspace_bytes(B, F, T, K, self.prec.code))
+
+    def nmf_update(self, kind, X, Tb, V, domain=2, eps=1e-12):
+        B, F, T = (int(s) for s in X.shape)
+        K = int(Tb.shape[-1])
+        ws = self._nmf_scratch(B, F, T, K)
+        self._check(L.assx_nmf_update(self.ctx, int(kind), float(domain), float(eps), ptr(X), ptr(Tb), ptr(V), ptr(ws),
+                                      B, F, T, K, self.prec.code, self._st()), "assx_nmf_update")
+
+    def nmf_loss(self, kind, X, Tb, V, domain=2, eps=1e-12, out=None):
+        B, F, T = (int(s) for s in X.shape)
+        K = int(Tb.shape[-1])
+        loss = out if out is not None else self.empty((B,), dtype=torch.float64)
+        ws = self._nmf_scratch(B, F, T, K)
+        self._check(L.assx_nmf_loss(self.ctx, int(kind), float(domain), float(eps), ptr(X), ptr(Tb), ptr(V), ptr(loss),
+                                    ptr(ws), B, F, T, K, self.prec.code, self._st()), "assx_nmf_loss")
+        return loss

@@ -1,0 +1,167 @@
+/*
+ * assx.h -- C-ABI of the MI355X-native iterative source-separation hot path.
+ *
+ * The reference (tky823/audio_source_separation) has NO plugin / FFI / operator API: its
+ * boundary is the Python class surface.  This header is therefore the
+ * NEW device boundary that the package's own Python classes (and any other host language)
+ * bind with ctypes / cgo / JNI: plain pointers and sizes, no torch types, `extern "C"`.
+ * Each entry point cites the reference code it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *   - All array arguments are DEVICE pointers owned by the caller, contiguous, row-major, laid
+ *     out exactly like the reference's NumPy arrays (leading batch axis B of independent
+ *     utterances added):
+ *         X  (B, M, F, T) complex      mixture STFT, T fastest      ilrma.py:61
+ *         W  (B, F, N, M) complex      demixing filters             ilrma.py:67-68
+ *         Tb (B, N, F, K) real         NMF basis                    ilrma.py:97
+ *         V  (B, N, K, T) real         NMF activation               ilrma.py:101
+ *         U  (B, N, F, M, M) complex   weighted spatial covariance  ilrma.py:511
+ *         Y  (B, N, F, T) complex      separated estimate           ilrma.py:153-165
+ *     complex = interleaved (re, im) of the real type selected by `dtype`.
+ *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 4.
+ *   - dtype: ASSX_F32 (float / complex64) or ASSX_F64 (double / complex128 = the reference's).
+ *   - `ws` is caller-owned device scratch of at least assx_workspace_bytes() bytes.
+ *   - `status` is a device int32[B]; kernels OR flags into it (ASSX_STATUS_*), never clear it.
+ *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - Return: 0 ok; <0 invalid argument (ASSX_E_*); >0 a hipError_t.  Nothing throws across the
+ *     boundary; assx_last_error(ctx) returns the message of the last failure on that context.
+ *   - One context per (device, host thread); contexts are not thread-safe.
+ */
+#ifndef ASSX_H
+#define ASSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ASSX_VERSION_STRING "assx 0.1.0 (gfx950)"
+
+enum { ASSX_F32 = 0, ASSX_F64 = 1 };
+
+enum { ASSX_E_ARG = -1, ASSX_E_UNSUPPORTED = -2, ASSX_E_NULL = -3 };
+
+/* status flags (device int32 per utterance) */
+enum {
+  ASSX_STATUS_SINGULAR = 1, /* an exactly singular W U_n met in IP: numpy.linalg.solve would raise LinAlgError */
+  ASSX_STATUS_COND_REJECT = 2 /* informational: at least one bin kept its old row (cond >= threshold) */
+};
+
+/* weight kinds for assx_cov_accumulate */
+enum { ASSX_W_NONE = 0, ASSX_W_NT = 1, ASSX_W_NFT = 2 };
+
+/* AuxIVA contrast */
+enum { ASSX_IVA_LAPLACE = 0, ASSX_IVA_GAUSS = 1 };
+
+/* NMF divergence / algorithm */
+enum { ASSX_NMF_EUC = 0, ASSX_NMF_KL = 1, ASSX_NMF_IS_MM = 2, ASSX_NMF_IS_ME = 3 };
+
+typedef struct assx_ctx assx_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int assx_ctx_create(int device, assx_ctx** ctx);
+int assx_ctx_destroy(assx_ctx* ctx);
+const char* assx_last_error(const assx_ctx* ctx);
+const char* assx_version(void);
+/* scratch bytes sufficient for any call below at these sizes */
+size_t assx_workspace_bytes(int B, int M, int F, int T, int K, int dtype);
+
+/* ---- (a3) demixing  y = W x ----------------------------------------------------------- */
+/* ILRMAbase.separate / IVAbase.separate  (src/bss/ilrma.py:153-165, src/bss/iva.py:105-117).
+ * scale: optional (B,N,F) complex multiplied into Y (the final projection-back scaling,
+ * ilrma.py:270, iva.py:455-456); NULL = none. */
+int assx_demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y,
+               int B, int M, int F, int T, int dtype, void* stream);
+
+/* ---- (a4) weighted spatial covariance -------------------------------------------------- */
+/* U[n,f] = (1/T) sum_t x(f,t) x(f,t)^H / max(r_n(.,t), eps)
+ * (src/bss/ilrma.py:497-511, src/bss/iva.py:493-499, 726-732).
+ * r: ASSX_W_NFT -> (B,N,F,T) real; ASSX_W_NT -> (B,N,T) real; ASSX_W_NONE -> NULL, N outputs
+ * collapse to 1 (U is (B,1,F,M,M): the plain covariance).  N = number of weight sets. */
+int assx_cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U,
+                        void* ws, int B, int M, int N, int F, int T, int dtype, void* stream);
+
+/* ---- (a5) iterative projection --------------------------------------------------------- */
+/* Gauss-Seidel IP sweep over the N sources, in place on W
+ * (src/bss/ilrma.py:512-530, src/bss/iva.py:500-518, 733-751): WU = W U_n; keep the old row
+ * unless cond_2(WU) < threshold; w = (WU)^{-1} e_n; W[n,:] = conj(w) / sqrt(w^H U_n w). */
+int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int32_t* status,
+                   int B, int M, int F, int dtype, void* stream);
+
+/* ---- (a2) ILRMA source model ----------------------------------------------------------- */
+/* GaussILRMA.update_source_model_basic, non-partitioned (src/bss/ilrma.py:356-366, 409-430):
+ * P = |W x|^2 recomputed on the fly; IS-NMF (mm) basis update, then activation update with
+ * the new basis.  Tb, V updated in place. */
+int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V,
+                             double domain, double eps, void* ws,
+                             int B, int M, int F, int T, int K, int dtype, void* stream);
+
+/* ---- (a4+a5) ILRMA spatial model ------------------------------------------------------- */
+/* GaussILRMA.update_spatial_model_ip (src/bss/ilrma.py:483-535): r = max((Tb V)^(2/domain), eps)
+ * rebuilt in-kernel from Tb, V (never materialised), covariance, IP sweep.  W in place.
+ * U_out: optional (B,N,F,M,M) complex receiving the covariance; NULL = scratch only. */
+int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V,
+                              double domain, double eps, double threshold, void* U_out,
+                              int32_t* status, void* ws,
+                              int B, int M, int F, int T, int K, int dtype, void* stream);
+
+/* ---- (a6) normalisation ---------------------------------------------------------------- */
+/* power[b,n] = mean_{f,t} |(W x)_n|^2  (src/bss/ilrma.py:298-306), one pass over X. */
+int assx_demix_power(assx_ctx* ctx, const void* X, const void* W, void* power /* (B,N) real */, void* ws,
+                     int B, int M, int F, int T, int dtype, void* stream);
+/* Same statistic from the plain covariance C (B,F,M,M): sum_t|y_n|^2 = T w_n^H C w_n; no pass over X. */
+int assx_power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power, void* ws,
+                        int B, int M, int F, int dtype, void* stream);
+/* 'power' normalisation (src/bss/ilrma.py:304-322): a = max(sqrt(power), eps);
+ * W[:,n,:] /= a_n;  Tb[n] /= a_n^domain. */
+int assx_ilrma_normalize_power(assx_ctx* ctx, void* W, void* Tb, const void* power, double domain, double eps,
+                               int B, int M, int F, int K, int dtype, void* stream);
+/* 'projection-back' normalisation (src/bss/ilrma.py:323-330): W[f,n,:] *= s[n,f]; Tb[n,f,:] *= |s[n,f]|^domain. */
+int assx_ilrma_normalize_pb(assx_ctx* ctx, void* W, void* Tb, const void* scale /* (B,N,F) complex */, double domain,
+                            int B, int M, int F, int K, int dtype, void* stream);
+
+/* ---- (a7) negative log-likelihoods ------------------------------------------------------ */
+/* GaussILRMA.compute_negative_loglikelihood (src/bss/ilrma.py:648-677). loss: (B,) float64. */
+int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V,
+                    double domain, double eps, double* loss, void* ws,
+                    int B, int M, int F, int T, int K, int dtype, void* stream);
+
+/* ---- AuxIVA ----------------------------------------------------------------------------- */
+/* r[b,n,t] from the current filters (src/bss/iva.py:489-491 Laplace sqrt(sum_f|y|^2),
+ * 722-724 Gauss mean_f|y|^2; not floored), and in the same pass the data term of
+ * compute_negative_loglikelihood for those filters (iva.py:604-619, 783-802) completed with
+ * -2 T sum_f log|det W_f|.  loss may be NULL. */
+int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, double eps,
+                        void* r /* (B,N,T) real */, double* loss /* (B,) or NULL */, void* ws,
+                        int B, int M, int F, int T, int dtype, void* stream);
+/* update_once_ip given r (src/bss/iva.py:493-518, 726-751): covariance with (N,T) weights + IP sweep. */
+int assx_auxiva_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* r, double eps, double threshold,
+                               void* U_out, int32_t* status, void* ws,
+                               int B, int M, int F, int T, int dtype, void* stream);
+
+/* ---- (a8) projection back --------------------------------------------------------------- */
+/* projection_back(Y, reference) for a 2-D reference (src/algorithm/projection_back.py:13-21) with
+ * Y = W X formed on the fly and reference = X[ref]:  scale[b,n,f] = (x_ref Y^H (Y Y^H)^{-1})[n]. */
+int assx_projection_back_scale(assx_ctx* ctx, const void* X, const void* W, int ref, void* scale /* (B,N,F) complex */,
+                               int32_t* status, void* ws, int B, int M, int F, int T, int dtype, void* stream);
+/* General form on a materialised Y (B,N,F,T) and an explicit reference (B,F,T). */
+int assx_projection_back(assx_ctx* ctx, const void* Y, const void* reference, void* scale,
+                         int32_t* status, void* ws, int B, int N, int F, int T, int dtype, void* stream);
+
+/* ---- (a1) NMF multiplicative updates ----------------------------------------------------- */
+/* EUCNMF/KLNMF/ISNMF.update_once_mm, ISNMF.update_once_me (src/algorithm/nmf.py:182-207,
+ * 241-266, 302-356).  X (B,F,T) real >= 0, Tb (B,F,K), V (B,K,T); Tb, V updated in place. */
+size_t assx_nmf_workspace_bytes(int B, int F, int T, int K, int dtype);
+int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V,
+                    void* ws, int B, int F, int T, int K, int dtype, void* stream);
+/* criterion((Tb V)^(2/domain), X).sum() (src/algorithm/nmf.py:170-174, 229-233, 288-292;
+ * src/criterion/divergence.py:21-45).  kind IS_ME uses the IS criterion. loss: (B,) float64. */
+int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void* X, const void* Tb, const void* V,
+                  double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASSX_H */

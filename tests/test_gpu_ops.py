@@ -1,0 +1,300 @@
+"""Stage-level GPU parity: every C-ABI entry point against the CPU oracle on the same seeded inputs.
+
+Tolerances (relative Frobenius error unless stated):
+  float64 storage: 1e-11 for single reductions/contractions (summation order differs), 1e-9 after an IP sweep.
+  float32 storage: 2e-5 for single reductions, 2e-3 after an IP sweep (cond(WU) amplifies rounding).
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import oracle_np as orc
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", params=["float64", "float32"])
+def eng(request):
+    from audio_source_separation_amd.ops import Engine
+    return Engine(dtype=request.param)
+
+
+def tol(eng, t64, t32):
+    return t64 if eng.prec.name == "float64" else t32
+
+
+def dev_c(eng, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.dev, eng.prec.cplx).contiguous()
+
+
+def dev_r(eng, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.dev, eng.prec.real).contiguous()
+
+
+def host(t):
+    a = t.detach().cpu().numpy()
+    return a.astype(np.complex128) if np.iscomplexobj(a) else a.astype(np.float64)
+
+
+def mixture(M, F, T, seed):
+    rng = np.random.default_rng(seed)
+    S = (rng.standard_normal((M, F, T)) + 1j * rng.standard_normal((M, F, T))) * rng.random((M, 1, T)) ** 2
+    A = rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M))
+    return np.einsum("fmn,nft->mft", A, S)
+
+
+def rand_filters(M, F, seed):
+    rng = np.random.default_rng(seed)
+    return np.eye(M)[None] + 0.3 * (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M)))
+
+
+SHAPES = [(2, 9, 70), (3, 17, 200), (4, 33, 257), (4, 5, 1030)]
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES)
+def test_demix(eng, M, F, T):
+    X, W = mixture(M, F, T, 1), rand_filters(M, F, 2)
+    Y = host(eng.demix(dev_c(eng, X[None]), dev_c(eng, W[None])))[0]
+    assert rel_err(Y, orc.separate(X, W)) < tol(eng, 1e-14, 1e-6)
+    rng = np.random.default_rng(3)
+    s = rng.standard_normal((M, F)) + 1j * rng.standard_normal((M, F))
+    Ys = host(eng.demix(dev_c(eng, X[None]), dev_c(eng, W[None]), scale=dev_c(eng, s[None])))[0]
+    assert rel_err(Ys, orc.separate(X, W) * s[..., None]) < tol(eng, 1e-14, 1e-6)
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES)
+def test_cov_accumulate(eng, M, F, T):
+    X = mixture(M, F, T, 4)
+    rng = np.random.default_rng(5)
+    r_nt = rng.random((M, T)) ** 3
+    r_nt[:, :3] = 0.0  # floored at eps
+    r_nft = rng.random((M, F, T)) ** 3
+    Xd = dev_c(eng, X[None])
+    U = host(eng.cov_accumulate(Xd, dev_r(eng, r_nt[None]), eps=1e-3))[0]
+    assert rel_err(U, orc.weighted_covariance(X, r_nt, 1e-3)) < tol(eng, 1e-12, 2e-5)
+    U = host(eng.cov_accumulate(Xd, dev_r(eng, r_nft[None]), eps=1e-3))[0]
+    assert rel_err(U, orc.weighted_covariance(X, r_nft, 1e-3)) < tol(eng, 1e-12, 2e-5)
+    C = host(eng.cov_accumulate(Xd))[0]
+    assert rel_err(C, orc.weighted_covariance(X, np.ones((1, T)), 1e-3)) < tol(eng, 1e-12, 2e-5)
+    # Hermitian by construction
+    assert np.array_equal(U, U.conj().transpose(0, 1, 3, 2))
+
+
+def test_cov_batched_matches_single(eng):
+    """Utterances are independent: a batched launch is bit-identical to per-utterance launches."""
+    M, F, T = 4, 9, 300
+    Xs = np.stack([mixture(M, F, T, 10 + b) for b in range(3)])
+    rs = np.random.default_rng(6).random((3, M, T)) + 0.1
+    Ub = host(eng.cov_accumulate(dev_c(eng, Xs), dev_r(eng, rs)))
+    for b in range(3):
+        U1 = host(eng.cov_accumulate(dev_c(eng, Xs[b:b + 1]), dev_r(eng, rs[b:b + 1])))[0]
+        assert np.array_equal(Ub[b], U1)
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES[:3])
+def test_ip_update(eng, M, F, T):
+    X, W = mixture(M, F, T, 7), rand_filters(M, F, 8)
+    r = np.random.default_rng(9).random((M, T)) + 0.05
+    U = orc.weighted_covariance(X, r)
+    Wd = dev_c(eng, W[None])
+    st = eng.new_status(1)
+    eng.ip_update(dev_c(eng, U[None]), Wd, 1e12, st)
+    Wref, mask = orc.ip_update(W.copy(), U)
+    assert mask.all() and int(st.item()) == 0
+    assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-10, 1e-3)
+
+
+def test_ip_cond_guard_and_singular():
+    """cond(WU) >= threshold keeps the row (ilrma.py:520-528); an exactly singular WU flags LinAlgError."""
+    from audio_source_separation_amd import _lib
+    from audio_source_separation_amd.ops import Engine
+    eng = Engine("float64")
+    g = load_golden("edge_cond_ilrma")
+    X = g["X"]
+    M, F, T = X.shape
+    Tb, V = g["T0"], g["V0"]
+    P = np.abs(X) ** 2
+    T1, V1 = orc.ilrma_source_update(P, Tb, V)
+    U = orc.weighted_covariance(X, orc.ilrma_variance(T1, V1))
+    W0 = np.tile(np.eye(M, dtype=np.complex128), (F, 1, 1))
+    Wref, mask = orc.ip_update(W0.copy(), U)
+    Wd = dev_c(eng, W0[None])
+    st = eng.new_status(1)
+    eng.ip_update(dev_c(eng, U[None]), Wd, 1e12, st)
+    Wg = host(Wd)[0]
+    kept = ~mask.all(axis=0)
+    assert kept[[2, 5]].all() and kept.sum() == 2
+    assert np.array_equal(Wg[kept], W0[kept])  # bit-exact: rows untouched
+    assert rel_err(Wg, Wref) < 1e-9
+    assert int(st.item()) & _lib.STATUS_COND_REJECT and not int(st.item()) & _lib.STATUS_SINGULAR
+    # moderately ill-conditioned bins straddling a custom threshold: decisions must match numpy's cond_2
+    rng = np.random.default_rng(11)
+    Ub = np.empty((M, 64, M, M), dtype=np.complex128)
+    for f in range(64):
+        Q1, _ = np.linalg.qr(rng.standard_normal((M, M)) + 1j * rng.standard_normal((M, M)))
+        s = np.logspace(0, -rng.uniform(0, 8), M)
+        Ub[:, f] = (Q1 * s) @ Q1.conj().T
+    Wb = np.tile(np.eye(M, dtype=np.complex128), (64, 1, 1))
+    for thr in (1e3, 1e4, 1e5):
+        Wr, mk = orc.ip_update(Wb.copy(), Ub, thr)
+        Wd = dev_c(eng, Wb[None])
+        eng.ip_update(dev_c(eng, Ub[None]), Wd, thr, eng.new_status(1))
+        got_kept = np.all(host(Wd)[0] == Wb, axis=2).T  # (N,F): row n of bin f untouched
+        # identity rows of an updated W can only coincide with the old row if kept
+        assert np.array_equal(got_kept, ~mk), thr
+    # exactly singular
+    Uz = np.zeros((M, 3, M, M), dtype=np.complex128)
+    st = eng.new_status(1)
+    eng.ip_update(dev_c(eng, Uz[None]), dev_c(eng, Wb[None, :3]), 1e12, st)
+    assert int(st.item()) & _lib.STATUS_SINGULAR
+
+
+@pytest.mark.parametrize("M,K,domain", [(2, 2, 2), (4, 4, 2), (3, 5, 2), (4, 10, 2), (2, 4, 1), (3, 3, 1.5)])
+def test_ilrma_source_update(eng, M, K, domain):
+    F, T = 19, 150
+    X, W = mixture(M, F, T, 20 + M), rand_filters(M, F, 21)
+    rng = np.random.default_rng(22)
+    Tb, V = rng.random((M, F, K)), rng.random((M, K, T))
+    Td, Vd = dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    eng.ilrma_source_update(dev_c(eng, X[None]), dev_c(eng, W[None]), Td, Vd, domain=domain)
+    T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(X, W)) ** 2, Tb, V, domain)
+    assert rel_err(host(Td)[0], T1) < tol(eng, 1e-11, 5e-5)
+    assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
+
+
+@pytest.mark.parametrize("M,K,domain", [(2, 2, 2), (4, 4, 2), (3, 5, 2), (4, 2, 1)])
+def test_ilrma_spatial_update(eng, M, K, domain):
+    F, T = 19, 330
+    X, W = mixture(M, F, T, 30 + M), rand_filters(M, F, 31)
+    rng = np.random.default_rng(32)
+    Tb, V = rng.random((M, F, K)) + 0.05, rng.random((M, K, T)) + 0.05
+    Wd = dev_c(eng, W[None])
+    Ud = eng.empty((1, M, F, M, M), complex_=True)
+    st = eng.new_status(1)
+    eng.ilrma_spatial_update(dev_c(eng, X[None]), Wd, dev_r(eng, Tb[None]), dev_r(eng, V[None]), domain=domain,
+                             status=st, U_out=Ud)
+    Wref, Uref, mask = orc.ilrma_spatial_update_ip(X, W.copy(), Tb, V, domain)
+    assert mask.all() and int(st.item()) == 0
+    assert rel_err(host(Ud)[0], Uref) < tol(eng, 1e-12, 2e-5)
+    assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-9, 2e-3)
+
+
+def test_ilrma_stage_fixture(eng):
+    """The reference's own stage outputs (tests/golden/ilrma_stages.npz)."""
+    g = load_golden("ilrma_stages")
+    X, W0, T0, V0 = g["X"], g["W0"], g["T0"], g["V0"]
+    Xd, Wd, Td, Vd = dev_c(eng, X[None]), dev_c(eng, W0[None]), dev_r(eng, T0[None]), dev_r(eng, V0[None])
+    l0 = eng.ilrma_loss(Xd, Wd, Td, Vd).item()
+    np.testing.assert_allclose(l0, g["loss0"], rtol=tol(eng, 1e-12, 1e-5))
+    eng.ilrma_source_update(Xd, Wd, Td, Vd)
+    assert rel_err(host(Td)[0], g["T1"]) < tol(eng, 1e-11, 5e-5)
+    assert rel_err(host(Vd)[0], g["V1"]) < tol(eng, 1e-11, 5e-5)
+    Ud = eng.empty((1,) + g["U"].shape, complex_=True)
+    eng.ilrma_spatial_update(Xd, Wd, Td, Vd, U_out=Ud)
+    assert rel_err(host(Ud)[0], g["U"]) < tol(eng, 1e-11, 1e-4)
+    assert rel_err(host(Wd)[0], g["W1"]) < tol(eng, 1e-9, 2e-3)
+    l1 = eng.ilrma_loss(Xd, Wd, Td, Vd).item()
+    np.testing.assert_allclose(l1, g["loss1"], rtol=tol(eng, 1e-10, 1e-4))
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES)
+def test_power_and_normalize(eng, M, F, T):
+    X, W = mixture(M, F, T, 40), rand_filters(M, F, 41)
+    Xd, Wd = dev_c(eng, X[None]), dev_c(eng, W[None])
+    p = host(eng.demix_power(Xd, Wd))[0]
+    pref = (np.abs(orc.separate(X, W)) ** 2).mean(axis=(1, 2))
+    np.testing.assert_allclose(p, pref, rtol=tol(eng, 1e-12, 2e-5))
+    C = eng.cov_accumulate(Xd)
+    p2 = host(eng.power_from_cov(C.reshape(1, F, M, M), Wd, T))[0]
+    np.testing.assert_allclose(p2, pref, rtol=tol(eng, 1e-12, 2e-5))
+    K = 3
+    Tb = np.random.default_rng(42).random((M, F, K))
+    for domain in (2, 1, 1.5):
+        Wn, Tn = dev_c(eng, W[None]), dev_r(eng, Tb[None])
+        eng.ilrma_normalize_power(Wn, Tn, dev_r(eng, pref[None]), domain=domain)
+        Wr, Tr = orc.ilrma_normalize(X, W, Tb, "power", domain)
+        assert rel_err(host(Wn)[0], Wr) < tol(eng, 1e-14, 1e-6)
+        assert rel_err(host(Tn)[0], Tr) < tol(eng, 1e-13, 1e-6)
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES[:3])
+def test_projection_back(eng, M, F, T):
+    X, W = mixture(M, F, T, 50), rand_filters(M, F, 51)
+    Xd, Wd = dev_c(eng, X[None]), dev_c(eng, W[None])
+    Y = orc.separate(X, W)
+    for ref in (0, M - 1):
+        s = host(eng.projection_back_scale(Xd, Wd, ref))[0]
+        assert rel_err(s, orc.projection_back(Y, X[ref])) < tol(eng, 1e-10, 2e-3)
+    s2 = host(eng.projection_back(dev_c(eng, Y[None]), dev_c(eng, X[0][None])))[0]
+    assert rel_err(s2, orc.projection_back(Y, X[0])) < tol(eng, 1e-10, 2e-3)
+    # 'projection-back' normalisation
+    K = 2
+    Tb = np.random.default_rng(52).random((M, F, K))
+    sc = orc.projection_back(Y, X[0])
+    for domain in (2, 1):
+        Wn, Tn = dev_c(eng, W[None]), dev_r(eng, Tb[None])
+        eng.ilrma_normalize_pb(Wn, Tn, dev_c(eng, sc[None]), domain=domain)
+        Wr, Tr = orc.ilrma_normalize(X, W, Tb, "projection-back", domain)
+        assert rel_err(host(Wn)[0], Wr) < tol(eng, 1e-13, 1e-6)
+        assert rel_err(host(Tn)[0], Tr) < tol(eng, 1e-13, 1e-6)
+
+
+def test_projection_back_golden(eng):
+    g = load_golden("projection_back")
+    for N in (2, 3, 4):
+        s = host(eng.projection_back(dev_c(eng, g["Y_n%d" % N][None]), dev_c(eng, g["ref_n%d" % N][None])))[0]
+        assert rel_err(s, g["scale_n%d" % N]) < tol(eng, 1e-11, 1e-3)
+
+
+@pytest.mark.parametrize("kind", ["laplace", "gauss"])
+@pytest.mark.parametrize("M,F,T", SHAPES)
+def test_auxiva_weights_and_loss(eng, kind, M, F, T):
+    from audio_source_separation_amd import _lib
+    X, W = mixture(M, F, T, 60), rand_filters(M, F, 61)
+    code = _lib.IVA_LAPLACE if kind == "laplace" else _lib.IVA_GAUSS
+    r, loss = eng.auxiva_weights(dev_c(eng, X[None]), dev_c(eng, W[None]), code, with_loss=True)
+    assert rel_err(host(r)[0], orc.auxiva_weights(orc.separate(X, W), kind)) < tol(eng, 1e-12, 2e-5)
+    np.testing.assert_allclose(loss.item(), orc.auxiva_loss(X, W, kind), rtol=tol(eng, 1e-11, 1e-4))
+
+
+@pytest.mark.parametrize("kind", ["laplace", "gauss"])
+def test_auxiva_update_once(eng, kind):
+    from audio_source_separation_amd import _lib
+    M, F, T = 3, 17, 300
+    X, W = mixture(M, F, T, 70), rand_filters(M, F, 71)
+    code = _lib.IVA_LAPLACE if kind == "laplace" else _lib.IVA_GAUSS
+    Xd, Wd = dev_c(eng, X[None]), dev_c(eng, W[None])
+    r, _ = eng.auxiva_weights(Xd, Wd, code)
+    eng.auxiva_spatial_update(Xd, Wd, r)
+    Wref, _, mask = orc.auxiva_update_once_ip(X, W.copy(), orc.separate(X, W), kind)
+    assert mask.all()
+    assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-9, 2e-3)
+
+
+NMF_CASES = ["euc_d2", "euc_d1", "euc_d15", "kl_d2", "kl_d1", "kl_d15", "is_mm_d2", "is_mm_d1", "is_mm_d15",
+             "is_me_d2", "is_k32"]
+
+
+@pytest.mark.parametrize("name", NMF_CASES)
+def test_nmf_golden(eng, name):
+    from audio_source_separation_amd import _lib
+    g = load_golden("nmf_" + name)
+    kind = {"EUC": _lib.NMF_EUC, "KL": _lib.NMF_KL, "IS": _lib.NMF_IS_MM}[str(g["kind"])]
+    if str(g["algorithm"]) == "me":
+        kind = _lib.NMF_IS_ME
+    domain = float(g["domain"])
+    Xd = dev_r(eng, g["X"][None])
+    Td, Vd = dev_r(eng, g["T0"][None]), dev_r(eng, g["V0"][None])
+    losses = []
+    done = 0
+    for k in g["iters"]:
+        while done < int(k):
+            eng.nmf_update(kind, Xd, Td, Vd, domain=domain)
+            losses.append(eng.nmf_loss(kind, Xd, Td, Vd, domain=domain).item())
+            done += 1
+        scale = 1 if k <= 5 else 10
+        assert rel_err(host(Td)[0], g["T_%d" % k]) < scale * tol(eng, 1e-11, 1e-4), k
+        assert rel_err(host(Vd)[0], g["V_%d" % k]) < scale * tol(eng, 1e-11, 1e-4), k
+    np.testing.assert_allclose(losses, g["loss_%d" % int(g["iters"][-1])], rtol=tol(eng, 1e-10, 2e-4))
