@@ -6,6 +6,11 @@ every call checks its status code and raises with the library's own message.
 import ctypes
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (SONAME libamdhip64.so.7, same as /opt/rocm's).  The process must
+# hold exactly ONE HIP runtime or device pointers / streams cannot be shared and the second runtime finds no
+# device: importing torch first makes the loader bind libassx.so to the runtime torch already mapped.
+import torch  # noqa: F401,E402
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libassx.so")
 

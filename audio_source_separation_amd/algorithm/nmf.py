@@ -1,0 +1,186 @@
+"""NMF by multiplicative updates on MI355X -- drop-in for `algorithm.nmf.EUCNMF / KLNMF / ISNMF`
+of the reference (/root/reference/src/algorithm/nmf.py:10-56, 150-356).
+
+Same constructors, `nmf(target, iteration=100, **kwargs) -> (basis.copy(), activation.copy())`,
+`basis` / `activation` / `loss` attributes.  `update_once()` and the per-iteration loss run as HIP
+kernels (include/assx.h: assx_nmf_update / assx_nmf_loss); there is no CPU fallback.
+"""
+import numpy as np
+
+from .._device import to_device, to_numpy, torch
+from .._state import DeviceArray, DeviceState
+from .. import _lib
+from ..ops import Engine
+
+EPS = 1e-12
+
+__metrics__ = ['EUC', 'KL', 'IS']
+
+
+class NMFbase(DeviceState):
+    basis = DeviceArray("T", complex_=False)
+    activation = DeviceArray("V", complex_=False)
+
+    _KIND = None
+
+    def __init__(self, n_basis=2, eps=EPS, *, dtype='float64', device=None):
+        """
+        Args:
+            n_basis: number of basis
+        """
+
+        self.n_basis = n_basis
+        self.loss = []
+
+        self.eps = eps
+        self.domain = 2
+
+        self.dtype = dtype
+        self.device = device
+        self._engine = None
+
+    def __call__(self, target, iteration=100, **kwargs):
+        self.target = target
+
+        self._reset(**kwargs)
+
+        self.update(iteration=iteration)
+
+        T, V = self.basis, self.activation
+
+        return T.copy(), V.copy()
+
+    def _reset(self, **kwargs):
+        assert self.target is not None, "Specify data!"
+
+        for key in kwargs.keys():
+            setattr(self, key, kwargs[key])
+
+        if self._engine is None:
+            self._engine = Engine(dtype=self.dtype, device=self.device)
+        eng = self._engine
+
+        n_basis = self.n_basis
+        target = self.target
+        ndim = target.dim() if isinstance(target, torch.Tensor) else np.ndim(target)
+        if ndim not in (2, 3):
+            raise ValueError("target must be (n_bins, n_frames), got {} dims".format(ndim))
+        self._batched = ndim == 3
+        Xd = to_device(target, eng.prec.real, eng.dev)
+        if not self._batched:
+            Xd = Xd.unsqueeze(0)
+        self._X = Xd.contiguous()
+        B, n_bins, n_frames = (int(s) for s in self._X.shape)
+
+        # NMF never warm-starts: fresh draws from the global RNG, basis first (nmf.py:36-43)
+        lead = (B,) if self._batched else ()
+        self.basis = np.random.rand(*(lead + (n_bins, n_basis)))
+        self.activation = np.random.rand(*(lead + (n_basis, n_frames)))
+
+    def _kind_code(self):
+        if self._KIND is None:
+            raise NotImplementedError("Implement 'update_once' function")
+        return self._KIND
+
+    def update(self, iteration=100):
+        for idx in range(iteration):
+            self.update_once()
+
+            loss = self._engine.nmf_loss(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
+                                         domain=self.domain, eps=self.eps)
+            self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
+
+    def update_once(self):
+        self._engine.nmf_update(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
+                                domain=self.domain, eps=self.eps)
+        self._touch("T", "V")
+
+
+class EUCNMF(NMFbase):
+    """reference: nmf.py:150-207"""
+    _KIND = _lib.NMF_EUC
+
+    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+        """
+        Args:
+            n_basis: number of basis
+        """
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+
+        assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
+        assert algorithm == 'mm', "algorithm must be 'mm'."
+
+        self.domain = domain
+        self.algorithm = algorithm
+
+    def update_once(self):
+        if self.algorithm == 'mm':
+            self.update_once_mm()
+        else:
+            raise ValueError("Not support {} based update.".format(self.algorithm))
+
+    def update_once_mm(self):
+        NMFbase.update_once(self)
+
+
+class KLNMF(NMFbase):
+    """reference: nmf.py:209-266"""
+    _KIND = _lib.NMF_KL
+
+    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+        """
+        Args:
+            K: number of basis
+        """
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+
+        assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
+        assert algorithm == 'mm', "algorithm must be 'mm'."
+
+        self.domain = domain
+        self.algorithm = algorithm
+
+    def update_once(self):
+        if self.algorithm == 'mm':
+            self.update_once_mm()
+        else:
+            raise ValueError("Not support {} based update.".format(self.algorithm))
+
+    def update_once_mm(self):
+        NMFbase.update_once(self)
+
+
+class ISNMF(NMFbase):
+    """reference: nmf.py:268-356"""
+    _KIND = _lib.NMF_IS_MM
+
+    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+        """
+        Args:
+            K: number of basis
+            algorithm: 'mm': MM algorithm based update
+        """
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+
+        assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
+
+        self.domain = domain
+        self.algorithm = algorithm
+
+    def _kind_code(self):
+        return _lib.NMF_IS_ME if self.algorithm == 'me' else _lib.NMF_IS_MM
+
+    def update_once(self):
+        if self.algorithm == 'mm':
+            self.update_once_mm()
+        elif self.algorithm == 'me':
+            self.update_once_me()
+        else:
+            raise ValueError("Not support {} based update.".format(self.algorithm))
+
+    def update_once_mm(self):
+        NMFbase.update_once(self)
+
+    def update_once_me(self):
+        assert self.domain == 2, "Only domain = 2 is supported."
+        NMFbase.update_once(self)

@@ -1,0 +1,333 @@
+"""Gauss-ILRMA on MI355X -- drop-in for the reference's `bss.ilrma.GaussILRMA` (IP spatial update).
+
+Same constructor, `__call__(input, iteration, **kwargs)`, attributes and callback protocol as
+/root/reference/src/bss/ilrma.py:22-677; the per-iteration `update_once()` runs as hand-written
+HIP kernels behind the C-ABI in include/assx.h (no CPU fallback).  Extra keyword-only arguments
+(`dtype`, `device`, `power_statistic`) default to the reference's behaviour.
+
+Not yet on the HIP path: `partitioning=True`, `algorithm_spatial` in
+{'ISS', 'pairwise', 'IP2'} -- these raise NotImplementedError at call time instead of silently
+falling back to the CPU.
+"""
+import numpy as np
+
+from .._device import to_device, to_numpy, torch
+from .._state import DeviceArray, DeviceState
+from .. import _lib
+from ..ops import Engine
+
+EPS = 1e-12
+THRESHOLD = 1e+12
+
+__algorithms_spatial__ = ['IP', 'IVA', 'ISS', 'IPA', 'pairwise', 'IP1', 'IP2']
+
+
+class ILRMAbase(DeviceState):
+    """Independent Low-rank Matrix Analysis (reference: ilrma.py:22-176)."""
+
+    demix_filter = DeviceArray("W", complex_=True)
+    basis = DeviceArray("T", complex_=False)
+    activation = DeviceArray("V", complex_=False)
+
+    def __init__(self, n_basis=10, partitioning=False, normalize=True, algorithm_spatial='IP', callbacks=None,
+                 recordable_loss=True, eps=EPS, *, dtype='float64', device=None):
+        if callbacks is not None:
+            if callable(callbacks):
+                callbacks = [callbacks]
+            self.callbacks = callbacks
+        else:
+            self.callbacks = None
+        self.eps = eps
+
+        self.n_basis = n_basis
+        self.partitioning = partitioning
+        self.normalize = normalize
+
+        assert algorithm_spatial in __algorithms_spatial__, "Choose from {} as `algorithm_spatial`.".format(__algorithms_spatial__)
+        assert algorithm_spatial in ['IP', 'ISS', 'pairwise', 'IP1', 'IP2'], "Not support {}-based demixing filter updates.".format(algorithm_spatial)
+        self.algorithm_spatial = algorithm_spatial
+
+        self.input = None
+        self.recordable_loss = recordable_loss
+        if self.recordable_loss:
+            self.loss = []
+        else:
+            self.loss = None
+
+        self.dtype = dtype
+        self.device = device
+        self._engine = None
+        self._estimation = None
+
+    # ------------------------------------------------------------------ device plumbing
+    def _require_supported(self):
+        if self.partitioning:
+            raise NotImplementedError("partitioning=True is not on the HIP path yet (no CPU fallback is provided).")
+        if self.algorithm_spatial not in ('IP', 'IP1'):
+            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' (no CPU fallback is provided).".format(self.algorithm_spatial))
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            self._engine = Engine(dtype=self.dtype, device=self.device)
+        return self._engine
+
+    def _upload_input(self):
+        eng = self._ensure_engine()
+        X = self.input
+        ndim = X.dim() if isinstance(X, torch.Tensor) else np.ndim(X)
+        if ndim not in (3, 4):
+            raise ValueError("input must be (n_channels, n_bins, n_frames), got {} dims".format(ndim))
+        self._batched = ndim == 4
+        Xd = to_device(X, eng.prec.cplx, eng.dev)
+        if not self._batched:
+            Xd = Xd.unsqueeze(0)
+        self._X = Xd.contiguous()
+        self._status = eng.new_status(self._X.shape[0])
+
+    def _reset(self, **kwargs):
+        assert self.input is not None, "Specify data!"
+
+        for key in kwargs.keys():
+            setattr(self, key, kwargs[key])
+
+        self._require_supported()
+        self._upload_input()
+        eng = self._engine
+        n_basis = self.n_basis
+
+        B, n_channels, n_bins, n_frames = (int(s) for s in self._X.shape)
+        n_sources = n_channels  # n_channels == n_sources (ilrma.py:61-62)
+
+        self.n_sources, self.n_channels = n_sources, n_channels
+        self.n_bins, self.n_frames = n_bins, n_frames
+
+        if not hasattr(self, 'demix_filter'):
+            W = torch.eye(n_sources, n_channels, dtype=eng.prec.cplx, device=eng.dev)
+            self._set_dev("W", W.repeat(B, n_bins, 1, 1).contiguous())
+        # else: the existing filter (previous call or user-supplied) is the warm start (ilrma.py:70-72)
+
+        shape_T = (n_sources, n_bins, n_basis)
+        shape_V = (n_sources, n_basis, n_frames)
+        if self._batched:
+            shape_T, shape_V = (B,) + shape_T, (B,) + shape_V
+        # global NumPy RNG, basis first then activation, exactly as ilrma.py:97-104
+        if not hasattr(self, 'basis'):
+            self.basis = np.random.rand(*shape_T)
+        if not hasattr(self, 'activation'):
+            self.activation = np.random.rand(*shape_V)
+
+        self._estimation = None  # = separate(X, W), formed on demand
+
+    # device tensors of the public arrays (uploaded on first use after a host-side assignment)
+    @property
+    def _Wd(self):
+        return self._dev("W", True)
+
+    @property
+    def _Td(self):
+        return self._dev("T", False)
+
+    @property
+    def _Vd(self):
+        return self._dev("V", False)
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def estimation(self):
+        """(n_sources, n_bins, n_frames): current y = W x (ilrma.py:76), or the final scaled output."""
+        if self._estimation is None:
+            if getattr(self, "_X", None) is None:
+                raise AttributeError("'{}' object has no attribute 'estimation'".format(type(self).__name__))
+            Y = self._engine.demix(self._X, self._dev("W", True))
+            Y = to_numpy(Y, np.complex128)
+            self._estimation = Y if self._batched else Y[0]
+        return self._estimation
+
+    @estimation.setter
+    def estimation(self, value):
+        self._estimation = value
+
+    def __call__(self, input, iteration=100, **kwargs):
+        raise NotImplementedError("Implement '__call__' in the subclass")
+
+    def __repr__(self):
+        s = "ILRMA("
+        s += "n_basis={n_basis}"
+        s += ", partitioning={partitioning}"
+        s += ", normalize={normalize}"
+        s += ")"
+
+        return s.format(**self.__dict__)
+
+    def update_once(self):
+        raise NotImplementedError("Implement 'update_once' function")
+
+    def separate(self, input, demix_filter):
+        """y = W x on the device (ilrma.py:153-165).  Accepts / returns NumPy arrays like the reference."""
+        eng = self._ensure_engine()
+        X = to_device(input, eng.prec.cplx, eng.dev)
+        W = to_device(demix_filter, eng.prec.cplx, eng.dev)
+        batched = X.dim() == 4
+        if not batched:
+            X = X.unsqueeze(0)
+        if W.dim() == 2:  # (N, M) broadcast over bins, as `demix_filter @ input` does in the reference
+            W = W.expand(X.shape[2], -1, -1)
+        if W.dim() == 3:
+            W = W.unsqueeze(0).expand(X.shape[0], -1, -1, -1)
+        Y = eng.demix(X.contiguous(), W.contiguous())
+        if isinstance(input, torch.Tensor):
+            return Y if batched else Y[0]
+        Y = to_numpy(Y, np.complex128)
+        return Y if batched else Y[0]
+
+    def compute_negative_loglikelihood(self):
+        raise NotImplementedError("Implement 'compute_negative_loglikelihood' function.")
+
+    def _check_status(self):
+        """Turn device-side flags into the exceptions NumPy would have raised (one sync)."""
+        flags = int(self._status.max().item())
+        if flags & _lib.STATUS_SINGULAR:
+            self._status.zero_()
+            raise np.linalg.LinAlgError("Singular matrix")
+
+    def _run_callbacks(self):
+        if self.callbacks is not None:
+            for callback in self.callbacks:
+                callback(self)
+
+
+class GaussILRMA(ILRMAbase):
+    """
+    Reference: "Determined Blind Source Separation Unifying Independent Vector Analysis and Nonnegative Matrix Factorization"
+    See https://ieeexplore.ieee.org/document/7486081
+    (reference implementation: ilrma.py:178-677)
+    """
+
+    def __init__(self, n_basis=10, domain=2, partitioning=False, normalize='power', algorithm_spatial='IP',
+                 reference_id=0, callbacks=None, recordable_loss=True, eps=EPS, threshold=THRESHOLD, *,
+                 dtype='float64', device=None, power_statistic='covariance'):
+        """
+        Args:
+            normalize <str>: 'power': power based normalization, or 'projection-back': projection back based normalization.
+            threshold <float>: threshold for condition number when computing (WU)^{-1}.
+            dtype: 'float64' (complex128 kernels = the reference's precision) or 'float32' (throughput mode).
+            power_statistic: 'covariance' evaluates mean|y_n|^2 = mean_f w_n^H C_f w_n from the plain covariance
+                C_f computed once per call (no pass over X); 'direct' re-reads X every iteration like ilrma.py:298-306.
+        """
+        super().__init__(n_basis=n_basis, partitioning=partitioning, normalize=normalize,
+                         algorithm_spatial=algorithm_spatial, callbacks=callbacks, recordable_loss=recordable_loss,
+                         eps=eps, dtype=dtype, device=device)
+
+        assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
+        assert power_statistic in ('covariance', 'direct')
+
+        self.domain = domain
+        self.reference_id = reference_id
+        self.threshold = threshold
+        self.power_statistic = power_statistic
+
+        if self.algorithm_spatial in ['pairwise', 'IP2']:
+            self.update_pair = None
+
+    def __call__(self, input, iteration=100, **kwargs):
+        """
+        Args:
+            input (n_channels, n_bins, n_frames)
+        Returns:
+            output (n_channels, n_bins, n_frames)
+        """
+        self.input = input
+
+        self._reset(**kwargs)
+
+        if self.recordable_loss:
+            loss = self.compute_negative_loglikelihood()
+            self.loss.append(loss)
+
+        self._run_callbacks()
+
+        for idx in range(iteration):
+            self.update_once()
+
+            if self.recordable_loss:
+                loss = self.compute_negative_loglikelihood()
+                self.loss.append(loss)
+
+            self._run_callbacks()
+
+        # final projection back (ilrma.py:258-273); scale and y = W x in two small passes over X
+        eng = self._engine
+        scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
+        Y = eng.demix(self._X, self._Wd, scale=scale)
+        self._check_status()
+
+        if isinstance(input, torch.Tensor):
+            output = Y if self._batched else Y[0]
+        else:
+            output = to_numpy(Y, np.complex128)
+            output = output if self._batched else output[0]
+        self.estimation = output
+
+        return output
+
+    def _reset(self, **kwargs):
+        super()._reset(**kwargs)
+        self._C = None
+        self._power = self._engine.empty((self._X.shape[0], self.n_sources))
+
+    def __repr__(self):
+        s = "Gauss-ILRMA("
+        s += "n_basis={n_basis}"
+        s += ", domain={domain}"
+        s += ", partitioning={partitioning}"
+        s += ", normalize={normalize}"
+        s += ", algorithm_spatial={algorithm_spatial}"
+        s += ")"
+
+        return s.format(**self.__dict__)
+
+    def update_once(self):
+        domain = self.domain
+        eps = self.eps
+        eng = self._engine
+
+        self.update_source_model()
+        self.update_spatial_model()
+
+        if self.normalize:
+            if self.normalize == 'power':
+                if self.power_statistic == 'covariance':
+                    if self._C is None:  # plain covariance of X: constant over the iterations
+                        B, M, F, _ = self._X.shape
+                        self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
+                    eng.power_from_cov(self._C, self._Wd, self.n_frames, out=self._power)
+                else:
+                    eng.demix_power(self._X, self._Wd, out=self._power)
+                eng.ilrma_normalize_power(self._Wd, self._Td, self._power, domain=domain, eps=eps)
+            elif self.normalize == 'projection-back':
+                scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
+                eng.ilrma_normalize_pb(self._Wd, self._Td, scale, domain=domain)
+            else:
+                raise ValueError("Not support normalization based on {}. Choose 'power' or 'projection-back'".format(self.normalize))
+            self._touch("W", "T")
+            self._estimation = None
+
+    def update_source_model(self):
+        """IS-NMF (mm) update of basis then activation on P = |W x|^2 (ilrma.py:356-366, 409-430)."""
+        self._engine.ilrma_source_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps)
+        self._touch("T", "V")
+
+    def update_spatial_model(self):
+        """Weighted covariance + iterative projection (ilrma.py:483-535)."""
+        self._engine.ilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
+                                          threshold=self.threshold, status=self._status)
+        self._touch("W")
+        self._estimation = None
+
+    def compute_negative_loglikelihood(self):
+        """sum(P/R + log R) - 2 T sum_f log|det W_f| (ilrma.py:648-677).  Syncs to return a Python float."""
+        loss = self._engine.ilrma_loss(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps)
+        self._check_status()
+        if self._batched:
+            return to_numpy(loss, np.float64)
+        return np.float64(loss.item())

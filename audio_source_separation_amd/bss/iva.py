@@ -1,0 +1,267 @@
+"""AuxIVA (Laplace / Gauss, iterative projection) on MI355X -- drop-in for `bss.iva.AuxLaplaceIVA`
+and `bss.iva.AuxGaussIVA` of the reference (/root/reference/src/bss/iva.py:22-128, 289-802).
+
+One iteration = two passes over X on the device:
+  pass A  r_n(t) from y = W x (iva.py:489-491 / 722-724) -- the same pass yields the data term of the
+          negative log-likelihood for the current filters (iva.py:604-619 / 783-802), so recording the
+          loss costs no extra pass;
+  pass B  weighted covariance (iva.py:493-499) + IP sweep (iva.py:500-518).
+`algorithm_spatial` in {'ISS', 'pairwise', 'IP2'} is not on the HIP path yet and raises
+NotImplementedError at call time; there is no CPU fallback.
+"""
+import numpy as np
+
+from .._device import to_device, to_numpy, torch
+from .._state import DeviceArray, DeviceState
+from .. import _lib
+from ..ops import Engine
+
+EPS = 1e-12
+THRESHOLD = 1e+12
+
+__algorithms_spatial__ = ['IP', 'IVA', 'ISS', 'IPA', 'pairwise', 'IP1', 'IP2']
+
+
+class IVAbase(DeviceState):
+    """reference: iva.py:22-128"""
+
+    demix_filter = DeviceArray("W", complex_=True)
+
+    def __init__(self, callbacks=None, recordable_loss=True, eps=EPS, *, dtype='float64', device=None):
+        if callbacks is not None:
+            if callable(callbacks):
+                callbacks = [callbacks]
+            self.callbacks = callbacks
+        else:
+            self.callbacks = None
+        self.eps = eps
+
+        self.input = None
+        self.recordable_loss = recordable_loss
+        if self.recordable_loss:
+            self.loss = []
+        else:
+            self.loss = None
+
+        self.dtype = dtype
+        self.device = device
+        self._engine = None
+        self._estimation = None
+
+    def _ensure_engine(self):
+        if self._engine is None:
+            self._engine = Engine(dtype=self.dtype, device=self.device)
+        return self._engine
+
+    def _reset(self, **kwargs):
+        assert self.input is not None, "Specify data!"
+
+        for key in kwargs.keys():
+            setattr(self, key, kwargs[key])
+
+        eng = self._ensure_engine()
+        X = self.input
+        ndim = X.dim() if isinstance(X, torch.Tensor) else np.ndim(X)
+        if ndim not in (3, 4):
+            raise ValueError("input must be (n_channels, n_bins, n_frames), got {} dims".format(ndim))
+        self._batched = ndim == 4
+        Xd = to_device(X, eng.prec.cplx, eng.dev)
+        if not self._batched:
+            Xd = Xd.unsqueeze(0)
+        self._X = Xd.contiguous()
+        B, n_channels, n_bins, n_frames = (int(s) for s in self._X.shape)
+        self._status = eng.new_status(B)
+        n_sources = n_channels  # n_channels == n_sources (iva.py:47)
+
+        self.n_sources, self.n_channels = n_sources, n_channels
+        self.n_bins, self.n_frames = n_bins, n_frames
+
+        if not hasattr(self, 'demix_filter'):
+            W = torch.eye(n_sources, n_channels, dtype=eng.prec.cplx, device=eng.dev)
+            self._set_dev("W", W.repeat(B, n_bins, 1, 1).contiguous())
+        self._estimation = None
+
+    @property
+    def _Wd(self):
+        return self._dev("W", True)
+
+    @property
+    def estimation(self):
+        if self._estimation is None:
+            if getattr(self, "_X", None) is None:
+                raise AttributeError("'{}' object has no attribute 'estimation'".format(type(self).__name__))
+            Y = to_numpy(self._engine.demix(self._X, self._Wd), np.complex128)
+            self._estimation = Y if self._batched else Y[0]
+        return self._estimation
+
+    @estimation.setter
+    def estimation(self, value):
+        self._estimation = value
+
+    def __repr__(self):
+        s = "IVA("
+        s += ")"
+
+        return s.format(**self.__dict__)
+
+    def update_once(self):
+        raise NotImplementedError("Implement 'update_once' function")
+
+    def separate(self, input, demix_filter):
+        """y = W x on the device (iva.py:105-117)."""
+        eng = self._ensure_engine()
+        X = to_device(input, eng.prec.cplx, eng.dev)
+        W = to_device(demix_filter, eng.prec.cplx, eng.dev)
+        batched = X.dim() == 4
+        if not batched:
+            X = X.unsqueeze(0)
+        if W.dim() == 2:
+            W = W.expand(X.shape[2], -1, -1)
+        if W.dim() == 3:
+            W = W.unsqueeze(0).expand(X.shape[0], -1, -1, -1)
+        Y = eng.demix(X.contiguous(), W.contiguous())
+        if isinstance(input, torch.Tensor):
+            return Y if batched else Y[0]
+        Y = to_numpy(Y, np.complex128)
+        return Y if batched else Y[0]
+
+    def compute_negative_loglikelihood(self):
+        raise NotImplementedError("Implement 'compute_negative_loglikelihood' function.")
+
+    def _check_status(self):
+        flags = int(self._status.max().item())
+        if flags & _lib.STATUS_SINGULAR:
+            self._status.zero_()
+            raise np.linalg.LinAlgError("Singular matrix")
+
+
+class AuxIVAbase(IVAbase):
+    """reference: iva.py:289-386"""
+
+    _KIND = None
+    _NAME = "AuxIVA"
+
+    def __init__(self, algorithm_spatial='IP', reference_id=0, callbacks=None, apply_projection_back=True,
+                 recordable_loss=True, eps=EPS, threshold=THRESHOLD, *, dtype='float64', device=None):
+        super().__init__(callbacks=callbacks, recordable_loss=recordable_loss, eps=eps, dtype=dtype, device=device)
+
+        self.algorithm_spatial = algorithm_spatial
+        self.reference_id = reference_id
+        self.apply_projection_back = apply_projection_back
+        self.threshold = threshold
+
+        if not self.algorithm_spatial in __algorithms_spatial__:
+            raise ValueError("Not support {} based spatial updates.".format(self.algorithm_spatial))
+
+        if self.algorithm_spatial in ['pairwise', 'IP2']:
+            self.update_pair = None
+
+    def _require_supported(self):
+        if self._KIND is None:
+            raise NotImplementedError("Implement 'update_once' function.")
+        if self.algorithm_spatial not in ('IP', 'IP1'):
+            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' (no CPU fallback is provided).".format(self.algorithm_spatial))
+
+    def _reset(self, **kwargs):
+        super()._reset(**kwargs)
+        self._require_supported()
+        self._r = None       # r_n(t) of the CURRENT filters; None = stale
+        self._r_src = None
+        self._loss_dev = None
+
+    def _refresh_weights(self, with_loss):
+        """Pass A: r (and the loss of the current filters when asked) in one sweep over X."""
+        self._r, self._loss_dev = self._engine.auxiva_weights(self._X, self._Wd, self._KIND, eps=self.eps,
+                                                             with_loss=with_loss)
+        self._r_src = self._Wd  # the filters these weights belong to (a host-side assignment replaces the tensor)
+
+    def __call__(self, input, iteration=100, **kwargs):
+        """
+        Args:
+            input (n_channels, n_bins, n_frames)
+        Returns:
+            output (n_channels, n_bins, n_frames)
+        """
+        self.input = input
+
+        self._reset(**kwargs)
+
+        if self.recordable_loss:
+            loss = self.compute_negative_loglikelihood()
+            self.loss.append(loss)
+
+        if self.callbacks is not None:
+            for callback in self.callbacks:
+                callback(self)
+
+        for idx in range(iteration):
+            self.update_once()
+
+            if self.recordable_loss:
+                loss = self.compute_negative_loglikelihood()
+                self.loss.append(loss)
+
+            if self.callbacks is not None:
+                for callback in self.callbacks:
+                    callback(self)
+
+        eng = self._engine
+        scale = None
+        if self.apply_projection_back:
+            scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
+        Y = eng.demix(self._X, self._Wd, scale=scale)
+        self._check_status()
+
+        if isinstance(input, torch.Tensor):
+            output = Y if self._batched else Y[0]
+        else:
+            output = to_numpy(Y, np.complex128)
+            output = output if self._batched else output[0]
+        self.estimation = output
+
+        return output
+
+    def __repr__(self):
+        s = self._NAME + "("
+        s += "algorithm_spatial={algorithm_spatial}"
+        s += ")"
+
+        return s.format(**self.__dict__)
+
+    def update_once(self):
+        if self.algorithm_spatial in ['IP', 'IP1']:
+            self.update_once_ip()
+        else:
+            self._require_supported()
+
+    def update_once_ip(self):
+        """iva.py:481-523 / 714-757: weights from the current estimate, covariance, IP sweep."""
+        if self._r is None or self._r_src is not self._Wd:
+            self._refresh_weights(with_loss=False)
+        self._engine.auxiva_spatial_update(self._X, self._Wd, self._r, eps=self.eps, threshold=self.threshold,
+                                           status=self._status)
+        self._touch("W")
+        self._estimation = None
+        self._r = None
+        self._loss_dev = None
+
+    def compute_negative_loglikelihood(self):
+        """iva.py:604-619 / 783-802.  Rides on the r_n(t) pass; syncs to return a Python float."""
+        if self._r is None or self._loss_dev is None or self._r_src is not self._Wd:
+            self._refresh_weights(with_loss=True)
+        self._check_status()
+        if self._batched:
+            return to_numpy(self._loss_dev, np.float64)
+        return np.float64(self._loss_dev.item())
+
+
+class AuxLaplaceIVA(AuxIVAbase):
+    """reference: iva.py:388-619"""
+    _KIND = _lib.IVA_LAPLACE
+    _NAME = "AuxLaplaceIVA"
+
+
+class AuxGaussIVA(AuxIVAbase):
+    """reference: iva.py:621-802"""
+    _KIND = _lib.IVA_GAUSS
+    _NAME = "AuxGaussIVA"

@@ -1,0 +1,90 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/assx.h declares, the ctypes
+table covers the header, and the host-side class logic that needs no GPU behaves like the reference."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, "include", "assx.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(assx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from audio_source_separation_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 20
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libassx.so does not export %s" % n
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and include/assx.h disagree"
+    assert _lib.version().startswith("assx ")
+
+
+def test_workspace_queries_need_no_gpu():
+    from audio_source_separation_amd import _lib
+    n64 = _lib.lib.assx_workspace_bytes(1, 4, 1025, 4096, 4, _lib.F64)
+    n32 = _lib.lib.assx_workspace_bytes(1, 4, 1025, 4096, 4, _lib.F32)
+    assert 0 < n32 < n64 < 1 << 30
+    assert _lib.lib.assx_workspace_bytes(0, 4, 10, 10, 4, _lib.F64) == 0
+    assert _lib.lib.assx_nmf_workspace_bytes(1, 1025, 4096, 32, _lib.F64) > 2 * 1025 * 4096 * 8
+
+
+def test_invalid_context_is_an_error_not_a_crash():
+    from audio_source_separation_amd import _lib
+    rc = _lib.lib.assx_demix(None, None, None, None, None, 1, 4, 8, 8, _lib.F64, None)
+    assert rc == -3  # ASSX_E_NULL
+    assert _lib.lib.assx_last_error(None) == b"ctx is NULL"
+
+
+def test_no_gpu_fails_loudly():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    X = np.ones((2, 4, 8), dtype=np.complex128)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        GaussILRMA(n_basis=2)(X, iteration=1)
+
+
+def test_constructor_contract_matches_reference():
+    from audio_source_separation_amd.algorithm.nmf import EUCNMF, ISNMF, KLNMF
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    from audio_source_separation_amd.bss.iva import AuxGaussIVA, AuxLaplaceIVA
+    m = GaussILRMA()
+    assert (m.n_basis, m.domain, m.partitioning, m.normalize, m.algorithm_spatial, m.reference_id) == \
+        (10, 2, False, "power", "IP", 0)
+    assert m.eps == 1e-12 and m.threshold == 1e12 and m.loss == [] and m.callbacks is None and m.input is None
+    f = lambda model: None  # noqa: E731
+    assert GaussILRMA(callbacks=f).callbacks == [f]  # a single callable is wrapped (ilrma.py:27-32)
+    assert GaussILRMA(recordable_loss=False).loss is None
+    assert GaussILRMA(algorithm_spatial="IP2").update_pair is None
+    for bad in ("IVA", "IPA"):
+        with pytest.raises(AssertionError):
+            GaussILRMA(algorithm_spatial=bad)
+    with pytest.raises(AssertionError):
+        GaussILRMA(algorithm_spatial="nope")
+    a = AuxLaplaceIVA()
+    assert (a.algorithm_spatial, a.reference_id, a.apply_projection_back, a.threshold) == ("IP", 0, True, 1e12)
+    assert repr(a) == "AuxLaplaceIVA(algorithm_spatial=IP)" and repr(AuxGaussIVA()) == "AuxGaussIVA(algorithm_spatial=IP)"
+    with pytest.raises(ValueError):
+        AuxGaussIVA(algorithm_spatial="nope")
+    for cls in (EUCNMF, KLNMF, ISNMF):
+        n = cls()
+        assert (n.n_basis, n.domain, n.algorithm, n.eps, n.loss) == (2, 2, "mm", 1e-12, [])
+        with pytest.raises(AssertionError):
+            cls(domain=0.5)
+    with pytest.raises(AssertionError):
+        EUCNMF(algorithm="me")
+    assert ISNMF(algorithm="me").algorithm == "me"
+    assert not hasattr(m, "demix_filter") and not hasattr(m, "basis") and not hasattr(m, "activation")
+    m.demix_filter = np.zeros((3, 2, 2), dtype=np.complex128)
+    assert hasattr(m, "demix_filter") and m.demix_filter.shape == (3, 2, 2)
