@@ -37,6 +37,7 @@ SIGNATURES = {
     "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),
     "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_spatial_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_cov_partials": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_demix_power": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_power_from_cov": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "assx_ilrma_normalize_power": (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _i, _vp]),

@@ -985,10 +985,11 @@ inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / 
 
 // covariance (any weight kind) into dense U; returns error code
 template <typename R, int M>
-int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K, double domain,
-            double eps, void* U, void* ws, int B, int F, int T, hipStream_t st) {
+int run_cov_partial(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K,
+                    double domain, double eps, void* ws, int B, int F, int T, hipStream_t st, int* TS_out) {
   int TS, tchunk;
   t_split(B, F, T, &TS, &tchunk);
+  *TS_out = TS;
   CovArgs<R> a;
   a.X = (const Cx<R>*)X;
   a.r = (const R*)r;
@@ -1001,7 +1002,6 @@ int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb,
   a.eps = (R)eps;
   a.p2d = make_pow(2.0 / domain);
   dim3 grid((unsigned)F * TS, B), block(64);
-  const int N = (wk == WK_NONE) ? 1 : M;
   switch (wk) {
     case WK_NONE: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NONE, true>), grid, block, 0, st, a); break;
     case WK_NT: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NT, true>), grid, block, 0, st, a); break;
@@ -1011,6 +1011,16 @@ int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb,
       else hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_TV, false>), grid, block, 0, st, a);
   }
   ASSX_LAUNCH_CHECK(ctx, "cov_partial_kernel");
+  return 0;
+}
+
+template <typename R, int M>
+int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K, double domain,
+            double eps, void* U, void* ws, int B, int F, int T, hipStream_t st) {
+  int TS = 1;
+  int rc = run_cov_partial<R, M>(ctx, wk, X, r, Tb, V, K, domain, eps, ws, B, F, T, st, &TS);
+  if (rc) return rc;
+  const int N = (wk == WK_NONE) ? 1 : M;
   const size_t total = (size_t)B * N * F * M * M;
   hipLaunchKernelGGL((cov_finalize_kernel<R, M>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const R*)ws,
                      (Cx<R>*)U, B, N, F, TS, (R)(1.0 / (double)T));
@@ -1146,6 +1156,20 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void*
     int rc = run_cov<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, U, ws, B, F, T, st);
     if (rc) return rc;
     return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+  });
+}
+
+int assx_ilrma_cov_partials(assx_ctx* ctx, const void* X, const void* Tb, const void* V, double domain, double eps,
+                            void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_cov_partials: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int TS;
+    return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, &TS);
   });
 }
 

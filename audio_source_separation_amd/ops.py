@@ -92,6 +92,14 @@ class Engine:
                                                 float(threshold), ptr(U_out), ptr(status), ptr(ws), B, M, F, T, K,
                                                 self.prec.code, self._st()), "assx_ilrma_spatial_update")
 
+    def ilrma_cov_partials(self, X, Tb, V, domain=2, eps=1e-12):
+        """ONE launch of the covariance-accumulate kernel (stage 1 of ilrma_spatial_update); for kernel timing."""
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_ilrma_cov_partials(self.ctx, ptr(X), ptr(Tb), ptr(V), float(domain), float(eps), ptr(ws),
+                                              B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_cov_partials")
+
     def demix_power(self, X, W, out=None):
         B, M, F, T = self._dims(X)
         p = out if out is not None else self.empty((B, M))

@@ -107,6 +107,11 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void*
                               int32_t* status, void* ws,
                               int B, int M, int F, int T, int K, int dtype, void* stream);
 
+/* Stage 1 of assx_ilrma_spatial_update alone: ONE launch of the covariance-accumulate kernel (packed
+ * Hermitian partial sums into ws).  Exposed so a harness can time exactly that kernel with HIP events. */
+int assx_ilrma_cov_partials(assx_ctx* ctx, const void* X, const void* Tb, const void* V, double domain, double eps,
+                            void* ws, int B, int M, int F, int T, int K, int dtype, void* stream);
+
 /* ---- (a6) normalisation ---------------------------------------------------------------- */
 /* power[b,n] = mean_{f,t} |(W x)_n|^2  (src/bss/ilrma.py:298-306), one pass over X. */
 int assx_demix_power(assx_ctx* ctx, const void* X, const void* W, void* power /* (B,N) real */, void* ws,
