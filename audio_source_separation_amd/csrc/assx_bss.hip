@@ -16,19 +16,13 @@
 // Reference citations: see include/assx.h next to each entry point.
 #include "assx_common.hpp"
 #include "assx_small_linalg.hpp"
+#include "assx_stream.hpp"
 
 using namespace assx;
 
 namespace {
 
-enum { WK_NONE = 0, WK_NT = 1, WK_NFT = 2, WK_TV = 3 };
-
-constexpr int KU = 4;        // k-unroll of the NMF contractions (K <= 4 is the single-chunk fast path)
 constexpr int REDUCE_THREADS = 256;
-
-struct Dims {
-  int B, F, T, K;
-};
 
 // ------------------------------------------------------------------------------------------
 // small device helpers
@@ -51,13 +45,6 @@ __device__ __forceinline__ void demix(const Cx<R> (&w)[M][M], const Cx<R> (&x)[M
     for (int m = 0; m < M; ++m) cfma(s, w[n][m], x[m]);
     y[n] = s;
   }
-}
-
-// packed Hermitian index: [0,M) diagonal (real), then pairs (m<l) as (re, im)
-template <int M>
-__host__ __device__ constexpr int herm_pair_base(int m, int l) {  // requires m < l
-  // pairs ordered (0,1),(0,2),...,(0,M-1),(1,2),...
-  return M + 2 * (m * M - m * (m + 1) / 2 + (l - m - 1));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -84,127 +71,6 @@ __global__ void __launch_bounds__(256) demix_kernel(const Cx<R>* __restrict__ X,
     if (scale) v = cmul(v, scale[((size_t)b * M + n) * d.F + f]);
     yb[n * FT] = v;
   }
-}
-
-// ------------------------------------------------------------------------------------------
-// (a4) weighted covariance partials: one wave per (b, f, t-split)
-//      part[b][ts][f][n*HM + h],  HM = M*M packed-Hermitian reals (un-normalised sums)
-// ------------------------------------------------------------------------------------------
-template <typename R>
-struct CovArgs {
-  const Cx<R>* X;
-  const R* r;    // WK_NT: (B,N,T)  WK_NFT: (B,N,F,T)
-  const R* Tb;   // WK_TV: (B,N,F,K)
-  const R* V;    // WK_TV: (B,N,K,T)
-  R* part;
-  Dims d;
-  int TS, tchunk;
-  R eps;
-  PowSpec p2d;   // 2/domain
-};
-
-template <typename R, int M, int WK, bool K4>
-__global__ void __launch_bounds__(64) cov_partial_kernel(CovArgs<R> a) {
-  constexpr int N = (WK == WK_NONE) ? 1 : M;
-  constexpr int HM = M * M;
-  constexpr int NV = next_pow2_c(N * HM);
-  const int f = blockIdx.x / a.TS, ts = blockIdx.x % a.TS, b = blockIdx.y;
-  const int lane = threadIdx.x;
-  const int F = a.d.F, T = a.d.T, K = a.d.K;
-  const size_t FT = (size_t)F * T;
-  const Cx<R>* xb = a.X + (size_t)b * M * FT + (size_t)f * T;
-
-  R acc[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) acc[i] = 0;
-
-  R tb[N][KU];
-  if (WK == WK_TV && K4) {
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-      for (int kk = 0; kk < KU; ++kk)
-        tb[n][kk] = (kk < K) ? a.Tb[(((size_t)b * N + n) * F + f) * K + kk] : (R)0;
-  }
-
-  const int t0 = ts * a.tchunk;
-  const int t1 = min(T, t0 + a.tchunk);
-  for (int t = t0 + lane; t < t1; t += WAVE) {
-    Cx<R> x[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
-    R p[HM];
-#pragma unroll
-    for (int m = 0; m < M; ++m) p[m] = cabs2(x[m]);
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int l = m + 1; l < M; ++l) {
-        Cx<R> q = cmulc(x[m], x[l]);
-        p[herm_pair_base<M>(m, l)] = q.x;
-        p[herm_pair_base<M>(m, l) + 1] = q.y;
-      }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      R wgt;
-      if (WK == WK_NONE) {
-        wgt = 1;
-      } else {
-        R r;
-        if (WK == WK_NT) {
-          r = a.r[((size_t)b * N + n) * T + t];
-        } else if (WK == WK_NFT) {
-          r = a.r[(((size_t)b * N + n) * F + f) * T + t];
-        } else {
-          const R* vb = a.V + ((size_t)b * N + n) * K * T + t;
-          R tv = 0;
-          if (K4) {
-#pragma unroll
-            for (int kk = 0; kk < KU; ++kk) tv = fma(tb[n][kk], vb[(size_t)min(kk, K - 1) * T], tv);
-          } else {
-            const R* tbn = a.Tb + (((size_t)b * N + n) * F + f) * K;
-            for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
-          }
-          r = powspec<R>(tv, a.p2d);  // R = (T V)^(2/domain), floored AFTER the power (ilrma.py:499-509)
-        }
-        wgt = (R)1 / floor_eps<R>(r, a.eps);
-      }
-#pragma unroll
-      for (int h = 0; h < HM; ++h) acc[n * HM + h] = fma(wgt, p[h], acc[n * HM + h]);
-    }
-  }
-  R tot = wave_reduce_scatter<R, NV>(acc);
-  const int i = scatter_index<NV>();
-  if (scatter_leader<NV>() && i < N * HM)
-    a.part[(((size_t)b * a.TS + ts) * F + f) * (N * HM) + i] = tot;
-}
-
-// sum t-splits, scale by 1/T, expand packed Hermitian -> dense U (B,N,F,M,M) complex
-template <typename R, int M>
-__global__ void __launch_bounds__(256) cov_finalize_kernel(const R* __restrict__ part, Cx<R>* __restrict__ U,
-                                                          int B, int N, int F, int TS, R inv_T) {
-  constexpr int HM = M * M;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)B * N * F * HM;
-  if (idx >= total) return;
-  const int l = idx % M, m = (idx / M) % M;
-  const int f = (idx / HM) % F;
-  const int n = (idx / ((size_t)HM * F)) % N;
-  const int b = idx / ((size_t)HM * F * N);
-  R re = 0, im = 0;
-  for (int ts = 0; ts < TS; ++ts) {
-    const R* p = part + (((size_t)b * TS + ts) * F + f) * (N * HM) + n * HM;
-    if (m == l) {
-      re += p[m];
-    } else {
-      const int lo = min(m, l), hi = max(m, l);
-      const int base = herm_pair_base<M>(lo, hi);
-      re += p[base];
-      im += p[base + 1];
-    }
-  }
-  if (m > l) im = -im;
-  U[idx] = cmake<R>(re * inv_T, im * inv_T);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -284,118 +150,6 @@ __global__ void __launch_bounds__(64) ip_kernel(const Cx<R>* __restrict__ U, Cx<
 }
 
 // ------------------------------------------------------------------------------------------
-// (a2) ILRMA source model, basis half: one wave per (b, f, t-split)
-//      part[b][ts][f][(n*K + k)*2 + {num, den}]
-// ------------------------------------------------------------------------------------------
-template <typename R>
-struct NmfArgs {
-  const Cx<R>* X;
-  const Cx<R>* W;
-  const R* Tb;
-  const R* V;
-  R* part;
-  Dims d;
-  int S, chunk;   // number of splits and split length (t-splits for basis, f-splits for activation)
-  R eps;
-  PowSpec p1;     // (domain+2)/domain
-};
-
-template <typename R, int M, bool K4>
-__global__ void __launch_bounds__(64) ilrma_basis_partial_kernel(NmfArgs<R> a) {
-  constexpr int N = M;
-  constexpr int NV = next_pow2_c(2 * N * KU);
-  const int f = blockIdx.x / a.S, ts = blockIdx.x % a.S, b = blockIdx.y;
-  const int lane = threadIdx.x;
-  const int F = a.d.F, T = a.d.T, K = a.d.K;
-  const size_t FT = (size_t)F * T;
-  const Cx<R>* xb = a.X + (size_t)b * M * FT + (size_t)f * T;
-  Cx<R> w[M][M];
-  load_filter<R, M>(a.W, (size_t)b * F + f, w);
-  const R* tbase = a.Tb + ((size_t)b * N * F + f) * K;  // + n*F*K + k
-  const int t0 = ts * a.chunk;
-  const int t1 = min(T, t0 + a.chunk);
-  R* out = a.part + (((size_t)b * a.S + ts) * F + f) * (size_t)(N * K * 2);
-
-  const int nchunks = K4 ? 1 : (K + KU - 1) / KU;
-  for (int c = 0; c < nchunks; ++c) {
-    const int k0 = c * KU;
-    R acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0;
-    R tb[N][KU];
-    if (K4) {
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) tb[n][kk] = (kk < K) ? tbase[(size_t)n * F * K + kk] : (R)0;
-    }
-    for (int t = t0 + lane; t < t1; t += WAVE) {
-      Cx<R> x[M], y[M];
-#pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
-      demix<R, M>(w, x, y);
-#pragma unroll
-      for (int n = 0; n < N; ++n) {
-        const R P = cabs2(y[n]);
-        const R* vb = a.V + ((size_t)b * N + n) * K * T + t;
-        R v[KU];
-        R tv = 0;
-        if (K4) {
-#pragma unroll
-          for (int kk = 0; kk < KU; ++kk) {
-            v[kk] = vb[(size_t)min(kk, K - 1) * T];
-            tv = fma(tb[n][kk], v[kk], tv);
-          }
-        } else {
-          const R* tbn = tbase + (size_t)n * F * K;
-          for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
-#pragma unroll
-          for (int kk = 0; kk < KU; ++kk) v[kk] = (k0 + kk < K) ? vb[(size_t)(k0 + kk) * T] : (R)0;
-        }
-        tv = floor_eps<R>(tv, a.eps);
-        const R inv = (R)1 / tv;                                  // TV_inverse
-        const R D = (a.p1.mode == POW_SQUARE) ? P * inv * inv      // division = P / TV**((d+2)/d)
-                                              : P / powspec<R>(tv, a.p1);
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
-          acc[(n * KU + kk) * 2 + 0] = fma(D, v[kk], acc[(n * KU + kk) * 2 + 0]);
-          acc[(n * KU + kk) * 2 + 1] = fma(inv, v[kk], acc[(n * KU + kk) * 2 + 1]);
-        }
-      }
-    }
-    R tot = wave_reduce_scatter<R, NV>(acc);
-    const int i = scatter_index<NV>();
-    if (scatter_leader<NV>() && i < 2 * N * KU) {
-      const int s = i & 1, kk = (i >> 1) % KU, n = (i >> 1) / KU;
-      const int k = k0 + kk;
-      if (k < K) out[(n * K + k) * 2 + s] = tot;
-    }
-  }
-}
-
-// T *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:417-419)
-template <typename R>
-__global__ void __launch_bounds__(256) ilrma_basis_finalize_kernel(const R* __restrict__ part, R* __restrict__ Tb,
-                                                                  int B, int N, int F, int K, int TS, R eps,
-                                                                  PowSpec p2) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)B * N * F * K;
-  if (idx >= total) return;
-  const int k = idx % K;
-  const int f = (idx / K) % F;
-  const int n = (idx / ((size_t)K * F)) % N;
-  const int b = idx / ((size_t)K * F * N);
-  R num = 0, den = 0;
-  for (int ts = 0; ts < TS; ++ts) {
-    const R* p = part + (((size_t)b * TS + ts) * F + f) * (size_t)(N * K * 2) + (n * K + k) * 2;
-    num += p[0];
-    den += p[1];
-  }
-  den = floor_eps<R>(den, eps);
-  Tb[idx] = Tb[idx] * powspec<R>(num / den, p2);
-}
-
-// ------------------------------------------------------------------------------------------
 // (a2) activation half: lanes own t; 4 waves stride over the f-split; LDS cross-wave reduce
 //      part[b][fs][(n*K + k)*2 + s][t]
 // ------------------------------------------------------------------------------------------
@@ -422,109 +176,6 @@ __device__ __forceinline__ void block4_reduce_to_wave0(R (&acc)[NV], R* lds /* [
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] += lds[i * WAVE + lane];
   }
-}
-
-template <typename R, int M, bool K4>
-__global__ void __launch_bounds__(256) ilrma_act_partial_kernel(NmfArgs<R> a) {
-  constexpr int N = M;
-  constexpr int NV = 2 * N * KU;
-  __shared__ R lds[2 * NV * WAVE];
-  const int tb_ = blockIdx.x, fs = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int F = a.d.F, T = a.d.T, K = a.d.K;
-  const size_t FT = (size_t)F * T;
-  const int t = tb_ * WAVE + lane;
-  const bool valid = t < T;
-  const int tc = valid ? t : T - 1;
-  const int f0 = fs * a.chunk, f1 = min(F, f0 + a.chunk);
-  const Cx<R>* xb = a.X + (size_t)b * M * FT + tc;
-
-  const int nchunks = K4 ? 1 : (K + KU - 1) / KU;
-  for (int c = 0; c < nchunks; ++c) {
-    const int k0 = c * KU;
-    R acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0;
-    R v[N][KU];
-#pragma unroll
-    for (int n = 0; n < N; ++n)
-#pragma unroll
-      for (int kk = 0; kk < KU; ++kk) {
-        const int k = K4 ? min(kk, K - 1) : min(k0 + kk, K - 1);
-        v[n][kk] = a.V[(((size_t)b * N + n) * K + k) * T + tc];
-      }
-    for (int f = f0 + wv; f < f1; f += 4) {
-      Cx<R> w[M][M];
-      load_filter<R, M>(a.W, (size_t)b * F + f, w);
-      Cx<R> x[M], y[M];
-#pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = xb[m * FT + (size_t)f * T];
-      demix<R, M>(w, x, y);
-#pragma unroll
-      for (int n = 0; n < N; ++n) {
-        const R P = cabs2(y[n]);
-        const R* tbn = a.Tb + (((size_t)b * N + n) * F + f) * K;
-        R tk[KU];
-        R tv = 0;
-        if (K4) {
-#pragma unroll
-          for (int kk = 0; kk < KU; ++kk) {
-            tk[kk] = (kk < K) ? tbn[kk] : (R)0;
-            tv = fma(tk[kk], v[n][kk], tv);
-          }
-        } else {
-          const R* vb = a.V + ((size_t)b * N + n) * K * T + tc;
-          for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
-#pragma unroll
-          for (int kk = 0; kk < KU; ++kk) tk[kk] = (k0 + kk < K) ? tbn[k0 + kk] : (R)0;
-        }
-        tv = floor_eps<R>(tv, a.eps);
-        const R inv = (R)1 / tv;
-        const R D = (a.p1.mode == POW_SQUARE) ? P * inv * inv : P / powspec<R>(tv, a.p1);
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
-          acc[(n * KU + kk) * 2 + 0] = fma(tk[kk], D, acc[(n * KU + kk) * 2 + 0]);
-          acc[(n * KU + kk) * 2 + 1] = fma(tk[kk], inv, acc[(n * KU + kk) * 2 + 1]);
-        }
-      }
-    }
-    block4_reduce_to_wave0<R, NV>(acc, lds);
-    if (wv == 0 && valid) {
-      R* out = a.part + ((size_t)b * a.S + fs) * (size_t)(N * K * 2) * T + t;
-#pragma unroll
-      for (int n = 0; n < N; ++n)
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) {
-          const int k = k0 + kk;
-          if (k < K) {
-            out[(size_t)((n * K + k) * 2 + 0) * T] = acc[(n * KU + kk) * 2 + 0];
-            out[(size_t)((n * K + k) * 2 + 1) * T] = acc[(n * KU + kk) * 2 + 1];
-          }
-        }
-    }
-    __syncthreads();
-  }
-}
-
-// V *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:426-428)
-template <typename R>
-__global__ void __launch_bounds__(256) ilrma_act_finalize_kernel(const R* __restrict__ part, R* __restrict__ V,
-                                                                int B, int N, int K, int T, int FS, R eps, PowSpec p2) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t total = (size_t)B * N * K * T;
-  if (idx >= total) return;
-  const int t = idx % T;
-  const int nk = (idx / T) % (N * K);
-  const int b = idx / ((size_t)T * N * K);
-  R num = 0, den = 0;
-  for (int fs = 0; fs < FS; ++fs) {
-    const R* p = part + (((size_t)b * FS + fs) * (size_t)(N * K * 2) + nk * 2) * T + t;
-    num += p[0];
-    den += p[T];
-  }
-  den = floor_eps<R>(den, eps);
-  V[idx] = V[idx] * powspec<R>(num / den, p2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -660,8 +311,19 @@ __device__ __forceinline__ double neg2T_logabsdet(const Cx<R>* __restrict__ W, s
   return -2.0 * (double)T * log(hypot(det.x, det.y));
 }
 
+template <typename R>
+struct LossArgs {
+  const Cx<R>* X;
+  const Cx<R>* W;
+  const R* Tb;
+  const R* V;
+  Dims d;
+  int S, chunk;  // t-splits and their length
+  R eps;
+};
+
 template <typename R, int M, bool K4>
-__global__ void __launch_bounds__(64) ilrma_loss_partial_kernel(NmfArgs<R> a, double* __restrict__ lpart, PowSpec p2d) {
+__global__ void __launch_bounds__(64) ilrma_loss_partial_kernel(LossArgs<R> a, double* __restrict__ lpart, PowSpec p2d) {
   constexpr int N = M;
   const int f = blockIdx.x / a.S, ts = blockIdx.x % a.S, b = blockIdx.y;
   const int lane = threadIdx.x;
@@ -924,15 +586,44 @@ struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte al
   size_t total;
 };
 
+// Flat partitions of the streaming kernels.  Deterministic by construction (MI355X geometry: 256 CUs; the
+// workgroups-per-CU figures are what the kernels' VGPR budgets admit), so the summation order -- hence every
+// result bit -- does not depend on a runtime occupancy query.  ASSX_ROUNDS scales the oversubscription.
+constexpr int CHIP_CUS = 256;
+
+inline long long g_target(int wgs_per_cu) {
+  static const int rounds = env_int("ASSX_ROUNDS", 1);
+  static const int forced = env_int("ASSX_G", 0);
+  if (forced > 0) return forced;
+  return (long long)CHIP_CUS * wgs_per_cu * (rounds < 1 ? 1 : rounds);
+}
+
+inline int tblocks(int T) { return (T + WAVE - 1) / WAVE; }
+
+// cov_stream_kernel: 1 wave per workgroup, 2 waves/SIMD; blocks of 64/LS frames
+template <typename R, int M>
+constexpr int cov_lane_split() { return 1; }
+inline FlatPart flat_cov(int B, int F, int T, int LS) {
+  const int fb = WAVE / LS, tbk = (T + fb - 1) / fb;
+  return make_flat((long long)B * F * tbk, tbk, g_target(8));
+}
+inline FlatPart flat_basis(int B, int F, int T) {  // basis_stream_kernel: 1 wave per workgroup, 2 waves/SIMD
+  return make_flat((long long)B * F * tblocks(T), tblocks(T), g_target(8));
+}
+inline FlatPart flat_act(int B, int F, int T) {    // act_stream_kernel: ACT_NH waves per workgroup, 2 waves/SIMD
+  return make_flat((long long)B * tblocks(T) * F, F, g_target(4));
+}
+
 inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   const int Kc = K < 1 ? 1 : K;
   int TS, tchunk, FS, fchunk;
   t_split(B, F, T, &TS, &tchunk);
   f_split(B, F, T, &FS, &fchunk);
-  size_t p_cov = (size_t)B * TS * F * (M * M * M);
-  size_t p_basis = (size_t)B * TS * F * (M * Kc * 2);
-  size_t p_act = (size_t)B * FS * (M * Kc * 2) * T;
+  const FlatPart fc = flat_cov(B, F, T, 1), fb = flat_basis(B, F, T), fa = flat_act(B, F, T);
+  size_t p_cov = (size_t)fc.G * fc.S * (M * M * M);
+  size_t p_basis = (size_t)fb.G * fb.S * (M * Kc * 2);
+  size_t p_act = (size_t)fa.G * fa.S * (M * Kc * 2) * WAVE;
   size_t p_pb = (size_t)B * TS * F * (M * M + 2 * M);
   size_t p_pow = (size_t)B * M * TS * F;
   size_t p_aux = (size_t)B * FS * M * T;
@@ -983,48 +674,48 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
 
 inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
-// covariance (any weight kind) into dense U; returns error code
+// covariance (any weight kind): streaming partials, then dense U; returns error code
 template <typename R, int M>
 int run_cov_partial(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K,
-                    double domain, double eps, void* ws, int B, int F, int T, hipStream_t st, int* TS_out) {
-  int TS, tchunk;
-  t_split(B, F, T, &TS, &tchunk);
-  *TS_out = TS;
+                    double domain, double eps, void* ws, int B, int F, int T, hipStream_t st, FlatPart* fp_out) {
   CovArgs<R> a;
-  a.X = (const Cx<R>*)X;
-  a.r = (const R*)r;
-  a.Tb = (const R*)Tb;
-  a.V = (const R*)V;
-  a.part = (R*)ws;
   a.d = Dims{B, F, T, K};
-  a.TS = TS;
-  a.tchunk = tchunk;
+  a.fp = flat_cov(B, F, T, wk == WK_NONE ? 1 : cov_lane_split<R, M>());
   a.eps = (R)eps;
   a.p2d = make_pow(2.0 / domain);
-  dim3 grid((unsigned)F * TS, B), block(64);
+  *fp_out = a.fp;
+  dim3 grid((unsigned)a.fp.G);
+  const bool d2 = a.p2d.mode == POW_ID;
+#define COV_LAUNCH(WKV, K4V, D2V, LSV, DXV, DWV, MW) \
+  hipLaunchKernelGGL((cov_stream_kernel<R, M, WKV, K4V, D2V, LSV, DXV, DWV, MW>), grid, dim3(64), 0, st, \
+                     (const Cx<R>*)X, (const R*)r, (const R*)Tb, (const R*)V, (R*)ws, a)
+  constexpr int LSX = cov_lane_split<R, M>();
   switch (wk) {
-    case WK_NONE: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NONE, true>), grid, block, 0, st, a); break;
-    case WK_NT: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NT, true>), grid, block, 0, st, a); break;
-    case WK_NFT: hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_NFT, true>), grid, block, 0, st, a); break;
+    case WK_NONE: COV_LAUNCH(WK_NONE, true, true, 1, 4, 1, 1); break;
+    case WK_NT: COV_LAUNCH(WK_NT, true, true, LSX, 3, 1, 2); break;
+    case WK_NFT: COV_LAUNCH(WK_NFT, true, true, LSX, 3, 1, 2); break;
     default:
-      if (K <= KU) hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_TV, true>), grid, block, 0, st, a);
-      else hipLaunchKernelGGL((cov_partial_kernel<R, M, WK_TV, false>), grid, block, 0, st, a);
+      if (K <= KU && d2) COV_LAUNCH(WK_TV, true, true, LSX, (sizeof(R) == 8 ? 2 : 4), 1, 2);
+      else if (K <= KU) COV_LAUNCH(WK_TV, true, false, LSX, 2, 1, 1);
+      else if (d2) COV_LAUNCH(WK_TV, false, true, LSX, 4, 1, 1);
+      else COV_LAUNCH(WK_TV, false, false, LSX, 2, 1, 1);
   }
-  ASSX_LAUNCH_CHECK(ctx, "cov_partial_kernel");
+#undef COV_LAUNCH
+  ASSX_LAUNCH_CHECK(ctx, "cov_stream_kernel");
   return 0;
 }
 
 template <typename R, int M>
 int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K, double domain,
             double eps, void* U, void* ws, int B, int F, int T, hipStream_t st) {
-  int TS = 1;
-  int rc = run_cov_partial<R, M>(ctx, wk, X, r, Tb, V, K, domain, eps, ws, B, F, T, st, &TS);
+  FlatPart fp;
+  int rc = run_cov_partial<R, M>(ctx, wk, X, r, Tb, V, K, domain, eps, ws, B, F, T, st, &fp);
   if (rc) return rc;
   const int N = (wk == WK_NONE) ? 1 : M;
   const size_t total = (size_t)B * N * F * M * M;
-  hipLaunchKernelGGL((cov_finalize_kernel<R, M>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const R*)ws,
-                     (Cx<R>*)U, B, N, F, TS, (R)(1.0 / (double)T));
-  ASSX_LAUNCH_CHECK(ctx, "cov_finalize_kernel");
+  hipLaunchKernelGGL((cov_stream_finalize_kernel<R, M>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const R*)ws,
+                     (Cx<R>*)U, B, N, F, fp, (R)(1.0 / (double)T));
+  ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
   return 0;
 }
 
@@ -1104,38 +795,47 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     constexpr int MM = decltype(mt)::value;
     const PowSpec p1 = make_pow((domain + 2.0) / domain), p2 = make_pow(domain / (domain + 2.0));
     NmfArgs<R> a;
-    a.X = (const Cx<R>*)X;
-    a.W = (const Cx<R>*)W;
-    a.Tb = (const R*)Tb;
-    a.V = (const R*)V;
-    a.part = (R*)ws;
     a.d = Dims{B, F, T, K};
     a.eps = (R)eps;
     a.p1 = p1;
-    // ---- basis
-    int TS, tchunk;
-    t_split(B, F, T, &TS, &tchunk);
-    a.S = TS;
-    a.chunk = tchunk;
-    dim3 grid((unsigned)F * TS, B);
-    if (K <= KU) hipLaunchKernelGGL((ilrma_basis_partial_kernel<R, MM, true>), grid, dim3(64), 0, st, a);
-    else hipLaunchKernelGGL((ilrma_basis_partial_kernel<R, MM, false>), grid, dim3(64), 0, st, a);
-    ASSX_LAUNCH_CHECK(ctx, "ilrma_basis_partial_kernel");
-    hipLaunchKernelGGL((ilrma_basis_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
-                       st, (const R*)ws, (R*)Tb, B, MM, F, K, TS, (R)eps, p2);
-    ASSX_LAUNCH_CHECK(ctx, "ilrma_basis_finalize_kernel");
-    // ---- activation (uses the new basis)
-    int FS, fchunk;
-    f_split(B, F, T, &FS, &fchunk);
-    a.S = FS;
-    a.chunk = fchunk;
-    dim3 grid2(blocks_for(T, WAVE), FS, B);
-    if (K <= KU) hipLaunchKernelGGL((ilrma_act_partial_kernel<R, MM, true>), grid2, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((ilrma_act_partial_kernel<R, MM, false>), grid2, dim3(256), 0, st, a);
-    ASSX_LAUNCH_CHECK(ctx, "ilrma_act_partial_kernel");
-    hipLaunchKernelGGL((ilrma_act_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
-                       (const R*)ws, (R*)V, B, MM, K, T, FS, (R)eps, p2);
-    ASSX_LAUNCH_CHECK(ctx, "ilrma_act_finalize_kernel");
+    const bool d2 = p1.mode == POW_SQUARE;
+    const bool k4 = K <= KU;
+    const Cx<R>* Xp = (const Cx<R>*)X;
+    const Cx<R>* Wp = (const Cx<R>*)W;
+    // ---- basis (reduce over t)
+    a.fp = flat_basis(B, F, T);
+    {
+      const dim3 gb(a.fp.G), bb(64);
+#define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
+  hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, Xp, Wp, (const R*)Tb, \
+                     (const R*)V, (R*)ws, a)
+      if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
+      else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
+      else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
+      else BASIS_LAUNCH(false, false, 2, 1, 1);
+#undef BASIS_LAUNCH
+    }
+    ASSX_LAUNCH_CHECK(ctx, "basis_stream_kernel");
+    hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
+                       st, (const R*)ws, (R*)Tb, B, MM, F, K, a.fp, (R)eps, p2);
+    ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
+    // ---- activation (reduce over f; uses the new basis)
+    a.fp = flat_act(B, F, T);
+    {
+      const dim3 ga(a.fp.G), ba(64 * ACT_NH);
+#define ACT_LAUNCH(K4V, D2V, DXV, MW) \
+  hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, Xp, Wp, (const R*)Tb, \
+                     (const R*)V, (R*)ws, a)
+      if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
+      else if (k4) ACT_LAUNCH(true, false, 2, 1);
+      else if (d2) ACT_LAUNCH(false, true, 4, 1);
+      else ACT_LAUNCH(false, false, 2, 1);
+#undef ACT_LAUNCH
+    }
+    ASSX_LAUNCH_CHECK(ctx, "act_stream_kernel");
+    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
+                       (const R*)ws, (R*)V, B, MM, F, K, T, a.fp, (R)eps, p2);
+    ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
     return 0;
   });
 }
@@ -1168,8 +868,8 @@ int assx_ilrma_cov_partials(assx_ctx* ctx, const void* X, const void* Tb, const 
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    int TS;
-    return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, &TS);
+    FlatPart fp;
+    return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, &fp);
   });
 }
 
@@ -1264,17 +964,15 @@ int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
     constexpr int MM = decltype(mt)::value;
     int TS, tchunk;
     t_split(B, F, T, &TS, &tchunk);
-    NmfArgs<R> a;
+    LossArgs<R> a;
     a.X = (const Cx<R>*)X;
     a.W = (const Cx<R>*)W;
     a.Tb = (const R*)Tb;
     a.V = (const R*)V;
-    a.part = nullptr;
     a.d = Dims{B, F, T, K};
     a.S = TS;
     a.chunk = tchunk;
     a.eps = (R)eps;
-    a.p1 = make_pow(1.0);
     const PowSpec p2d = make_pow(2.0 / domain);
     dim3 grid((unsigned)F * TS, B);
     if (K <= KU) hipLaunchKernelGGL((ilrma_loss_partial_kernel<R, MM, true>), grid, dim3(64), 0, st, a, lpart, p2d);

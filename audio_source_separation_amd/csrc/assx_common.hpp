@@ -58,6 +58,11 @@ struct alignas(2 * sizeof(R)) Cx {
   R x, y;
 };
 
+// native 2-vector of the real type: the register / LDS image of one complex sample (a single 8- or 16-byte
+// load/store; arrays of these stay in VGPRs where arrays of the aligned struct sometimes fall to scratch)
+template <typename R>
+using Vec2 = R __attribute__((ext_vector_type(2)));
+
 template <typename R>
 __host__ __device__ __forceinline__ Cx<R> cmake(R a, R b) {
   Cx<R> c;
@@ -65,6 +70,10 @@ __host__ __device__ __forceinline__ Cx<R> cmake(R a, R b) {
   c.y = b;
   return c;
 }
+template <typename R>
+__device__ __forceinline__ Vec2<R> ldv(const Cx<R>* p) { return *reinterpret_cast<const Vec2<R>*>(p); }
+template <typename R>
+__device__ __forceinline__ Cx<R> tocx(Vec2<R> v) { return cmake<R>(v.x, v.y); }
 template <typename R>
 __device__ __forceinline__ Cx<R> cadd(Cx<R> a, Cx<R> b) { return cmake<R>(a.x + b.x, a.y + b.y); }
 template <typename R>
@@ -146,6 +155,19 @@ __device__ __forceinline__ R powspec(R x, PowSpec p) {
   }
 }
 
+// Pin a wave-uniform value into SGPRs.  Kernel arguments travel in structs, so the compiler cannot prove the
+// read-only arrays do not alias the output and falls back to vector loads for uniform addresses; without this
+// every per-bin constant (basis row, demixing row) would occupy a VGPR per lane.
+__device__ __forceinline__ double uniform_value(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readfirstlane(lo);
+  hi = __builtin_amdgcn_readfirstlane(hi);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float uniform_value(float v) {
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
 template <typename R>
 __device__ __forceinline__ R floor_eps(R v, R eps) {  // numpy: v[v < eps] = eps (NaN stays NaN)
   return (v < eps) ? eps : v;
@@ -164,14 +186,15 @@ __device__ __forceinline__ R wave_allreduce_sum(R v) {
 constexpr int ilog2_c(int n) { return n <= 1 ? 0 : 1 + ilog2_c(n >> 1); }
 constexpr int next_pow2_c(int n) { return n <= 1 ? 1 : 2 * next_pow2_c((n + 1) >> 1); }
 
-// Butterfly reduce-scatter of NV (power of two, <= 64) per-lane partial sums across the wave.
-// On return v[0] of lane l holds the wave-wide total of value index  l >> (6 - log2(NV))
-// (every lane of that group holds the same total).  NV-1 + (6-log2 NV) shuffles instead of 6*NV.
-template <typename R, int NV>
+// Butterfly reduce-scatter of NV (power of two, <= WIDTH) per-lane partial sums across each aligned group of
+// WIDTH lanes (WIDTH = 64: the whole wave).  On return v[0] of lane l holds the group-wide total of value index
+// (l % WIDTH) >> (log2 WIDTH - log2 NV) (every lane sharing that index holds the same total).
+// NV-1 + (log2 WIDTH - log2 NV) shuffles instead of NV * log2 WIDTH.
+template <typename R, int NV, int WIDTH = WAVE>
 __device__ __forceinline__ R wave_reduce_scatter(R (&v)[NV]) {
-  static_assert(NV >= 1 && NV <= 64 && (NV & (NV - 1)) == 0, "NV must be a power of two <= 64");
+  static_assert(NV >= 1 && NV <= WIDTH && (NV & (NV - 1)) == 0, "NV must be a power of two <= WIDTH");
   const int lane = threadIdx.x & (WAVE - 1);
-  int off = 32;
+  int off = WIDTH / 2;
 #pragma unroll
   for (int h = NV / 2; h >= 1; h >>= 1) {
     const bool up = (lane & off) != 0;
@@ -186,17 +209,17 @@ __device__ __forceinline__ R wave_reduce_scatter(R (&v)[NV]) {
   }
   R r = v[0];
 #pragma unroll
-  for (int o = 32 / NV; o >= 1; o >>= 1) r += __shfl_xor(r, o, WAVE);
+  for (int o = (WIDTH / 2) / NV; o >= 1; o >>= 1) r += __shfl_xor(r, o, WAVE);
   return r;
 }
 
-template <int NV>
+template <int NV, int WIDTH = WAVE>
 __device__ __forceinline__ int scatter_index() {  // value index owned by this lane after wave_reduce_scatter<NV>
-  return (threadIdx.x & (WAVE - 1)) >> (6 - ilog2_c(NV));
+  return ((threadIdx.x & (WAVE - 1)) & (WIDTH - 1)) >> (ilog2_c(WIDTH) - ilog2_c(NV));
 }
-template <int NV>
-__device__ __forceinline__ bool scatter_leader() {  // one lane per value index
-  return ((threadIdx.x & (WAVE - 1)) & ((WAVE / NV) - 1)) == 0;
+template <int NV, int WIDTH = WAVE>
+__device__ __forceinline__ bool scatter_leader() {  // one lane per value index (per group)
+  return ((threadIdx.x & (WAVE - 1)) & ((WIDTH / NV) - 1)) == 0;
 }
 
 // dispatch helpers ---------------------------------------------------------------------------
