@@ -36,11 +36,12 @@ SIGNATURES = {
     "assx_cov_accumulate": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),
     "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "assx_ilrma_spatial_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_spatial_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_cov_partials": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_demix_power": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_power_from_cov": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "assx_ilrma_normalize_power": (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_normalize_power_bins": (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_normalize_pb": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_auxiva_weights": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

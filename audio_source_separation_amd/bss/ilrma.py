@@ -273,6 +273,7 @@ class GaussILRMA(ILRMAbase):
     def _reset(self, **kwargs):
         super()._reset(**kwargs)
         self._C = None
+        self._pbins = None
         self._power = self._engine.empty((self._X.shape[0], self.n_sources))
 
     def __repr__(self):
@@ -297,13 +298,11 @@ class GaussILRMA(ILRMAbase):
         if self.normalize:
             if self.normalize == 'power':
                 if self.power_statistic == 'covariance':
-                    if self._C is None:  # plain covariance of X: constant over the iterations
-                        B, M, F, _ = self._X.shape
-                        self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
-                    eng.power_from_cov(self._C, self._Wd, self.n_frames, out=self._power)
+                    # the IP kernel already emitted w_n^H C_f w_n per bin (update_spatial_model)
+                    eng.ilrma_normalize_power_bins(self._Wd, self._Td, self._pbins, domain=domain, eps=eps)
                 else:
                     eng.demix_power(self._X, self._Wd, out=self._power)
-                eng.ilrma_normalize_power(self._Wd, self._Td, self._power, domain=domain, eps=eps)
+                    eng.ilrma_normalize_power(self._Wd, self._Td, self._power, domain=domain, eps=eps)
             elif self.normalize == 'projection-back':
                 scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
                 eng.ilrma_normalize_pb(self._Wd, self._Td, scale, domain=domain)
@@ -319,8 +318,16 @@ class GaussILRMA(ILRMAbase):
 
     def update_spatial_model(self):
         """Weighted covariance + iterative projection (ilrma.py:483-535)."""
-        self._engine.ilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
-                                          threshold=self.threshold, status=self._status)
+        eng = self._engine
+        C = pbins = None
+        if self.normalize == 'power' and self.power_statistic == 'covariance':
+            if self._C is None:  # plain covariance of X: constant over the iterations, one pass per call
+                B, M, F, _ = self._X.shape
+                self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
+                self._pbins = eng.empty((B, M, F), dtype=torch.float64)
+            C, pbins = self._C, self._pbins
+        eng.ilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
+                                 threshold=self.threshold, status=self._status, C=C, power_bins=pbins)
         self._touch("W")
         self._estimation = None
 

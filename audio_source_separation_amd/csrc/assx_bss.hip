@@ -74,79 +74,165 @@ __global__ void __launch_bounds__(256) demix_kernel(const Cx<R>* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------
-// (a5) IP sweep: one lane per (b, f); Gauss-Seidel over sources, all linear algebra in float64
+// (a5) IP sweep.  A group of GW = next_pow2(M*M) lanes owns one bin (b, f): lane (i, j) holds element (i, j) of
+//      W and of the working matrix, rows/columns travel by in-group shuffles.  Gauss-Seidel over the sources
+//      (sequential), Gauss-Jordan with partial pivoting inside, all in float64.  The 1025 bins of one utterance
+//      become 257 waves spread over the chip instead of 17 latency-bound single-lane waves (30 us -> a few us).
+//      FROM_PART: the covariance arrives as the streaming kernel's partial records (cov_stream_kernel) and is
+//      reduced here (saves the separate finalize launch); otherwise as dense U (B,N,F,M,M).
+//      Optionally emits pw[b][n][f] = w_n^H C_f w_n (the per-bin share of the power normalisation statistic).
 // ------------------------------------------------------------------------------------------
-template <typename R, int M>
-__global__ void __launch_bounds__(64) ip_kernel(const Cx<R>* __restrict__ U, Cx<R>* __restrict__ W, double thr,
-                                               int32_t* __restrict__ status, int B, int F) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * F) return;
-  const int b = idx / F, f = idx % F;
-  Cd w[M][M];
+template <int GW>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+  for (int off = GW / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, GW);
+  return v;
+}
+template <int GW>
+__device__ __forceinline__ Cd group_shfl(Cd v, int src) {
+  return cmake<double>(__shfl(v.x, src, GW), __shfl(v.y, src, GW));
+}
+
+template <typename R, int M, bool FROM_PART>
+__global__ void __launch_bounds__(64)
+    ip_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
+                    Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
+                    int32_t* __restrict__ status, int B, int F) {
+  constexpr int N = M;
+  constexpr int MM = M * M;
+  constexpr int GW = next_pow2_c(MM);
+  constexpr int GPW = WAVE / GW;  // groups per wave
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int e = lane & (GW - 1);
+  const long long grp = (long long)blockIdx.x * GPW + lane / GW;
+  const bool in_range = grp < (long long)B * F;
+  const long long bf = in_range ? grp : (long long)B * F - 1;  // out-of-range groups shadow the last bin, store nothing
+  const bool active = e < MM;
+  const int i = active ? e / M : 0, j = active ? e % M : 0;
+  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
+
+  Cd w;
   {
-    const Cx<R>* p = W + (size_t)idx * (M * M);
-#pragma unroll
-    for (int n = 0; n < M; ++n)
-#pragma unroll
-      for (int m = 0; m < M; ++m) w[n][m] = cmake<double>((double)p[n * M + m].x, (double)p[n * M + m].y);
+    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
+    w = cmake<double>((double)v.x, (double)v.y);
   }
   int flags = 0;
-#pragma unroll
-  for (int n = 0; n < M; ++n) {
-    const Cx<R>* un = U + (((size_t)b * M + n) * F + f) * (M * M);
-    Cd A[M][M], A0[M][M];
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int j = 0; j < M; ++j) A[i][j] = cmake<double>(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < M; ++k)
-#pragma unroll
-      for (int j = 0; j < M; ++j) {
-        Cd u = cmake<double>((double)un[k * M + j].x, (double)un[k * M + j].y);
-#pragma unroll
-        for (int i = 0; i < M; ++i) cfma(A[i][j], w[i][k], u);  // WU = W @ U_n
+  // partial records covering this bin (FROM_PART): computed once, 32-bit arithmetic (NB < 2^31 is checked on the host)
+  int g_lo = 0, g_hi = -1, base = 0;
+  if (FROM_PART) {
+    const unsigned q_lo = (unsigned)bf * (unsigned)fp.len;
+    g_lo = (int)(q_lo / (unsigned)fp.L);
+    g_hi = (int)((q_lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
+  }
+
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+    // ---- this lane's element of U_n
+    Cd u;
+    if (FROM_PART) {
+      double re = 0.0, im = 0.0;
+      for (int g = g_lo; g <= g_hi; ++g) {
+        const int slot = (int)bf - (int)(((unsigned)g * (unsigned)fp.L) / (unsigned)fp.len);
+        const R* p = part + (((size_t)g * fp.S + slot) * N + n) * MM;
+        re += (double)p[base];
+        if (i != j) im += (double)p[base + 1];
       }
-#pragma unroll
-    for (int i = 0; i < M; ++i)
-#pragma unroll
-      for (int j = 0; j < M; ++j) A0[i][j] = A[i][j];
-    const double nA2 = frob2<M>(A);
-    const bool nonsingular = gj_inverse<M>(A, nullptr);
-    if (!nonsingular) {
-      flags |= ASSX_STATUS_SINGULAR;  // numpy.linalg.solve raises here; the host turns the flag into LinAlgError
-      continue;
+      if (i > j) im = -im;
+      u = cmake<double>(re * inv_T, im * inv_T);
+    } else {
+      const Cx<R> v = U[(((size_t)b * N + n) * F + f) * MM + i * M + j];
+      u = cmake<double>((double)v.x, (double)v.y);
     }
-    const double nI2 = frob2<M>(A);
-    const bool ok = cond2_below<M>(nA2, nI2, thr, A0, A);
-    if (!ok) {
-      flags |= ASSX_STATUS_COND_REJECT;
-      continue;  // keep the old row (np.where(condition, ..., w_n_Hermite))
-    }
-    // w = (WU)^{-1} e_n = column n of the inverse;  den = sqrt(w^H U_n w)
-    Cd q = cmake<double>(0.0, 0.0);
+    // ---- A = W @ U_n
+    Cd a = cmake<double>(0.0, 0.0);
 #pragma unroll
-    for (int i = 0; i < M; ++i) {
-      Cd s = cmake<double>(0.0, 0.0);
+    for (int k = 0; k < M; ++k) cfma(a, group_shfl<GW>(w, i * M + k), group_shfl<GW>(u, k * M + j));
+    const Cd a0 = a;
+    const double nA2 = group_sum<GW>(active ? cabs2(a) : 0.0);
+    // ---- in-place Gauss-Jordan inverse with partial pivoting (LAPACK's pivot rule: first max of |re|+|im|)
+    bool singular = false;
+    int piv[M];
 #pragma unroll
-      for (int j = 0; j < M; ++j) {
-        Cd u = cmake<double>((double)un[i * M + j].x, (double)un[i * M + j].y);
-        cfma(s, u, A[j][n]);
+    for (int c = 0; c < M; ++c) {
+      int p = c;
+      double best = -1.0;
+#pragma unroll
+      for (int r = c; r < M; ++r) {
+        const double m1 = cabs1(group_shfl<GW>(a, r * M + c));
+        if (m1 > best) {
+          best = m1;
+          p = r;
+        }
       }
-      cfma(q, cconj(A[i][n]), s);
+      if (!(best > 0.0)) singular = true;
+      piv[c] = p;
+      const int src_i = (i == c) ? p : ((i == p) ? c : i);
+      a = group_shfl<GW>(a, src_i * M + j);  // row interchange c <-> p
+      const Cd pv = group_shfl<GW>(a, c * M + c);
+      const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
+      const Cd acj = group_shfl<GW>(a, c * M + j);
+      const Cd rcj = cmul((j == c) ? cmake<double>(1.0, 0.0) : acj, ipv);
+      const Cd fic = group_shfl<GW>(a, i * M + c);
+      if (i == c) {
+        a = rcj;
+      } else {
+        const Cd base = (j == c) ? cmake<double>(0.0, 0.0) : a;
+        a = cmake<double>(base.x - (fic.x * rcj.x - fic.y * rcj.y), base.y - (fic.x * rcj.y + fic.y * rcj.x));
+      }
     }
+#pragma unroll
+    for (int c = M - 1; c >= 0; --c) {  // undo the row interchanges as column interchanges
+      const int p = piv[c];
+      const int src_j = (j == c) ? p : ((j == p) ? c : j);
+      a = group_shfl<GW>(a, i * M + src_j);
+    }
+    const double nI2 = group_sum<GW>(active ? cabs2(a) : 0.0);
+    // ---- cond_2(WU) < threshold ?   (Frobenius bounds; exact spectral norms only in the factor-M band)
+    bool ok;
+    {
+      const double condF = sqrt(nA2) * sqrt(nI2);
+      const bool amb = !singular && (condF == condF) && condF >= thr && condF < thr * (double)M;
+      ok = !singular && (condF == condF) && condF < thr;
+      if (__any(amb)) {  // rare: every lane gathers both matrices and evaluates redundantly
+        Cd ma[MM], mi[MM];
+#pragma unroll
+        for (int q = 0; q < MM; ++q) {
+          ma[q] = group_shfl<GW>(a0, q);
+          mi[q] = group_shfl<GW>(a, q);
+        }
+        if (amb) ok = spectral_norm_slow(ma, M) * spectral_norm_slow(mi, M) < thr;
+      }
+    }
+    if (singular) flags |= ASSX_STATUS_SINGULAR;       // numpy.linalg.solve raises here
+    else if (!ok) flags |= ASSX_STATUS_COND_REJECT;    // keep the old row (np.where(condition, ..., w_n_Hermite))
+    // ---- w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
+    const Cd wi = group_shfl<GW>(a, i * M + n);
+    const Cd wj = group_shfl<GW>(a, j * M + n);
+    Cd term = cmul(cmul(cconj(wi), u), wj);
+    if (!active) term = cmake<double>(0.0, 0.0);
+    const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
     const Cd den = csqrt_principal(q);
-#pragma unroll
-    for (int j = 0; j < M; ++j) w[n][j] = cdiv(cconj(A[j][n]), den);
+    if (ok && !singular && i == n) w = cdiv(cconj(wj), den);
   }
-  {
-    Cx<R>* p = W + (size_t)idx * (M * M);
+
+  if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
+  if (pw) {  // per-bin share of mean|y_n|^2 = mean_f w_n^H C_f w_n
+    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
+    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
 #pragma unroll
-    for (int n = 0; n < M; ++n)
-#pragma unroll
-      for (int m = 0; m < M; ++m) p[n * M + m] = cmake<R>((R)w[n][m].x, (R)w[n][m].y);
+    for (int n = 0; n < N; ++n) {
+      const Cd wni = group_shfl<GW>(w, n * M + i);
+      const Cd wnj = group_shfl<GW>(w, n * M + j);
+      const Cd t1 = cmul(wni, c);
+      double term = t1.x * wnj.x + t1.y * wnj.y;  // Re(W[n,i] C[i,j] conj(W[n,j]))
+      if (!active) term = 0.0;
+      const double sum = group_sum<GW>(term);
+      if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
+    }
   }
-  if (flags && status) atomicOr(&status[b], flags);
+  if (flags && status && in_range && e == 0) atomicOr(&status[b], flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,6 +356,39 @@ __global__ void __launch_bounds__(256) normalize_power_kernel(Cx<R>* __restrict_
     const int b = j / ((size_t)F * K * M);
     R a = floor_eps<R>(sqrt(power[b * M + n]), eps);
     Tb[j] = Tb[j] / powspec<R>(a, pd);
+  }
+}
+
+// 'power' normalisation with the statistic still split per bin: every workgroup first reduces
+// power_bins[b][n][0..F) (double, tiny, L2-resident) for ITS utterance in a fixed order, then rescales its slice
+// of W / Tb.  Saves the separate reduction launch.  One utterance per blockIdx.y.
+template <typename R>
+__global__ void __launch_bounds__(256) normalize_power_bins_kernel(Cx<R>* __restrict__ W, R* __restrict__ Tb,
+                                                                  const double* __restrict__ pbins, int M, int F,
+                                                                  int K, R eps, PowSpec pd) {
+  __shared__ R anorm[8];
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  for (int n = wv; n < M; n += 4) {  // one wave per source: fixed-order strided sum + butterfly
+    const double* p = pbins + ((size_t)b * M + n) * F;
+    double s = 0.0;
+    for (int f = lane; f < F; f += WAVE) s += p[f];
+    s = wave_allreduce_sum<double>(s);
+    if (lane == 0) anorm[n] = floor_eps<R>(sqrt((R)(s / (double)F)), eps);
+  }
+  __syncthreads();
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nW = (size_t)F * M * M, nT = (size_t)M * F * K;
+  if (idx < nW) {
+    const int n = (idx / M) % M;
+    Cx<R>* w = W + (size_t)b * nW + idx;
+    const R a = anorm[n];
+    *w = cmake<R>(w->x / a, w->y / a);
+  } else if (idx < nW + nT) {
+    const size_t j = idx - nW;
+    const int n = j / ((size_t)F * K);
+    R* t = Tb + (size_t)b * nT + j;
+    *t = *t / powspec<R>(anorm[n], pd);
   }
 }
 
@@ -670,7 +789,9 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
 #define CHECK_COMMON(ctx, B, M, F, T)                                                        \
   ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");                              \
   ASSX_REQUIRE(ctx, (B) >= 1 && (M) >= 1 && (F) >= 1 && (T) >= 1, ASSX_E_ARG,                 \
-               "invalid sizes B=%d M=%d F=%d T=%d", (B), (M), (F), (T))
+               "invalid sizes B=%d M=%d F=%d T=%d", (B), (M), (F), (T));                       \
+  ASSX_REQUIRE(ctx, (long long)(M) * (F) * (T) < (1LL << 31) && (long long)(B) * (F) * (((T) + 31) / 32 + 1) < (1LL << 31), \
+               ASSX_E_UNSUPPORTED, "utterance too large for 32-bit in-kernel offsets (M*F*T and B*F*T/32 must be < 2^31)")
 
 inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
@@ -720,10 +841,17 @@ int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb,
 }
 
 template <typename R, int M>
-int run_ip(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int B, int F, hipStream_t st) {
-  hipLaunchKernelGGL((ip_kernel<R, M>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)U,
-                     (Cx<R>*)W, thr, status, B, F);
-  ASSX_LAUNCH_CHECK(ctx, "ip_kernel");
+int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
+           double thr, int32_t* status, int B, int F, hipStream_t st) {
+  constexpr int GPW = WAVE / next_pow2_c(M * M);
+  const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
+  if (part)
+    hipLaunchKernelGGL((ip_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
+                       1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F);
+  else
+    hipLaunchKernelGGL((ip_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F);
+  ASSX_LAUNCH_CHECK(ctx, "ip_group_kernel");
   return 0;
 }
 
@@ -779,7 +907,7 @@ int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int3
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+    return run_ip<R, MM>(ctx, U, nullptr, FlatPart{}, 1, W, nullptr, nullptr, threshold, status, B, F, st);
   });
 }
 
@@ -841,21 +969,27 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
 }
 
 int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double domain,
-                              double eps, double threshold, void* U_out, int32_t* status, void* ws, int B, int M, int F,
-                              int T, int K, int dtype, void* stream) {
+                              double eps, double threshold, void* U_out, const void* C, double* power_bins,
+                              int32_t* status, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_spatial_update: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
+  ASSX_REQUIRE(ctx, (C == nullptr) == (power_bins == nullptr), ASSX_E_ARG,
+               "assx_ilrma_spatial_update: C and power_bins must be given together");
   hipStream_t st = (hipStream_t)stream;
-  const WsLayout L = ws_layout(B, M, F, T, K, dtype);
-  void* U = U_out ? U_out : (void*)((char*)ws + L.u);
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    int rc = run_cov<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, U, ws, B, F, T, st);
+    FlatPart fp;
+    int rc = run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, &fp);
     if (rc) return rc;
-    return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+    if (U_out) {  // dense covariance on request only; the IP sweep reduces the partial records itself
+      hipLaunchKernelGGL((cov_stream_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)),
+                         dim3(256), 0, st, (const R*)ws, (Cx<R>*)U_out, B, MM, F, fp, (R)(1.0 / (double)T));
+      ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
+    }
+    return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, threshold, status, B, F, st);
   });
 }
 
@@ -929,6 +1063,27 @@ int assx_ilrma_normalize_power(assx_ctx* ctx, void* W, void* Tb, const void* pow
   else
     return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
   ASSX_LAUNCH_CHECK(ctx, "normalize_power_kernel");
+  return 0;
+}
+
+int assx_ilrma_normalize_power_bins(assx_ctx* ctx, void* W, void* Tb, const double* power_bins, double domain,
+                                    double eps, int B, int M, int F, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, W && Tb && power_bins, ASSX_E_NULL, "assx_ilrma_normalize_power_bins: NULL array");
+  ASSX_REQUIRE(ctx, M <= 8, ASSX_E_UNSUPPORTED, "M > 8 unsupported");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t per_b = (size_t)F * M * M + (size_t)M * F * K;
+  const PowSpec pd = make_pow(domain);
+  const dim3 grid(blocks_for(per_b, 256), B);
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((normalize_power_bins_kernel<double>), grid, dim3(256), 0, st, (Cx<double>*)W, (double*)Tb,
+                       power_bins, M, F, K, eps, pd);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((normalize_power_bins_kernel<float>), grid, dim3(256), 0, st, (Cx<float>*)W, (float*)Tb,
+                       power_bins, M, F, K, (float)eps, pd);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "normalize_power_bins_kernel");
   return 0;
 }
 
@@ -1024,14 +1179,18 @@ int assx_auxiva_spatial_update(assx_ctx* ctx, const void* X, void* W, const void
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_spatial_update: NULL array");
   hipStream_t st = (hipStream_t)stream;
-  const WsLayout L = ws_layout(B, M, F, T, 1, dtype);
-  void* U = U_out ? U_out : (void*)((char*)ws + L.u);
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    int rc = run_cov<R, MM>(ctx, WK_NT, X, r, nullptr, nullptr, 1, 2.0, eps, U, ws, B, F, T, st);
+    FlatPart fp;
+    int rc = run_cov_partial<R, MM>(ctx, WK_NT, X, r, nullptr, nullptr, 1, 2.0, eps, ws, B, F, T, st, &fp);
     if (rc) return rc;
-    return run_ip<R, MM>(ctx, U, W, threshold, status, B, F, st);
+    if (U_out) {
+      hipLaunchKernelGGL((cov_stream_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)),
+                         dim3(256), 0, st, (const R*)ws, (Cx<R>*)U_out, B, MM, F, fp, (R)(1.0 / (double)T));
+      ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
+    }
+    return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, threshold, status, B, F, st);
   });
 }
 

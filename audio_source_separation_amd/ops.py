@@ -84,13 +84,16 @@ class Engine:
                                                ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_source_update")
 
-    def ilrma_spatial_update(self, X, W, Tb, V, domain=2, eps=1e-12, threshold=1e12, status=None, U_out=None):
+    def ilrma_spatial_update(self, X, W, Tb, V, domain=2, eps=1e-12, threshold=1e12, status=None, U_out=None,
+                             C=None, power_bins=None):
+        """C (B,F,M,M) + power_bins (B,N,F) float64: also emit the per-bin power statistic of the updated filters."""
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         self._check(L.assx_ilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
-                                                float(threshold), ptr(U_out), ptr(status), ptr(ws), B, M, F, T, K,
-                                                self.prec.code, self._st()), "assx_ilrma_spatial_update")
+                                                float(threshold), ptr(U_out), ptr(C), ptr(power_bins), ptr(status),
+                                                ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
+                    "assx_ilrma_spatial_update")
 
     def ilrma_cov_partials(self, X, Tb, V, domain=2, eps=1e-12):
         """ONE launch of the covariance-accumulate kernel (stage 1 of ilrma_spatial_update); for kernel timing."""
@@ -121,6 +124,13 @@ class Engine:
         K = int(Tb.shape[-1])
         self._check(L.assx_ilrma_normalize_power(self.ctx, ptr(W), ptr(Tb), ptr(power), float(domain), float(eps), B, M,
                                                  F, K, self.prec.code, self._st()), "assx_ilrma_normalize_power")
+
+    def ilrma_normalize_power_bins(self, W, Tb, power_bins, domain=2, eps=1e-12):
+        B, F, N, M = (int(s) for s in W.shape)
+        K = int(Tb.shape[-1])
+        self._check(L.assx_ilrma_normalize_power_bins(self.ctx, ptr(W), ptr(Tb), ptr(power_bins), float(domain),
+                                                      float(eps), B, M, F, K, self.prec.code, self._st()),
+                    "assx_ilrma_normalize_power_bins")
 
     def ilrma_normalize_pb(self, W, Tb, scale, domain=2):
         B, F, N, M = (int(s) for s in W.shape)

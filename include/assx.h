@@ -101,9 +101,13 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
 /* ---- (a4+a5) ILRMA spatial model ------------------------------------------------------- */
 /* GaussILRMA.update_spatial_model_ip (src/bss/ilrma.py:483-535): r = max((Tb V)^(2/domain), eps)
  * rebuilt in-kernel from Tb, V (never materialised), covariance, IP sweep.  W in place.
- * U_out: optional (B,N,F,M,M) complex receiving the covariance; NULL = scratch only. */
+ * U_out: optional (B,N,F,M,M) complex receiving the covariance; NULL = not materialised.
+ * C, power_bins: optional pair.  C (B,F,M,M) = plain covariance of X; power_bins (B,N,F) float64 receives
+ * w_n^H C_f w_n of the UPDATED filters, the per-bin share of the power-normalisation statistic
+ * (src/bss/ilrma.py:298-306) -- emitted by the IP kernel so normalisation needs no further pass or launch. */
 int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V,
                               double domain, double eps, double threshold, void* U_out,
+                              const void* C, double* power_bins,
                               int32_t* status, void* ws,
                               int B, int M, int F, int T, int K, int dtype, void* stream);
 
@@ -123,6 +127,10 @@ int assx_power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power
  * W[:,n,:] /= a_n;  Tb[n] /= a_n^domain. */
 int assx_ilrma_normalize_power(assx_ctx* ctx, void* W, void* Tb, const void* power, double domain, double eps,
                                int B, int M, int F, int K, int dtype, void* stream);
+/* Same normalisation with the statistic still per bin: power_bins (B,N,F) float64 from
+ * assx_ilrma_spatial_update; mean power = (1/F) sum_f power_bins[b,n,f].  Reduction fused into the rescale. */
+int assx_ilrma_normalize_power_bins(assx_ctx* ctx, void* W, void* Tb, const double* power_bins, double domain,
+                                    double eps, int B, int M, int F, int K, int dtype, void* stream);
 /* 'projection-back' normalisation (src/bss/ilrma.py:323-330): W[f,n,:] *= s[n,f]; Tb[n,f,:] *= |s[n,f]|^domain. */
 int assx_ilrma_normalize_pb(assx_ctx* ctx, void* W, void* Tb, const void* scale /* (B,N,F) complex */, double domain,
                             int B, int M, int F, int K, int dtype, void* stream);
