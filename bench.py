@@ -66,13 +66,8 @@ def main():
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from audio_source_separation_amd import distributed as D
+    rank, world, local_rank = D.init_from_env(backend="nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     n_gpus = world
     dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
 
@@ -92,9 +87,7 @@ def main():
         return m
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        D.barrier(dev)
 
     def timed_steps(model, steps, warmup, with_loss=False):
         for _ in range(warmup):
@@ -108,12 +101,7 @@ def main():
             if with_loss:
                 model.loss.append(model.compute_negative_loglikelihood())
         barrier()
-        dt = time.perf_counter() - t0
-        if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        return dt
+        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     model = make_model(False)
     elapsed = timed_steps(model, args.steps, args.warmup)
@@ -146,9 +134,17 @@ def main():
         e1.synchronize()
         ms = e0.elapsed_time(e1) / args.kernel_reps
         achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "cov_partial_kernel", "achieved": round(achieved, 1),
+        # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; same kernel, same shape)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "cov_traffic.json")))[args.dtype]
+            if (M, F, T, K) == (4, 1025, 4096, 4):
+                traffic = int(round(tj["traffic_bytes"] * B))
+        except Exception:
+            pass
+        roofline = {"bound": "hbm", "kernel": "cov_stream_kernel", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": None, "kernel_ms": round(ms, 5), "algorithmic_bytes": bytes_per_launch}
+                    "traffic": traffic, "kernel_ms": round(ms, 5), "algorithmic_bytes": bytes_per_launch}
 
     # ---------------- CPU baseline: the NumPy oracle on the same workload (rank 0, N=1 only)
     cpu_baseline = None
