@@ -430,57 +430,6 @@ __device__ __forceinline__ double neg2T_logabsdet(const Cx<R>* __restrict__ W, s
   return -2.0 * (double)T * log(hypot(det.x, det.y));
 }
 
-template <typename R>
-struct LossArgs {
-  const Cx<R>* X;
-  const Cx<R>* W;
-  const R* Tb;
-  const R* V;
-  Dims d;
-  int S, chunk;  // t-splits and their length
-  R eps;
-};
-
-template <typename R, int M, bool K4>
-__global__ void __launch_bounds__(64) ilrma_loss_partial_kernel(LossArgs<R> a, double* __restrict__ lpart, PowSpec p2d) {
-  constexpr int N = M;
-  const int f = blockIdx.x / a.S, ts = blockIdx.x % a.S, b = blockIdx.y;
-  const int lane = threadIdx.x;
-  const int F = a.d.F, T = a.d.T, K = a.d.K;
-  const size_t FT = (size_t)F * T;
-  const Cx<R>* xb = a.X + (size_t)b * M * FT + (size_t)f * T;
-  Cx<R> w[M][M];
-  load_filter<R, M>(a.W, (size_t)b * F + f, w);
-  const R* tbase = a.Tb + ((size_t)b * N * F + f) * K;
-  double acc = 0.0;
-  const int t0 = ts * a.chunk, t1 = min(T, t0 + a.chunk);
-  for (int t = t0 + lane; t < t1; t += WAVE) {
-    Cx<R> x[M], y[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
-    demix<R, M>(w, x, y);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const R* vb = a.V + ((size_t)b * N + n) * K * T + t;
-      const R* tbn = tbase + (size_t)n * F * K;
-      R tv = 0;
-      if (K4) {
-#pragma unroll
-        for (int kk = 0; kk < KU; ++kk) tv = fma((kk < K) ? tbn[kk] : (R)0, vb[(size_t)min(kk, K - 1) * T], tv);
-      } else {
-        for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
-      }
-      const R r = floor_eps<R>(powspec<R>(tv, p2d), a.eps);
-      acc += (double)(cabs2(y[n]) / r) + log((double)r);
-    }
-  }
-  acc = wave_allreduce_sum<double>(acc);
-  if (lane == 0) {
-    if (ts == 0) acc += neg2T_logabsdet<M, R>(a.W, (size_t)b * F + f, T);
-    lpart[(size_t)b * ((size_t)a.S * F) + (size_t)ts * F + f] = acc;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // AuxIVA: s[b,n,t] = sum_f |y_n(f,t)|^2 partials over f-splits: part[b][fs][n][t]
 // ------------------------------------------------------------------------------------------
@@ -733,6 +682,10 @@ inline FlatPart flat_act(int B, int F, int T) {    // act_stream_kernel: ACT_NH 
   return make_flat((long long)B * tblocks(T) * F, F, g_target(4));
 }
 
+inline FlatPart flat_loss(int F, int T) {  // loss_stream_kernel: per-utterance partition (grid.y = B)
+  return make_flat((long long)F * tblocks(T), tblocks(T), g_target(8));
+}
+
 inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   const int Kc = K < 1 ? 1 : K;
@@ -758,7 +711,8 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   L.u = off;
   off += align_up((size_t)B * M * F * M * M * 2 * r, 256);
   L.lpart = off;
-  size_t nl = (size_t)B * ((size_t)TS * F + (size_t)M * F + (size_t)(M * T + 255) / 256 + F + 16);
+  size_t nl = (size_t)B * ((size_t)TS * F + (size_t)M * F + (size_t)(M * T + 255) / 256 + F + 16 +
+                           (size_t)flat_loss(F, T).G);
   off += align_up(nl * 8, 256);
   L.small = off;
   off += align_up((size_t)B * (M + 8) * 8, 256);
@@ -1117,24 +1071,29 @@ int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    int TS, tchunk;
-    t_split(B, F, T, &TS, &tchunk);
-    LossArgs<R> a;
-    a.X = (const Cx<R>*)X;
-    a.W = (const Cx<R>*)W;
-    a.Tb = (const R*)Tb;
-    a.V = (const R*)V;
+    NmfArgs<R> a;
     a.d = Dims{B, F, T, K};
-    a.S = TS;
-    a.chunk = tchunk;
+    a.fp = flat_loss(F, T);
     a.eps = (R)eps;
+    a.p1 = make_pow(1.0);
     const PowSpec p2d = make_pow(2.0 / domain);
-    dim3 grid((unsigned)F * TS, B);
-    if (K <= KU) hipLaunchKernelGGL((ilrma_loss_partial_kernel<R, MM, true>), grid, dim3(64), 0, st, a, lpart, p2d);
-    else hipLaunchKernelGGL((ilrma_loss_partial_kernel<R, MM, false>), grid, dim3(64), 0, st, a, lpart, p2d);
-    ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_partial_kernel");
+    const bool d2 = p2d.mode == POW_ID, k4 = K <= KU;
+    const int lstride = a.fp.G + F;  // [G data-term partials | F log-det terms] per utterance
+    const dim3 grid(a.fp.G, B), blk(64);
+#define LOSS_LAUNCH(K4V, D2V, DXV, DWV, MW)                                                                     \
+  hipLaunchKernelGGL((loss_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), grid, blk, 0, st, (const Cx<R>*)X,      \
+                     (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lstride, a, p2d)
+    if (k4 && d2) LOSS_LAUNCH(true, true, 4, 1, 2);
+    else if (k4) LOSS_LAUNCH(true, false, 2, 1, 1);
+    else if (d2) LOSS_LAUNCH(false, true, 4, 1, 2);
+    else LOSS_LAUNCH(false, false, 2, 1, 1);
+#undef LOSS_LAUNCH
+    ASSX_LAUNCH_CHECK(ctx, "loss_stream_kernel");
+    hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W,
+                       lpart, B, F, T, lstride, a.fp.G);
+    ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
     hipLaunchKernelGGL((sum_reduce_kernel<double, double>), dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lpart,
-                       loss, (size_t)TS * F, 1.0);
+                       loss, (size_t)lstride, 1.0);
     ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
     return 0;
   });

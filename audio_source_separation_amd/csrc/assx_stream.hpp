@@ -519,6 +519,146 @@ __global__ void __launch_bounds__(256) basis_stream_finalize_kernel(const R* __r
 }
 
 // ------------------------------------------------------------------------------------------
+// (a7) ILRMA negative log-likelihood, data term: sum_{n,t} P/R + log R per workgroup range (ilrma.py:672-675).
+//      Same streaming structure as the basis kernel, one float64 accumulator per lane.  The flat partition is
+//      per utterance (blockIdx.y) so a partial never mixes utterances: lpart[b][g].
+// ------------------------------------------------------------------------------------------
+template <typename R, int M, bool K4, bool D2, int DXT, int DWT, int MINW = 1>
+__global__ void __launch_bounds__(64, MINW)
+    loss_stream_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
+                       const R* __restrict__ V, double* __restrict__ lpart, int lstride, NmfArgs<R> a, PowSpec p2d) {
+  constexpr int N = M;
+  static_assert(DXT % DWT == 0, "ring depths");
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
+  const size_t FT = (size_t)F * T;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const long long q0 = (long long)g * a.fp.L;
+  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  double acc = 0.0;
+  // sum log R is carried as log(prod R): running mantissa product + integer exponent (frexp once per block), ONE
+  // log per lane at the end instead of N per frame.
+  double lm = 1.0;
+  int le = 0;
+  if (q0 < q1) {
+    const int nblk = (int)(q1 - q0);
+    Cursor cc;
+    cc.f = (int)(q0 / TBk);
+    cc.tb = (int)(q0 - (long long)cc.f * TBk);
+    cc.b = b;
+    Cursor px = cc, pw = cc;
+    const Cx<R>* xb = X + (size_t)b * M * FT;
+    const R* vb = V + (size_t)b * N * K * T;
+    auto issue_x = [&](const Cursor& cu, Vec2<R>(&x)[M]) {
+      const int t = cu.tb * WAVE + lane;
+      const unsigned tc = (unsigned)(t < T ? t : T - 1);
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = ldv<R>(xb + ((unsigned)(m * F + cu.f) * (unsigned)T + tc));
+    };
+    auto issue_v = [&](const Cursor& cu, R(&v)[N][KU]) {
+      const int t = cu.tb * WAVE + lane;
+      const unsigned tc = (unsigned)(t < T ? t : T - 1);
+      if (K4) {
+#pragma unroll
+        for (int n = 0; n < N; ++n)
+#pragma unroll
+          for (int kk = 0; kk < KU; ++kk) v[n][kk] = vb[(unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T + tc];
+      }
+    };
+    Cx<R> w[N][M];
+    R tbr[N][KU];
+    auto load_rows = [&](const Cursor& cu) {  // wave-uniform: scalar loads, once per bin
+      const Cx<R>* wp = W + ((size_t)b * F + cu.f) * (N * M);
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < M; ++m) w[n][m] = wp[n * M + m];
+      if (K4) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          const R* tbn = Tb + (((size_t)b * N + n) * F + cu.f) * K;
+#pragma unroll
+          for (int kk = 0; kk < KU; ++kk) tbr[n][kk] = (kk < K) ? tbn[kk] : (R)0;
+        }
+      }
+    };
+    Vec2<R> xq[DXT][M];
+    R vq[DWT][N][KU];
+#pragma unroll
+    for (int j = 0; j < DXT; ++j) {
+      if (j < nblk) {
+        issue_x(px, xq[j]);
+        advance(px, TBk, F);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DWT; ++j) {
+      if (j < nblk) {
+        issue_v(pw, vq[j]);
+        advance(pw, TBk, F);
+      }
+    }
+    load_rows(cc);
+    for (int it0 = 0; it0 < nblk; it0 += DXT) {
+#pragma unroll
+      for (int j = 0; j < DXT; ++j) {
+        const int it = it0 + j;
+        if (it < nblk) {
+          Cx<R> x[M];
+          R v[N][KU];
+#pragma unroll
+          for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
+#pragma unroll
+          for (int n = 0; n < N; ++n)
+#pragma unroll
+            for (int kk = 0; kk < KU; ++kk) v[n][kk] = vq[j % DWT][n][kk];
+          if (it + DXT < nblk) {
+            issue_x(px, xq[j]);
+            advance(px, TBk, F);
+          }
+          if (it + DWT < nblk) {
+            issue_v(pw, vq[j % DWT]);
+            advance(pw, TBk, F);
+          }
+          const Cursor cur = cc;
+          advance(cc, TBk, F);
+          const int t = cur.tb * WAVE + lane;
+          double term = 0.0, rprod = 1.0;
+#pragma unroll
+          for (int n = 0; n < N; ++n) {
+            Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+            for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+            R tv = 0;
+            if (K4) {
+#pragma unroll
+              for (int kk = 0; kk < KU; ++kk) tv = fma(tbr[n][kk], v[n][kk], tv);
+            } else {
+              const unsigned tc = (unsigned)(t < T ? t : T - 1);
+              const R* tbn = Tb + (((size_t)b * N + n) * F + cur.f) * K;
+              for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(unsigned)(n * K + k) * (unsigned)T + tc], tv);
+            }
+            const R r = floor_eps<R>(D2 ? tv : powspec<R>(tv, p2d), a.eps);
+            term += (double)(cabs2(y) * fast_rcp(r));
+            rprod *= (double)r;
+          }
+          if (t < T) {
+            acc += term;
+            int e;
+            lm = frexp(lm * rprod, &e);
+            le += e;
+          }
+          if (cc.tb == 0 && it + 1 < nblk) load_rows(cc);
+        }
+      }
+    }
+  }
+  acc += (double)le * 0.6931471805599453 + log(lm);
+  acc = wave_allreduce_sum<double>(acc);
+  if (lane == 0) lpart[(size_t)b * lstride + g] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // (a2) activation half (reduce over f).  Lanes own 64 frames; a workgroup = ACT_NH waves walking interleaved
 //      bins of the same frame block, each wave handling all N sources; the streams are combined through LDS.
 //      items = (b, tb, f), len = F.   part[g][slot][n][k][{num,den}][64]
