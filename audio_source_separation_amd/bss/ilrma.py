@@ -13,6 +13,7 @@ import numpy as np
 
 from .._device import to_device, to_numpy, torch
 from .._state import DeviceArray, DeviceState
+from .._loss import LazyLossList
 from .. import _lib
 from ..ops import Engine
 
@@ -50,7 +51,7 @@ class ILRMAbase(DeviceState):
         self.input = None
         self.recordable_loss = recordable_loss
         if self.recordable_loss:
-            self.loss = []
+            self.loss = LazyLossList()  # a list; entries are materialised from HBM on first read
         else:
             self.loss = None
 
@@ -241,8 +242,7 @@ class GaussILRMA(ILRMAbase):
         self._reset(**kwargs)
 
         if self.recordable_loss:
-            loss = self.compute_negative_loglikelihood()
-            self.loss.append(loss)
+            self._record_loss()
 
         self._run_callbacks()
 
@@ -250,8 +250,7 @@ class GaussILRMA(ILRMAbase):
             self.update_once()
 
             if self.recordable_loss:
-                loss = self.compute_negative_loglikelihood()
-                self.loss.append(loss)
+                self._record_loss()
 
             self._run_callbacks()
 
@@ -330,6 +329,14 @@ class GaussILRMA(ILRMAbase):
                                  threshold=self.threshold, status=self._status, C=C, power_bins=pbins)
         self._touch("W")
         self._estimation = None
+
+    def _record_loss(self):
+        """Append the current loss without a host sync (the value stays in HBM until `loss` is read)."""
+        loss = self._engine.ilrma_loss(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps)
+        if isinstance(self.loss, LazyLossList):
+            self.loss.append_device(loss, self._batched)
+        else:  # a user replaced `loss` by a plain list
+            self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
 
     def compute_negative_loglikelihood(self):
         """sum(P/R + log R) - 2 T sum_f log|det W_f| (ilrma.py:648-677).  Syncs to return a Python float."""

@@ -13,6 +13,7 @@ import numpy as np
 
 from .._device import to_device, to_numpy, torch
 from .._state import DeviceArray, DeviceState
+from .._loss import LazyLossList
 from .. import _lib
 from ..ops import Engine
 
@@ -39,7 +40,7 @@ class IVAbase(DeviceState):
         self.input = None
         self.recordable_loss = recordable_loss
         if self.recordable_loss:
-            self.loss = []
+            self.loss = LazyLossList()  # a list; entries are materialised from HBM on first read
         else:
             self.loss = None
 
@@ -187,8 +188,7 @@ class AuxIVAbase(IVAbase):
         self._reset(**kwargs)
 
         if self.recordable_loss:
-            loss = self.compute_negative_loglikelihood()
-            self.loss.append(loss)
+            self._record_loss()
 
         if self.callbacks is not None:
             for callback in self.callbacks:
@@ -198,8 +198,7 @@ class AuxIVAbase(IVAbase):
             self.update_once()
 
             if self.recordable_loss:
-                loss = self.compute_negative_loglikelihood()
-                self.loss.append(loss)
+                self._record_loss()
 
             if self.callbacks is not None:
                 for callback in self.callbacks:
@@ -244,6 +243,15 @@ class AuxIVAbase(IVAbase):
         self._estimation = None
         self._r = None
         self._loss_dev = None
+
+    def _record_loss(self):
+        """Append the current loss without a host sync (the value stays in HBM until `loss` is read)."""
+        if self._r is None or self._loss_dev is None or self._r_src is not self._Wd:
+            self._refresh_weights(with_loss=True)
+        if isinstance(self.loss, LazyLossList):
+            self.loss.append_device(self._loss_dev, self._batched)
+        else:
+            self.loss.append(to_numpy(self._loss_dev, np.float64) if self._batched else np.float64(self._loss_dev.item()))
 
     def compute_negative_loglikelihood(self):
         """iva.py:604-619 / 783-802.  Rides on the r_n(t) pass; syncs to return a Python float."""

@@ -74,6 +74,17 @@ template <typename R>
 __device__ __forceinline__ Vec2<R> ldv(const Cx<R>* p) { return *reinterpret_cast<const Vec2<R>*>(p); }
 template <typename R>
 __device__ __forceinline__ Cx<R> tocx(Vec2<R> v) { return cmake<R>(v.x, v.y); }
+// wave-uniform base pointer + 32-bit per-lane BYTE offset: written so that the backend selects the
+// `global_load ... v_off, s[base:base+1]` (SGPR base + zero-extended VGPR offset) addressing form instead of a
+// per-lane 64-bit address computation (v_lshl_add_u64 per load).
+template <typename R>
+__device__ __forceinline__ Vec2<R> ldv_so(const Cx<R>* base, unsigned byte_off) {
+  return *reinterpret_cast<const Vec2<R>*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+template <typename R>
+__device__ __forceinline__ R ld_so(const R* base, unsigned byte_off) {
+  return *reinterpret_cast<const R*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 template <typename R>
 __device__ __forceinline__ Cx<R> cadd(Cx<R> a, Cx<R> b) { return cmake<R>(a.x + b.x, a.y + b.y); }
 template <typename R>

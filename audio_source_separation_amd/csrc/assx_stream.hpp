@@ -140,6 +140,7 @@ __global__ void __launch_bounds__(64, MINW)
   cc.b = bf_first / F;
   cc.f = bf_first - cc.b * F;
   Cursor px = cc, pw = cc;               // prefetch cursors (X ring, weight ring)
+  const bool ragged = (T % FB) != 0;     // only then can a lane fall beyond the last frame
 
   R acc[NV];
 #pragma unroll
@@ -148,9 +149,14 @@ __global__ void __launch_bounds__(64, MINW)
   auto issue_x = [&](const Cursor& c, Vec2<R>(&x)[M]) {
     const int t = c.tb * FB + fl;
     const unsigned tc = (unsigned)(t < T ? t : T - 1);
-    const Cx<R>* xb = X + (size_t)c.b * M * FT;  // 64-bit part changes only with the utterance
+    // row base = wave-uniform 64-bit pointer (SGPR pair), lane part = 32-bit frame offset: the loads use the
+    // SGPR-base + VGPR-offset addressing form and need no per-lane 64-bit address arithmetic
+    const Cx<R>* xb = X + (size_t)c.b * M * FT;
 #pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = ldv<R>(xb + ((unsigned)(m * F + c.f) * (unsigned)T + tc));
+    for (int m = 0; m < M; ++m) {
+      const Cx<R>* row = xb + (size_t)((unsigned)(m * F + c.f) * (unsigned)T);
+      x[m] = ldv_so<R>(row, tc * (unsigned)sizeof(Cx<R>));
+    }
   };
   auto issue_w = [&](const Cursor& c, R(&wv)[SPL][NWV]) {
     const int t = c.tb * FB + fl;
@@ -159,15 +165,18 @@ __global__ void __launch_bounds__(64, MINW)
     for (int j = 0; j < SPL; ++j) {
       const int n = s0 + j;
       if (WK == WK_NT) {
-        wv[j][0] = rw[((size_t)c.b * N + n) * T + tc];
+        const R* row = rw + ((size_t)c.b * N + n) * T;
+        wv[j][0] = ld_so<R>(row, tc * (unsigned)sizeof(R));
       } else if (WK == WK_NFT) {
-        const R* rb = rw + (size_t)c.b * N * FT;
-        wv[j][0] = rb[(unsigned)(n * F + c.f) * (unsigned)T + tc];
+        const R* row = rw + (size_t)c.b * N * FT + (size_t)((unsigned)(n * F + c.f) * (unsigned)T);
+        wv[j][0] = ld_so<R>(row, tc * (unsigned)sizeof(R));
       } else if (WK == WK_TV && K4) {
         const R* vb = V + (size_t)c.b * N * K * T;
 #pragma unroll
-        for (int kk = 0; kk < KU; ++kk)
-          wv[j][kk] = vb[(unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T + tc];
+        for (int kk = 0; kk < KU; ++kk) {
+          const R* row = vb + (size_t)((unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T);
+          wv[j][kk] = ld_so<R>(row, tc * (unsigned)sizeof(R));
+        }
       }
     }
   };
@@ -257,7 +266,7 @@ __global__ void __launch_bounds__(64, MINW)
             }
             wgt[q] = fast_rcp(floor_eps<R>(r, a.eps));
           }
-          if (t >= T) wgt[q] = 0;
+          if (ragged && t >= T) wgt[q] = 0;
         }
         // each Hermitian product is formed once and fanned into every source's accumulator right away, so the
         // M*M products are never all live (saves ~28 VGPRs in f64 -- the margin that keeps 2 waves per SIMD)
@@ -360,6 +369,7 @@ __global__ void __launch_bounds__(64, MINW)
   c0.b = bf_first / F;
   c0.f = bf_first - c0.b * F;
   const int nchunks = K4 ? 1 : (K + KU - 1) / KU;
+  const bool ragged = (T % WAVE) != 0;
 
   for (int c = 0; c < nchunks; ++c) {
     const int k0 = c * KU;
@@ -373,7 +383,10 @@ __global__ void __launch_bounds__(64, MINW)
       const unsigned tc = (unsigned)(t < T ? t : T - 1);
       const Cx<R>* xb = X + (size_t)cu.b * M * FT;
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = ldv<R>(xb + ((unsigned)(m * F + cu.f) * (unsigned)T + tc));
+      for (int m = 0; m < M; ++m) {
+        const Cx<R>* row = xb + (size_t)((unsigned)(m * F + cu.f) * (unsigned)T);  // uniform base + 32-bit lane offset
+        x[m] = ldv_so<R>(row, tc * (unsigned)sizeof(Cx<R>));
+      }
     };
     auto issue_v = [&](const Cursor& cu, R(&v)[N][KU]) {
       const int t = cu.tb * WAVE + lane;
@@ -384,7 +397,8 @@ __global__ void __launch_bounds__(64, MINW)
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk) {
           const int k = k0 + kk;
-          v[n][kk] = vb[(unsigned)(n * K + (k < K ? k : K - 1)) * (unsigned)T + tc];
+          const R* row = vb + (size_t)((unsigned)(n * K + (k < K ? k : K - 1)) * (unsigned)T);
+          v[n][kk] = ld_so<R>(row, tc * (unsigned)sizeof(R));
         }
     };
     Cx<R> w[N][M];
@@ -465,7 +479,7 @@ __global__ void __launch_bounds__(64, MINW)
             tv = floor_eps<R>(tv, a.eps);
             R inv = fast_rcp(tv);                                 // TV_inverse
             R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);   // division = P / TV**((d+2)/d)
-            if (t >= T) {
+            if (ragged && t >= T) {
               inv = 0;
               D = 0;
             }
@@ -553,7 +567,10 @@ __global__ void __launch_bounds__(64, MINW)
       const int t = cu.tb * WAVE + lane;
       const unsigned tc = (unsigned)(t < T ? t : T - 1);
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = ldv<R>(xb + ((unsigned)(m * F + cu.f) * (unsigned)T + tc));
+      for (int m = 0; m < M; ++m) {
+        const Cx<R>* row = xb + (size_t)((unsigned)(m * F + cu.f) * (unsigned)T);
+        x[m] = ldv_so<R>(row, tc * (unsigned)sizeof(Cx<R>));
+      }
     };
     auto issue_v = [&](const Cursor& cu, R(&v)[N][KU]) {
       const int t = cu.tb * WAVE + lane;
@@ -562,7 +579,10 @@ __global__ void __launch_bounds__(64, MINW)
 #pragma unroll
         for (int n = 0; n < N; ++n)
 #pragma unroll
-          for (int kk = 0; kk < KU; ++kk) v[n][kk] = vb[(unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T + tc];
+          for (int kk = 0; kk < KU; ++kk) {
+            const R* row = vb + (size_t)((unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T);
+            v[n][kk] = ld_so<R>(row, tc * (unsigned)sizeof(R));
+          }
       }
     };
     Cx<R> w[N][M];
@@ -712,7 +732,10 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
       const int nmine = (fb - fa - h + ACT_NH - 1) / ACT_NH;
       auto issue_x = [&](int f, Vec2<R>(&x)[M]) {
 #pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = ldv<R>(xb + ((unsigned)(m * F + f) * (unsigned)T + tc));
+        for (int m = 0; m < M; ++m) {
+          const Cx<R>* row = xb + (size_t)((unsigned)(m * F + f) * (unsigned)T);  // uniform base + 32-bit lane offset
+          x[m] = ldv_so<R>(row, tc * (unsigned)sizeof(Cx<R>));
+        }
       };
       Vec2<R> xq[DXT][M];
 #pragma unroll
