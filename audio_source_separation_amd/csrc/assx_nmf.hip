@@ -11,17 +11,13 @@
 //   (3) finalize     : sum the split-K slabs, floor the denominator, multiply-update in place.
 // The GEMM is an LDS-tiled 64x64x16 register-blocked kernel in the storage precision.
 #include "assx_common.hpp"
+#include "assx_nmf_mfma.hpp"
 
 using namespace assx;
 
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, TM = 4, TN = 4;
-
-struct TermSpec {
-  int kind;
-  PowSpec pa, pb;  // exponents applied to TV for the numerator / denominator weights
-};
 
 // kind/domain -> elementwise weights (only TV and the denominators are floored: nmf.py:312-316)
 inline TermSpec make_terms(int kind, double d) {
@@ -50,11 +46,6 @@ inline PowSpec update_exponent(int kind, double d) {
     case ASSX_NMF_IS_MM: return make_pow(d / (d + 2.0));
     default: return make_pow(1.0);  // IS me: no outer power (nmf.py:345,354)
   }
-}
-
-template <typename R>
-__device__ __forceinline__ R pow0(R x, PowSpec p) {  // x**0 == 1 exactly as numpy (domain=2 EUC/KL numerators)
-  return (p.mode == POW_GENERIC && p.e == 0.0) ? (R)1 : powspec<R>(x, p);
 }
 
 // AB (B,2,F,T): AB[b,0] = numerator weights, AB[b,1] = denominator weights
@@ -256,6 +247,30 @@ struct NmfWs {
   size_t ab, part, lpart, total;
 };
 
+constexpr int NMF_MFMA_MAX_K = 64;
+
+// split counts of the MFMA path (deterministic: no device query)
+inline void mfma_basis_split(int B, int F, int T, int* TS, int* tchunk) {
+  const int fg = (F + 63) / 64;
+  int ts = (1024 + fg * B - 1) / (fg * B);
+  const int max_ts = (T + 63) / 64;
+  if (ts > max_ts) ts = max_ts;
+  if (ts < 1) ts = 1;
+  int chunk = ((T + ts - 1) / ts + 15) / 16 * 16;
+  *tchunk = chunk;
+  *TS = (T + chunk - 1) / chunk;
+}
+inline void mfma_act_split(int B, int F, int T, int* FS, int* fchunk) {
+  const int tg = (T + 15) / 16;
+  int fs = (1024 + tg * B - 1) / (tg * B);
+  const int max_fs = (F + 63) / 64;
+  if (fs > max_fs) fs = max_fs;
+  if (fs < 1) fs = 1;
+  int chunk = ((F + fs - 1) / fs + 15) / 16 * 16;
+  *fchunk = chunk;
+  *FS = (F + chunk - 1) / chunk;
+}
+
 inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   NmfWs w;
@@ -268,6 +283,13 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   const size_t sb = pick_splits((int)tiles_b, T), sa = pick_splits((int)tiles_a, F);
   size_t pmax = sb * 2 * B * F * K;
   if (sa * 2 * B * K * T > pmax) pmax = sa * 2 * B * K * T;
+  {
+    int TS, tchunk, FS, fchunk;
+    mfma_basis_split(B, F, T, &TS, &tchunk);
+    mfma_act_split(B, F, T, &FS, &fchunk);
+    if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
+    if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
+  }
   off += align_up(pmax * r, 256);
   w.lpart = off;
   off += align_up((size_t)B * F * ((T + 255) / 256) * 8, 256);
@@ -275,9 +297,44 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   return w;
 }
 
+// matrix-core path (n_basis <= 64): two chained-MFMA kernels + the split finalize
+template <typename R, int KT>
+int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
+                    int B, int F, int T, int K, int dtype, hipStream_t st) {
+  const NmfWs L = nmf_ws(B, F, T, K, dtype);
+  R* part = (R*)((char*)ws + L.part);
+  const TermSpec ts = make_terms(kind, domain);
+  const PowSpec pe = update_exponent(kind, domain);
+  int TS, tchunk, FS, fchunk;
+  mfma_basis_split(B, F, T, &TS, &tchunk);
+  mfma_act_split(B, F, T, &FS, &fchunk);
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X,
+                     (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_basis_mfma_kernel");
+  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 256)), dim3(256), 0, st, (const R*)part,
+                     (R*)Tb, B, (size_t)F * K, TS, (R)eps, pe);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
+  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT>), dim3((T + 15) / 16, FS, B), dim3(256), 0, st, (const R*)X,
+                     (const R*)Tb, (const R*)V, part, B, F, T, K, fchunk, (R)eps, ts);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_act_mfma_kernel");
+  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 256)), dim3(256), 0, st, (const R*)part,
+                     (R*)V, B, (size_t)K * T, FS, (R)eps, pe);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
+  return 0;
+}
+
 template <typename R>
 int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st) {
+  static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
+  if (K <= NMF_MFMA_MAX_K && !no_mfma) {
+    switch ((K + 15) / 16) {
+      case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      case 2: return nmf_update_mfma<R, 2>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      case 3: return nmf_update_mfma<R, 3>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      default: return nmf_update_mfma<R, 4>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+    }
+  }
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   R* AB = (R*)((char*)ws + L.ab);
   R* part = (R*)((char*)ws + L.part);

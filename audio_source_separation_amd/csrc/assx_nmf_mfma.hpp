@@ -1,0 +1,315 @@
+// NMF half-updates on the matrix cores (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32), n_basis <= 64.
+//
+// One half-update is three chained products per 16x16 sub-tile of the spectrogram, all register to register:
+//   (1) TV   = Tb V                       MFMA, K = n_basis          (or its transpose, see below)
+//   (2) A    = X * g(TV),  Bm = h(TV)     elementwise, in the accumulator layout
+//   (3) num += A . V^T,   den += Bm . V^T  (basis)      |  num += Tb^T . A, den += Tb^T . Bm  (activation)
+// The trick that avoids any LDS transpose: MFMA's accumulator register r of lane l holds row crow(r,l) and column
+// l&15, and the NEXT product reduces over exactly the rows (basis: frames, via the transposed product TV^T;
+// activation: bins) -- a reduction may take its terms in any order, so accumulator register r is fed straight back
+// as the k-slice r of the A (basis) / B (activation) operand, with the other operand loaded in the matching order.
+// Operand layout (probed on gfx950, tools/probes/mfma_f64_probe.hip): A lane l -> A[l&15][l>>4], B lane l ->
+// B[l>>4][l&15]; C/D f64: row (l>>4)+4r, f32: row 4(l>>4)+r; column l&15.
+// All global reads are 32- or 128-byte row segments whose cache lines are fully consumed by the same wave.
+#pragma once
+#include "assx_common.hpp"
+
+namespace assx {
+
+typedef double v4d_t __attribute__((ext_vector_type(4)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+template <typename R>
+struct Mfma16;
+template <>
+struct Mfma16<double> {
+  using acc_t = v4d_t;
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mfma16<float> {
+  using acc_t = v4f_t;
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int crow(int r, int lane) { return 4 * (lane >> 4) + r; }
+};
+
+struct TermSpec {
+  int kind;
+  PowSpec pa, pb;  // exponents applied to TV for the numerator / denominator weights
+};
+
+template <typename R>
+__device__ __forceinline__ R pow0(R x, PowSpec p) {  // x**0 == 1 exactly as numpy (domain=2 EUC/KL numerators)
+  return (p.mode == POW_GENERIC && p.e == 0.0) ? (R)1 : powspec<R>(x, p);
+}
+
+// numerator / denominator weights of one element (only TV is floored here: nmf.py:312-316)
+template <typename R>
+__device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R& a, R& bm) {
+  tv = floor_eps<R>(tv, eps);
+  if (s.kind == ASSX_NMF_EUC) {  // X * TV^((2-d)/d) ; TV^((4-d)/d)
+    a = x * pow0<R>(tv, s.pa);
+    bm = pow0<R>(tv, s.pb);
+  } else if (s.kind == ASSX_NMF_KL) {  // X / TV ; TV^((2-d)/d)
+    a = x / tv;
+    bm = pow0<R>(tv, s.pb);
+  } else {  // IS: X / TV^((d+2)/d) ; 1 / TV
+    bm = (R)1 / tv;
+    a = (s.pa.mode == POW_SQUARE) ? x * bm * bm : x / pow0<R>(tv, s.pa);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// basis half: num|den (F,K) = [A|Bm] (F,T) . V^T, reduced over this workgroup's frame range.
+//   grid (ceil(F/64), TS, B), 4 waves, wave w owns bins f0 = (4*blockIdx.x + w)*16 .. +15.
+//   part[ts][b*2 + s][f*K + k]
+// ---------------------------------------------------------------------------------------------------------
+template <typename R, int KT>
+__global__ void __launch_bounds__(256)
+    nmf_basis_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
+                          R* __restrict__ part, int B, int F, int T, int K, int tchunk, R eps, TermSpec s) {
+  using MM = Mfma16<R>;
+  using acc_t = typename MM::acc_t;
+  constexpr int KS = KT * 4;      // k-slices of 4 in product (1)
+  constexpr int KP = KT * 16;     // n_basis padded to the tile
+  constexpr int LD = 17;          // padded row of the staged tile (bank-conflict-free column reads)
+  constexpr int NLD = KP * 16 / 64;  // staged elements per lane
+  // The V tile (KP x 16 frames) is read in two layouts -- as A operand of (1) and as B operand of (3).  Each wave
+  // stages it once through its private LDS slice with coalesced 128-byte row reads instead of issuing 16 narrow
+  // global loads per sub-tile (the CU's single L1 pipe made the first version load-issue bound).
+  __shared__ R vt[4][KP][LD];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int b = blockIdx.z, ts = blockIdx.y;
+  const int f0 = (blockIdx.x * 4 + wv) * 16;
+  if (f0 >= F) return;  // no workgroup barriers in this kernel (LDS slices are wave-private)
+  const bool fvalid = f0 + li < F;
+  const int f = fvalid ? f0 + li : F - 1;
+  const R* xrow = X + ((size_t)b * F + f) * T;
+  const R* vb = V + (size_t)b * K * T;
+
+  R tb[KS];  // B operand of product (1): Tb^T[k = 4j + lk][f]
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int k = 4 * j + lk;
+    tb[j] = (k < K) ? Tb[((size_t)b * F + f) * K + k] : (R)0;
+  }
+  acc_t num[KT], den[KT];
+#pragma unroll
+  for (int c = 0; c < KT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      num[c][r] = 0;
+      den[c][r] = 0;
+    }
+
+  const int ta = ts * tchunk;
+  const int te = min(T, ta + tchunk);
+  // staged element e = i*64 + lane  ->  row k = e / 16, frame t0 + e % 16 (16 lanes cover one 128-byte row segment)
+  R stage[NLD];
+  R xq[4];  // X of the next sub-tile, in the accumulator layout (HBM latency hidden behind the current tile)
+  auto fetch = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 64 + lane;
+      const int k = e >> 4, tt = min(t0 + (e & 15), T - 1);
+      stage[i] = (k < K) ? vb[(size_t)k * T + tt] : (R)0;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xq[r] = xrow[min(t0 + MM::crow(r, lane), T - 1)];
+  };
+  fetch(ta);
+  for (int t0 = ta; t0 < te; t0 += 16) {
+    R xc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xc[r] = xq[r];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 64 + lane;
+      vt[wv][e >> 4][e & 15] = stage[i];
+    }
+    if (t0 + 16 < te) fetch(t0 + 16);  // next tile travels while this one is consumed
+    __builtin_amdgcn_wave_barrier();
+    // (1) TV^T sub-tile: rows = frames t0 + crow, columns = bins f0 + li
+    acc_t tv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tv[r] = 0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) tv = MM::mma(vt[wv][4 * j + lk][li], tb[j], tv);  // A operand: V^T[t = li][k]
+    // (2) elementwise in the accumulator layout
+    R a[4], bm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int t = t0 + MM::crow(r, lane);
+      nmf_terms<R>(s, xc[r], tv[r], eps, a[r], bm[r]);
+      if (!(fvalid && t < te)) {
+        a[r] = 0;
+        bm[r] = 0;
+      }
+    }
+    // (3) num[f, kb] += sum_t a[f,t] V[kb,t]: accumulator register r is k-slice r of the A operand
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const R vv = vt[wv][16 * c + li][MM::crow(r, lane)];  // B operand: V^T[t-pos of slice r][kb]; rows >= K are 0
+        num[c] = MM::mma(a[r], vv, num[c]);
+        den[c] = MM::mma(bm[r], vv, den[c]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // D[row = f0 + crow][col = kb]
+  const size_t FK = (size_t)F * K;
+  R* pn = part + ((size_t)ts * B * 2 + (size_t)b * 2) * FK;
+#pragma unroll
+  for (int c = 0; c < KT; ++c) {
+    const int kb = 16 * c + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fo = f0 + MM::crow(r, lane);
+      if (fo < F && kb < K) {
+        pn[(size_t)fo * K + kb] = num[c][r];
+        pn[FK + (size_t)fo * K + kb] = den[c][r];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// activation half: num|den (K,T) = Tb^T (K,F) . [A|Bm] (F,T), reduced over this workgroup's bin range.
+//   grid (ceil(T/16), FS, B); the 4 waves stride over the bin range in sub-tiles of 16 and are combined through LDS.
+//   part[fs][b*2 + s][k*T + t]
+// ---------------------------------------------------------------------------------------------------------
+template <typename R, int KT>
+__global__ void __launch_bounds__(256)
+    nmf_act_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
+                        int B, int F, int T, int K, int fchunk, R eps, TermSpec s) {
+  using MM = Mfma16<R>;
+  using acc_t = typename MM::acc_t;
+  constexpr int KS = KT * 4;
+  constexpr int KP = KT * 16;
+  constexpr int LD = KP + 4;          // padded row of the staged 16 x KP basis tile
+  constexpr int NLD = KP * 16 / 64;   // staged elements per lane
+  __shared__ R tt_[4][16][LD];        // wave-private basis tiles (read as A operand of (1) and of (3))
+  __shared__ R red[3][KT * 2 * 4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int b = blockIdx.z, fs = blockIdx.y;
+  const int t0 = blockIdx.x * 16;
+  const bool tvalid = t0 + li < T;
+  const int t = tvalid ? t0 + li : T - 1;
+  const R* tbb = Tb + (size_t)b * F * K;
+  const R* xb = X + (size_t)b * F * T;
+
+  R vbr[KS];  // B operand of product (1): V[k = 4j + lk][t]
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int k = 4 * j + lk;
+    vbr[j] = (k < K) ? V[((size_t)b * K + k) * T + t] : (R)0;
+  }
+  acc_t num[KT], den[KT];
+#pragma unroll
+  for (int c = 0; c < KT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      num[c][r] = 0;
+      den[c][r] = 0;
+    }
+
+  const int fa = fs * fchunk;
+  const int fe = min(F, fa + fchunk);
+  // staged element e = i*64 + lane -> bin f0 + e / KP, basis e % KP: consecutive lanes read consecutive k of a row
+  R stage[NLD];
+  R xq[4];  // X of the next sub-tile, in the accumulator layout
+  auto fetch = [&](int f0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 64 + lane;
+      const int fr = f0 + e / KP, k = e % KP;
+      stage[i] = (k < K && fr < fe) ? tbb[(size_t)fr * K + k] : (R)0;  // bins beyond the range contribute 0
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xq[r] = xb[(size_t)min(f0 + MM::crow(r, lane), F - 1) * T + t];
+  };
+  int f0 = fa + 16 * wv;
+  if (f0 < fe) fetch(f0);
+  for (; f0 < fe; f0 += 64) {
+    R xc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xc[r] = xq[r];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = i * 64 + lane;
+      tt_[wv][e / KP][e % KP] = stage[i];
+    }
+    if (f0 + 64 < fe) fetch(f0 + 64);
+    __builtin_amdgcn_wave_barrier();
+    // (1) TV sub-tile: rows = bins f0 + crow, columns = frames t0 + li
+    acc_t tv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tv[r] = 0;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) tv = MM::mma(tt_[wv][li][4 * j + lk], vbr[j], tv);  // A operand: Tb[f = li][k]
+    // (2)
+    R a[4], bm[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fr = f0 + MM::crow(r, lane);
+      nmf_terms<R>(s, xc[r], tv[r], eps, a[r], bm[r]);
+      if (!(tvalid && fr < fe)) {
+        a[r] = 0;
+        bm[r] = 0;
+      }
+    }
+    // (3) num[kb, t] += sum_f Tb[f,kb] a[f,t]: accumulator register r is k-slice r of the B operand
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const R tv3 = tt_[wv][MM::crow(r, lane)][16 * c + li];  // A operand: Tb^T[kb][f-pos of slice r]
+        num[c] = MM::mma(tv3, a[r], num[c]);
+        den[c] = MM::mma(tv3, bm[r], den[c]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  // combine the 4 waves
+  if (wv > 0) {
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[c][r];
+        red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[c][r];
+      }
+  }
+  __syncthreads();
+  if (wv == 0 && tvalid) {
+    const size_t KTt = (size_t)K * T;
+    R* pn = part + ((size_t)fs * B * 2 + (size_t)b * 2) * KTt;
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        R n = num[c][r], d = den[c][r];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          n += red[w][(c * 2 + 0) * 4 + r][lane];
+          d += red[w][(c * 2 + 1) * 4 + r][lane];
+        }
+        const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
+        if (kb < K) {
+          pn[(size_t)kb * T + t] = n;
+          pn[KTt + (size_t)kb * T + t] = d;
+        }
+      }
+  }
+}
+
+}  // namespace assx

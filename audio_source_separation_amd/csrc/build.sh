@@ -6,8 +6,12 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"
 pids=()
 for src in assx_api assx_bss assx_nmf; do
-  if [ ! -f "$src.o" ] || [ "$src.hip" -nt "$src.o" ] || [ assx_common.hpp -nt "$src.o" ] || \
-     [ assx_small_linalg.hpp -nt "$src.o" ] || [ ../../include/assx.h -nt "$src.o" ]; then
+  stale=0
+  [ -f "$src.o" ] || stale=1
+  for dep in "$src.hip" assx_common.hpp assx_small_linalg.hpp assx_stream.hpp assx_nmf_mfma.hpp ../../include/assx.h build.sh; do
+    [ "$dep" -nt "$src.o" ] && stale=1
+  done
+  if [ "$stale" = 1 ]; then
     $HIPCC $FLAGS -c "$src.hip" -o "$src.o" &
     pids+=($!)
   fi
