@@ -9,6 +9,7 @@ import numpy as np
 
 from .._device import to_device, to_numpy, torch
 from .._state import DeviceArray, DeviceState
+from .._loss import LazyLossList
 from .. import _lib
 from ..ops import Engine
 
@@ -30,7 +31,7 @@ class NMFbase(DeviceState):
         """
 
         self.n_basis = n_basis
-        self.loss = []
+        self.loss = LazyLossList()  # a list; entries are materialised from HBM on first read
 
         self.eps = eps
         self.domain = 2
@@ -88,7 +89,10 @@ class NMFbase(DeviceState):
 
             loss = self._engine.nmf_loss(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
                                          domain=self.domain, eps=self.eps)
-            self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
+            if isinstance(self.loss, LazyLossList):
+                self.loss.append_device(loss, self._batched)  # no host sync inside the loop
+            else:
+                self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
 
     def update_once(self):
         self._engine.nmf_update(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),

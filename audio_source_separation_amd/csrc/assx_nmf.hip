@@ -252,7 +252,7 @@ constexpr int NMF_MFMA_MAX_K = 64;
 // split counts of the MFMA path (deterministic: no device query)
 inline void mfma_basis_split(int B, int F, int T, int* TS, int* tchunk) {
   const int fg = (F + 63) / 64;
-  int ts = (1024 + fg * B - 1) / (fg * B);
+  int ts = (512 + fg * B - 1) / (fg * B);  // one resident round at 2 waves/SIMD; fewer slabs for the finalize
   const int max_ts = (T + 63) / 64;
   if (ts > max_ts) ts = max_ts;
   if (ts < 1) ts = 1;
@@ -292,7 +292,13 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   }
   off += align_up(pmax * r, 256);
   w.lpart = off;
-  off += align_up((size_t)B * F * ((T + 255) / 256) * 8, 256);
+  {
+    int FS, fchunk;
+    mfma_act_split(B, F, T, &FS, &fchunk);
+    size_t nl = (size_t)B * F * ((T + 255) / 256);
+    if ((size_t)B * FS * ((T + 15) / 16) > nl) nl = (size_t)B * FS * ((T + 15) / 16);
+    off += align_up(nl * 8, 256);
+  }
   w.total = off;
   return w;
 }
@@ -444,6 +450,36 @@ int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void
   double* lpart = (double*)((char*)ws + L.lpart);
   const PowSpec p2d = make_pow(2.0 / domain);
   const int k2 = (kind == ASSX_NMF_IS_ME) ? ASSX_NMF_IS_MM : kind;
+  static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
+  if (K <= NMF_MFMA_MAX_K && !no_mfma) {
+    int FS, fchunk;
+    mfma_act_split(B, F, T, &FS, &fchunk);
+    const dim3 g2((T + 15) / 16, FS, B);
+#define NMF_LOSS_LAUNCH(RT, KTV)                                                                                 \
+  hipLaunchKernelGGL((nmf_loss_mfma_kernel<RT, KTV>), g2, dim3(256), 0, st, (const RT*)X, (const RT*)Tb,          \
+                     (const RT*)V, lpart, F, T, K, fchunk, k2, eps, p2d)
+#define NMF_LOSS_BY_K(RT)                     \
+  switch ((K + 15) / 16) {                    \
+    case 1: NMF_LOSS_LAUNCH(RT, 1); break;    \
+    case 2: NMF_LOSS_LAUNCH(RT, 2); break;    \
+    case 3: NMF_LOSS_LAUNCH(RT, 3); break;    \
+    default: NMF_LOSS_LAUNCH(RT, 4);          \
+  }
+    if (dtype == ASSX_F64) {
+      NMF_LOSS_BY_K(double)
+    } else if (dtype == ASSX_F32) {
+      NMF_LOSS_BY_K(float)
+    } else {
+      return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+    }
+#undef NMF_LOSS_BY_K
+#undef NMF_LOSS_LAUNCH
+    ASSX_LAUNCH_CHECK(ctx, "nmf_loss_mfma_kernel");
+    hipLaunchKernelGGL(sum_reduce_f64_kernel, dim3(B), dim3(256), 0, st, (const double*)lpart, loss,
+                       (size_t)g2.x * g2.y);
+    ASSX_LAUNCH_CHECK(ctx, "sum_reduce_f64_kernel");
+    return 0;
+  }
   dim3 grid(nblocks(T, 256), F, B);
   if (dtype == ASSX_F64)
     hipLaunchKernelGGL((nmf_loss_kernel<double>), grid, dim3(256), 0, st, (const double*)X, (const double*)Tb,

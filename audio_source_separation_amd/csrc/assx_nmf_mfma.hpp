@@ -312,4 +312,72 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// loss: sum_{f,t} criterion((Tb V)^(2/domain), X)   (nmf.py:170-174, 229-233, 288-292; divergence.py:21-45)
+//   Same tiling as the activation kernel (TV sub-tiles by MFMA, elementwise in the accumulator layout);
+//   one float64 partial per workgroup: lpart[b][blockIdx.y * gridDim.x + blockIdx.x]
+// ---------------------------------------------------------------------------------------------------------
+template <typename R, int KT>
+__global__ void __launch_bounds__(256)
+    nmf_loss_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
+                         double* __restrict__ lpart, int F, int T, int K, int fchunk, int kind, double eps,
+                         PowSpec p2d) {
+  using MM = Mfma16<R>;
+  using acc_t = typename MM::acc_t;
+  constexpr int KS = KT * 4;
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  const int b = blockIdx.z, fs = blockIdx.y;
+  const int t0 = blockIdx.x * 16;
+  const bool tvalid = t0 + li < T;
+  const int t = tvalid ? t0 + li : T - 1;
+  const R* tbb = Tb + (size_t)b * F * K;
+  const R* xb = X + (size_t)b * F * T;
+  R vbr[KS];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int k = 4 * j + lk;
+    vbr[j] = (k < K) ? V[((size_t)b * K + k) * T + t] : (R)0;
+  }
+  const int fa = fs * fchunk;
+  const int fe = min(F, fa + fchunk);
+  double acc = 0.0;
+  for (int f0 = fa + 16 * wv; f0 < fe; f0 += 64) {
+    R xc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xc[r] = xb[(size_t)min(f0 + MM::crow(r, lane), F - 1) * T + t];
+    acc_t tv;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tv[r] = 0;
+    const int fA = min(f0 + li, F - 1);
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int k = 4 * j + lk;
+      const R ta = (k < K) ? tbb[(size_t)fA * K + k] : (R)0;
+      tv = MM::mma(ta, vbr[j], tv);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int fr = f0 + MM::crow(r, lane);
+      if (tvalid && fr < fe) {
+        const double in = (double)powspec<R>(tv[r], p2d);  // (T V) ** (2 / domain), not floored
+        const double x = (double)xc[r];
+        if (kind == ASSX_NMF_EUC) {
+          acc += (x - in) * (x - in);
+        } else {
+          const double _in = in + eps, _tg = x + eps;  // divergence.py:26-27, 39-40
+          const double ratio = _tg / _in;
+          acc += (kind == ASSX_NMF_KL) ? _tg * log(ratio) + _in - _tg : ratio - log(ratio) - 1.0;
+        }
+      }
+    }
+  }
+  acc = wave_allreduce_sum<double>(acc);
+  if (lane == 0) red[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    lpart[(size_t)b * gridDim.y * gridDim.x + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
 }  // namespace assx
