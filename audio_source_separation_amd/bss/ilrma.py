@@ -5,10 +5,15 @@ Same constructor, `__call__(input, iteration, **kwargs)`, attributes and callbac
 HIP kernels behind the C-ABI in include/assx.h (no CPU fallback).  Extra keyword-only arguments
 (`dtype`, `device`, `power_statistic`) default to the reference's behaviour.
 
+`algorithm_spatial='ISS'` is on the HIP path too: the rank-1 updates are applied to the demixing filters (Y = W X is
+linear in W, so the reference's statistics on Y are quadratic forms of the same weighted covariances as IP); unlike
+the reference, `demix_filter` therefore stays available during the loop instead of being None.
+
 Not yet on the HIP path: `partitioning=True`, `algorithm_spatial` in
-{'ISS', 'pairwise', 'IP2'} -- these raise NotImplementedError at call time instead of silently
-falling back to the CPU.
+{'pairwise', 'IP2'} -- these raise NotImplementedError at call time instead of silently falling back to the CPU.
 """
+import warnings
+
 import numpy as np
 
 from .._device import to_device, to_numpy, torch
@@ -64,8 +69,8 @@ class ILRMAbase(DeviceState):
     def _require_supported(self):
         if self.partitioning:
             raise NotImplementedError("partitioning=True is not on the HIP path yet (no CPU fallback is provided).")
-        if self.algorithm_spatial not in ('IP', 'IP1'):
-            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' (no CPU fallback is provided).".format(self.algorithm_spatial))
+        if self.algorithm_spatial not in ('IP', 'IP1', 'ISS'):
+            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' or 'ISS' (no CPU fallback is provided).".format(self.algorithm_spatial))
 
     def _ensure_engine(self):
         if self._engine is None:
@@ -227,6 +232,9 @@ class GaussILRMA(ILRMAbase):
         self.threshold = threshold
         self.power_statistic = power_statistic
 
+        if self.algorithm_spatial == 'ISS':
+            warnings.warn("in progress", UserWarning)  # as the reference does (ilrma.py:197-198)
+
         if self.algorithm_spatial in ['pairwise', 'IP2']:
             self.update_pair = None
 
@@ -316,7 +324,7 @@ class GaussILRMA(ILRMAbase):
         self._touch("T", "V")
 
     def update_spatial_model(self):
-        """Weighted covariance + iterative projection (ilrma.py:483-535)."""
+        """Weighted covariance + iterative projection (ilrma.py:483-535) or ISS sweep (ilrma.py:537-564)."""
         eng = self._engine
         C = pbins = None
         if self.normalize == 'power' and self.power_statistic == 'covariance':
@@ -325,8 +333,9 @@ class GaussILRMA(ILRMAbase):
                 self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
                 self._pbins = eng.empty((B, M, F), dtype=torch.float64)
             C, pbins = self._C, self._pbins
+        spatial = _lib.SPATIAL_ISS if self.algorithm_spatial == 'ISS' else _lib.SPATIAL_IP
         eng.ilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
-                                 threshold=self.threshold, status=self._status, C=C, power_bins=pbins)
+                                 threshold=self.threshold, status=self._status, C=C, power_bins=pbins, spatial=spatial)
         self._touch("W")
         self._estimation = None
 

@@ -6,7 +6,9 @@ One iteration = two passes over X on the device:
           negative log-likelihood for the current filters (iva.py:604-619 / 783-802), so recording the
           loss costs no extra pass;
   pass B  weighted covariance (iva.py:493-499) + IP sweep (iva.py:500-518).
-`algorithm_spatial` in {'ISS', 'pairwise', 'IP2'} is not on the HIP path yet and raises
+`algorithm_spatial='ISS'` (iva.py:525-542, 758-775) shares both passes: the rank-1 updates are applied to W through
+quadratic forms of the same covariances (Y = W X is linear in W), so `demix_filter` stays available in the loop.
+`algorithm_spatial` in {'pairwise', 'IP2'} is not on the HIP path yet and raises
 NotImplementedError at call time; there is no CPU fallback.
 """
 import numpy as np
@@ -160,8 +162,8 @@ class AuxIVAbase(IVAbase):
     def _require_supported(self):
         if self._KIND is None:
             raise NotImplementedError("Implement 'update_once' function.")
-        if self.algorithm_spatial not in ('IP', 'IP1'):
-            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' (no CPU fallback is provided).".format(self.algorithm_spatial))
+        if self.algorithm_spatial not in ('IP', 'IP1', 'ISS'):
+            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' or 'ISS' (no CPU fallback is provided).".format(self.algorithm_spatial))
 
     def _reset(self, **kwargs):
         super()._reset(**kwargs)
@@ -230,15 +232,24 @@ class AuxIVAbase(IVAbase):
     def update_once(self):
         if self.algorithm_spatial in ['IP', 'IP1']:
             self.update_once_ip()
+        elif self.algorithm_spatial == 'ISS':
+            self.update_once_iss()
         else:
             self._require_supported()
 
     def update_once_ip(self):
         """iva.py:481-523 / 714-757: weights from the current estimate, covariance, IP sweep."""
+        self._spatial_update(_lib.SPATIAL_IP)
+
+    def update_once_iss(self):
+        """iva.py:525-542 / 758-775: weights from the current estimate, covariance, ISS sweep."""
+        self._spatial_update(_lib.SPATIAL_ISS)
+
+    def _spatial_update(self, spatial):
         if self._r is None or self._r_src is not self._Wd:
             self._refresh_weights(with_loss=False)
         self._engine.auxiva_spatial_update(self._X, self._Wd, self._r, eps=self.eps, threshold=self.threshold,
-                                           status=self._status)
+                                           status=self._status, spatial=spatial)
         self._touch("W")
         self._estimation = None
         self._r = None

@@ -236,6 +236,108 @@ __global__ void __launch_bounds__(64)
 }
 
 // ------------------------------------------------------------------------------------------
+// (f1) ISS sweep (ilrma.py:537-564, iva.py:525-542, 758-775).  The reference applies the rank-1 updates to
+//      Y (N passes that read and rewrite Y).  Y = W X stays linear in W, so the statistics are quadratic forms of
+//      the SAME weighted covariances the IP path uses:
+//          sum_t y_s conj(y_n) / r_s = T w_s U_s w_n^H ,   sum_t |y_n|^2 / r_s = T w_n U_s w_n^H
+//      (sums, not means: the reference omits the 1/T of the paper) and the update is W[s,:] -= v_s W[n,:].
+//      One pass over X (cov_stream_kernel) + this per-bin kernel, same lane-group layout as ip_group_kernel.
+// ------------------------------------------------------------------------------------------
+template <typename R, int M, bool FROM_PART>
+__global__ void __launch_bounds__(64)
+    iss_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
+                     double n_frames, Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw,
+                     int B, int F) {
+  constexpr int N = M;
+  constexpr int MM = M * M;
+  constexpr int GW = next_pow2_c(MM);
+  constexpr int GPW = WAVE / GW;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int e = lane & (GW - 1);
+  const long long grp = (long long)blockIdx.x * GPW + lane / GW;
+  const bool in_range = grp < (long long)B * F;
+  const long long bf = in_range ? grp : (long long)B * F - 1;
+  const bool active = e < MM;
+  const int i = active ? e / M : 0, j = active ? e % M : 0;
+  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
+
+  Cd w;
+  {
+    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
+    w = cmake<double>((double)v.x, (double)v.y);
+  }
+  // this lane's element (i, j) of every source's covariance (the weights are fixed during the sweep)
+  Cd u[N];
+  if (FROM_PART) {
+    const unsigned q_lo = (unsigned)bf * (unsigned)fp.len;
+    const int g_lo = (int)(q_lo / (unsigned)fp.L), g_hi = (int)((q_lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      double re = 0.0, im = 0.0;
+      for (int g = g_lo; g <= g_hi; ++g) {
+        const int slot = (int)bf - (int)(((unsigned)g * (unsigned)fp.L) / (unsigned)fp.len);
+        const R* p = part + (((size_t)g * fp.S + slot) * N + s) * MM;
+        re += (double)p[base];
+        if (i != j) im += (double)p[base + 1];
+      }
+      if (i > j) im = -im;
+      u[s] = cmake<double>(re * inv_T, im * inv_T);
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      const Cx<R> v = U[(((size_t)b * N + s) * F + f) * MM + i * M + j];
+      u[s] = cmake<double>((double)v.x, (double)v.y);
+    }
+  }
+
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+    const Cd wn_i = group_shfl<GW>(w, n * M + i);
+    const Cd wn_jc = cconj(group_shfl<GW>(w, n * M + j));
+    Cd vmine = cmake<double>(0.0, 0.0);  // v_s for this lane's row s = i
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+      const Cd ws_i = group_shfl<GW>(w, s * M + i);
+      const Cd uw = cmul(u[s], wn_jc);          // U_s[i][j] conj(W[n][j])
+      Cd tq = cmul(ws_i, uw);                   // W[s][i] U_s[i][j] conj(W[n][j])
+      Cd td = cmul(wn_i, uw);                   // W[n][i] U_s[i][j] conj(W[n][j])
+      if (!active) {
+        tq = cmake<double>(0.0, 0.0);
+        td = tq;
+      }
+      const Cd q = cmake<double>(group_sum<GW>(tq.x), group_sum<GW>(tq.y));
+      const double d = group_sum<GW>(td.x);     // Hermitian form: real
+      Cd v;
+      if (s == n) v = cmake<double>(1.0 - 1.0 / sqrt(n_frames * d), 0.0);
+      else v = cmake<double>(q.x / d, q.y / d);
+      if (i == s) vmine = v;
+    }
+    const Cd wn_j = cconj(wn_jc);
+    const Cd dlt = cmul(vmine, wn_j);           // all rows use the OLD row n (Y - V_n Y[n] is evaluated at once)
+    w = cmake<double>(w.x - dlt.x, w.y - dlt.y);
+  }
+
+  if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
+  if (pw) {
+    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
+    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const Cd wni = group_shfl<GW>(w, n * M + i);
+      const Cd wnj = group_shfl<GW>(w, n * M + j);
+      const Cd t1 = cmul(wni, c);
+      double term = t1.x * wnj.x + t1.y * wnj.y;
+      if (!active) term = 0.0;
+      const double sum = group_sum<GW>(term);
+      if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // (a2) activation half: lanes own t; 4 waves stride over the f-split; LDS cross-wave reduce
 //      part[b][fs][(n*K + k)*2 + s][t]
 // ------------------------------------------------------------------------------------------
@@ -809,6 +911,21 @@ int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, v
   return 0;
 }
 
+template <typename R, int M>
+int run_iss(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
+            int B, int F, hipStream_t st) {
+  constexpr int GPW = WAVE / next_pow2_c(M * M);
+  const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
+  if (part)
+    hipLaunchKernelGGL((iss_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
+                       1.0 / (double)T, (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, B, F);
+  else
+    hipLaunchKernelGGL((iss_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                       (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, B, F);
+  ASSX_LAUNCH_CHECK(ctx, "iss_group_kernel");
+  return 0;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -862,6 +979,17 @@ int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int3
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     return run_ip<R, MM>(ctx, U, nullptr, FlatPart{}, 1, W, nullptr, nullptr, threshold, status, B, F, st);
+  });
+}
+
+int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, int M, int F, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, U && W && n_frames >= 1, ASSX_E_NULL, "assx_iss_update: NULL array / bad n_frames");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    return run_iss<R, MM>(ctx, U, nullptr, FlatPart{}, n_frames, W, nullptr, nullptr, B, F, st);
   });
 }
 
@@ -922,15 +1050,18 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
   });
 }
 
-int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double domain,
-                              double eps, double threshold, void* U_out, const void* C, double* power_bins,
-                              int32_t* status, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W, const void* Tb, const void* V,
+                              double domain, double eps, double threshold, void* U_out, const void* C,
+                              double* power_bins, int32_t* status, void* ws, int B, int M, int F, int T, int K,
+                              int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_spatial_update: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
   ASSX_REQUIRE(ctx, (C == nullptr) == (power_bins == nullptr), ASSX_E_ARG,
                "assx_ilrma_spatial_update: C and power_bins must be given together");
+  ASSX_REQUIRE(ctx, spatial == ASSX_SPATIAL_IP || spatial == ASSX_SPATIAL_ISS, ASSX_E_ARG, "bad spatial algorithm %d",
+               spatial);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -943,6 +1074,7 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void*
                          dim3(256), 0, st, (const R*)ws, (Cx<R>*)U_out, B, MM, F, fp, (R)(1.0 / (double)T));
       ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
     }
+    if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, B, F, st);
     return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, threshold, status, B, F, st);
   });
 }
@@ -1132,9 +1264,9 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
   });
 }
 
-int assx_auxiva_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* r, double eps, double threshold,
-                               void* U_out, int32_t* status, void* ws, int B, int M, int F, int T, int dtype,
-                               void* stream) {
+int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W, const void* r, double eps,
+                               double threshold, void* U_out, int32_t* status, void* ws, int B, int M, int F, int T,
+                               int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_spatial_update: NULL array");
   hipStream_t st = (hipStream_t)stream;
@@ -1149,6 +1281,7 @@ int assx_auxiva_spatial_update(assx_ctx* ctx, const void* X, void* W, const void
                          dim3(256), 0, st, (const R*)ws, (Cx<R>*)U_out, B, MM, F, fp, (R)(1.0 / (double)T));
       ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
     }
+    if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, B, F, st);
     return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, threshold, status, B, F, st);
   });
 }

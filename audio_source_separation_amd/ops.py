@@ -84,13 +84,19 @@ class Engine:
                                                ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_source_update")
 
+    def iss_update(self, U, W, n_frames):
+        B, F, N, M = (int(s) for s in W.shape)
+        self._check(L.assx_iss_update(self.ctx, ptr(U), ptr(W), int(n_frames), B, M, F, self.prec.code, self._st()),
+                    "assx_iss_update")
+        return W
+
     def ilrma_spatial_update(self, X, W, Tb, V, domain=2, eps=1e-12, threshold=1e12, status=None, U_out=None,
-                             C=None, power_bins=None):
+                             C=None, power_bins=None, spatial=_lib.SPATIAL_IP):
         """C (B,F,M,M) + power_bins (B,N,F) float64: also emit the per-bin power statistic of the updated filters."""
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_ilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
+        self._check(L.assx_ilrma_spatial_update(self.ctx, int(spatial), ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
                                                 float(threshold), ptr(U_out), ptr(C), ptr(power_bins), ptr(status),
                                                 ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_spatial_update")
@@ -157,10 +163,11 @@ class Engine:
                                           B, M, F, T, self.prec.code, self._st()), "assx_auxiva_weights")
         return r, loss
 
-    def auxiva_spatial_update(self, X, W, r, eps=1e-12, threshold=1e12, status=None, U_out=None):
+    def auxiva_spatial_update(self, X, W, r, eps=1e-12, threshold=1e12, status=None, U_out=None,
+                              spatial=_lib.SPATIAL_IP):
         B, M, F, T = self._dims(X)
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_auxiva_spatial_update(self.ctx, ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
+        self._check(L.assx_auxiva_spatial_update(self.ctx, int(spatial), ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
                                                  ptr(U_out), ptr(status), ptr(ws), B, M, F, T, self.prec.code,
                                                  self._st()), "assx_auxiva_spatial_update")
 

@@ -294,7 +294,50 @@ def gen_edge():
     save("edge_zeros_auxgauss", X=X, loss=np.asarray(model.loss), W_final=model.demix_filter, Y_out=Y)
 
 
+# ----------------------------------------------------------------------------
+# G6: ISS spatial updates
+# ----------------------------------------------------------------------------
+class SnapshotISS(Snapshot):
+    """During ISS the reference exposes demix_filter only inside callbacks (ilrma.py:219-228)."""
+
+
+def gen_iss():
+    for cls, tag in ((AuxLaplaceIVA, "laplace"), (AuxGaussIVA, "gauss")):
+        for M in (2, 3, 4):
+            F, T = 17, 48
+            X = convolutive_mixture(M, F, T, seed=600 + M)
+            snap = Snapshot((1, 2, 5), with_nmf=False)
+            model = cls(algorithm_spatial="ISS", callbacks=snap)
+            Y = model(X, iteration=5)
+            save("iss_auxiva_%s_m%d" % (tag, M), X=X, kind=tag, iters=np.asarray((1, 2, 5)), loss=np.asarray(model.loss),
+                 Y_out=Y, W_final=model.demix_filter, **snap.data)
+    seed = 650
+    for M, K, normalize, domain in [(2, 2, "power", 2), (4, 4, "power", 2), (3, 3, "projection-back", 2),
+                                    (4, 2, False, 2), (3, 4, "power", 1)]:
+        seed += 1
+        F, T = 17, 48
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        T0 = np.random.rand(M, F, K)
+        V0 = np.random.rand(M, K, T)
+        np.random.set_state(state)
+        snap = Snapshot((1, 2, 5), with_nmf=True)
+        model = GaussILRMA(n_basis=K, domain=domain, normalize=normalize, algorithm_spatial="ISS", callbacks=snap)
+        Y = model(X, iteration=5)
+        tag = "m%d_k%d_%s_d%s" % (M, K, {"power": "pow", "projection-back": "pb", False: "none"}[normalize],
+                                   str(domain).replace(".", ""))
+        save("iss_ilrma_" + tag, X=X, M=M, K=K, domain=domain, normalize=np.array(str(normalize)), seed=seed, T0=T0,
+             V0=V0, iters=np.asarray((1, 2, 5)), loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter,
+             T_final=model.basis, V_final=model.activation, **snap.data)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
+    gen_iss()
     gen_nmf()
     gen_auxiva()
     gen_ilrma()

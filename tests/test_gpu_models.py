@@ -96,6 +96,8 @@ def test_gauss_ilrma_api_surface():
     assert rel_err(Ysep, orc.separate(X, model.demix_filter)) < 1e-13
     with pytest.raises(NotImplementedError):
         GaussILRMA(partitioning=True)(X, iteration=1)
+    with pytest.warns(UserWarning):
+        GaussILRMA(algorithm_spatial="ISS")
     with pytest.raises(NotImplementedError):
         GaussILRMA(algorithm_spatial="IP2")(X, iteration=1)
     with pytest.raises(AssertionError):
@@ -203,7 +205,7 @@ def test_auxiva_options_and_edges(kind):
     Y = m(g["X"], iteration=3)
     assert rel_err(Y, g["Y_ref2"]) < 1e-9 and m.loss is None
     with pytest.raises(NotImplementedError):
-        cls(algorithm_spatial="ISS")(g["X"], iteration=1)
+        cls(algorithm_spatial="IP2")(g["X"], iteration=1)
     with pytest.raises(ValueError):
         cls(algorithm_spatial="bogus")
     g = load_golden("edge_zeros_aux%s" % kind)
@@ -274,3 +276,42 @@ def test_full_size_properties():
     np.testing.assert_allclose(p.cpu().numpy(), 1.0, rtol=1e-9)
     # the projected-back estimate reconstructs the reference channel: sum_n Y_n = X[ref]
     assert rel_err(Y.sum(dim=0).cpu().numpy(), X[0].cpu().numpy()) < 1e-9
+
+
+ISS_AUX = ["iss_auxiva_%s_m%d" % (k, m) for k in ("laplace", "gauss") for m in (2, 3, 4)]
+ISS_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "iss_ilrma_*.npz")))
+
+
+@pytest.mark.parametrize("name", ISS_AUX)
+def test_auxiva_iss_golden(name):
+    from audio_source_separation_amd.bss.iva import AuxGaussIVA, AuxLaplaceIVA
+    g = load_golden(name)
+    cls = AuxLaplaceIVA if str(g["kind"]) == "laplace" else AuxGaussIVA
+    iters = [int(k) for k in g["iters"]]
+    snap = Snap(iters, nmf=False)
+    model = cls(algorithm_spatial="ISS", callbacks=snap)
+    Y = model(g["X"], iteration=max(iters))
+    for k in iters:
+        assert rel_err(snap.data["W_%d" % k], g["W_%d" % k]) < 1e-8, k
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-8 and rel_err(model.demix_filter, g["W_final"]) < 1e-8
+
+
+@pytest.mark.parametrize("name", ISS_ILRMA)
+def test_gauss_ilrma_iss_golden(name):
+    import warnings
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    snap = Snap(iters, nmf=True)
+    np.random.seed(int(g["seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = GaussILRMA(n_basis=int(g["K"]), domain=float(g["domain"]), normalize=_norm(g), algorithm_spatial="ISS",
+                           callbacks=snap)
+    Y = model(g["X"], iteration=max(iters))
+    for k in iters:
+        for key in ("W", "T", "V"):
+            assert rel_err(snap.data["%s_%d" % (key, k)], g["%s_%d" % (key, k)]) < 1e-8, (key, k)
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-8 and rel_err(model.demix_filter, g["W_final"]) < 1e-8

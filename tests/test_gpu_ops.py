@@ -298,3 +298,15 @@ def test_nmf_golden(eng, name):
         assert rel_err(host(Td)[0], g["T_%d" % k]) < scale * tol(eng, 1e-11, 1e-4), k
         assert rel_err(host(Vd)[0], g["V_%d" % k]) < scale * tol(eng, 1e-11, 1e-4), k
     np.testing.assert_allclose(losses, g["loss_%d" % int(g["iters"][-1])], rtol=tol(eng, 1e-10, 2e-4))
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES[:3])
+def test_iss_update(eng, M, F, T):
+    """ISS on the covariances (assx_iss_update) == the reference's Y-based sweep (oracle.iss_update)."""
+    X, W = mixture(M, F, T, 80), rand_filters(M, F, 81)
+    R = np.random.default_rng(82).random((M, F, T)) + 0.05
+    U = orc.weighted_covariance(X, R)
+    Wd = dev_c(eng, W[None])
+    eng.iss_update(dev_c(eng, U[None]), Wd, T)
+    Y = orc.iss_update(orc.separate(X, W), R)
+    assert rel_err(orc.separate(X, host(Wd)[0]), Y) < tol(eng, 1e-10, 2e-3)

@@ -172,3 +172,31 @@ def test_edge_zeros():
         res = orc.auxiva(g["X"], 3, kind)
         np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-9)
         assert rel_err(res["Y"], g["Y_out"]) < 1e-8
+
+
+ISS_AUX = ["iss_auxiva_%s_m%d" % (k, m) for k in ("laplace", "gauss") for m in (2, 3, 4)]
+ISS_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "iss_ilrma_*.npz")))
+
+
+@pytest.mark.parametrize("name", ISS_AUX)
+def test_iss_auxiva(name):
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    res = orc.auxiva_iss(g["X"], max(iters), str(g["kind"]), snapshots=iters)
+    for k in iters:
+        assert rel_err(res["snapshots"][k], g["W_%d" % k]) < 1e-9, k
+    np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(res["Y"], g["Y_out"]) < 1e-9 and rel_err(res["W"], g["W_final"]) < 1e-9
+
+
+@pytest.mark.parametrize("name", ISS_ILRMA)
+def test_iss_ilrma(name):
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    res = orc.gauss_ilrma_iss(g["X"], max(iters), g["T0"], g["V0"], domain=float(g["domain"]), normalize=_norm(g),
+                              snapshots=iters)
+    for k in iters:
+        W, T, V = res["snapshots"][k]
+        assert rel_err(W, g["W_%d" % k]) < 1e-9 and rel_err(T, g["T_%d" % k]) < 1e-9 and rel_err(V, g["V_%d" % k]) < 1e-9
+    np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(res["Y"], g["Y_out"]) < 1e-9 and rel_err(res["W"], g["W_final"]) < 1e-9
