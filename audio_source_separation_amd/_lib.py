@@ -19,7 +19,7 @@ W_NONE, W_NT, W_NFT = 0, 1, 2
 IVA_LAPLACE, IVA_GAUSS = 0, 1
 NMF_EUC, NMF_KL, NMF_IS_MM, NMF_IS_ME = 0, 1, 2, 3
 STATUS_SINGULAR, STATUS_COND_REJECT = 1, 2
-SPATIAL_IP, SPATIAL_ISS = 0, 1
+SPATIAL_IP, SPATIAL_ISS, SPATIAL_IP2 = 0, 1, 2
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -36,8 +36,9 @@ SIGNATURES = {
     "assx_demix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_cov_accumulate": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),
-    "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "assx_ilrma_spatial_update": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, ctypes.c_uint, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_spatial_update": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ip2_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_iss_update": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_cov_partials": (_i, [_vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_demix_power": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -47,7 +48,7 @@ SIGNATURES = {
     "assx_ilrma_normalize_pb": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_auxiva_weights": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "assx_auxiva_spatial_update": (_i, [_vp, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_auxiva_spatial_update": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back_scale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

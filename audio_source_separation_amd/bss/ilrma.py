@@ -9,8 +9,10 @@ HIP kernels behind the C-ABI in include/assx.h (no CPU fallback).  Extra keyword
 linear in W, so the reference's statistics on Y are quadratic forms of the same weighted covariances as IP); unlike
 the reference, `demix_filter` therefore stays available during the loop instead of being None.
 
-Not yet on the HIP path: `partitioning=True`, `algorithm_spatial` in
-{'pairwise', 'IP2'} -- these raise NotImplementedError at call time instead of silently falling back to the CPU.
+`algorithm_spatial in {'IP2', 'pairwise'}` (ilrma.py:432-481, 566-646) is on the HIP path as well.
+
+Not yet on the HIP path: `partitioning=True` -- raises NotImplementedError at call
+time instead of silently falling back to the CPU.
 """
 import warnings
 
@@ -69,8 +71,8 @@ class ILRMAbase(DeviceState):
     def _require_supported(self):
         if self.partitioning:
             raise NotImplementedError("partitioning=True is not on the HIP path yet (no CPU fallback is provided).")
-        if self.algorithm_spatial not in ('IP', 'IP1', 'ISS'):
-            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' or 'ISS' (no CPU fallback is provided).".format(self.algorithm_spatial))
+        if self.algorithm_spatial not in ('IP', 'IP1', 'ISS', 'IP2', 'pairwise'):
+            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path (no CPU fallback is provided).".format(self.algorithm_spatial))
 
     def _ensure_engine(self):
         if self._engine is None:
@@ -255,6 +257,9 @@ class GaussILRMA(ILRMAbase):
         self._run_callbacks()
 
         for idx in range(iteration):
+            if self.algorithm_spatial in ['pairwise', 'IP2']:
+                self._select_update_pair()
+
             self.update_once()
 
             if self.recordable_loss:
@@ -319,9 +324,29 @@ class GaussILRMA(ILRMAbase):
             self._estimation = None
 
     def update_source_model(self):
-        """IS-NMF (mm) update of basis then activation on P = |W x|^2 (ilrma.py:356-366, 409-430)."""
-        self._engine.ilrma_source_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps)
+        """IS-NMF (mm) update of basis then activation on P = |W x|^2 (ilrma.py:356-366, 409-430); with IP2 only the
+        selected pair's source models move (ilrma.py:432-481)."""
+        sources = None
+        if self.algorithm_spatial in ['pairwise', 'IP2']:
+            if self.partitioning:
+                raise NotImplementedError("Not support partitioning function.")
+            sources = self.update_pair
+        self._engine.ilrma_source_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
+                                         sources=sources)
         self._touch("T", "V")
+
+    def _select_update_pair(self):
+        """(0,1), (1,2), ..., (N-1,0)   (ilrma.py:635-646)."""
+        n_sources = self.n_sources
+
+        if self.update_pair is None:
+            m, n = 0, 1
+        else:
+            m, n = self.update_pair
+            m, n = m + 1, n + 1
+            m, n = m % n_sources, n % n_sources
+
+        self.update_pair = m, n
 
     def update_spatial_model(self):
         """Weighted covariance + iterative projection (ilrma.py:483-535) or ISS sweep (ilrma.py:537-564)."""
@@ -333,9 +358,14 @@ class GaussILRMA(ILRMAbase):
                 self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
                 self._pbins = eng.empty((B, M, F), dtype=torch.float64)
             C, pbins = self._C, self._pbins
-        spatial = _lib.SPATIAL_ISS if self.algorithm_spatial == 'ISS' else _lib.SPATIAL_IP
+        spatial, pair = _lib.SPATIAL_IP, (0, 1)
+        if self.algorithm_spatial == 'ISS':
+            spatial = _lib.SPATIAL_ISS
+        elif self.algorithm_spatial in ['pairwise', 'IP2']:
+            spatial, pair = _lib.SPATIAL_IP2, self.update_pair
         eng.ilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
-                                 threshold=self.threshold, status=self._status, C=C, power_bins=pbins, spatial=spatial)
+                                 threshold=self.threshold, status=self._status, C=C, power_bins=pbins, spatial=spatial,
+                                 pair=pair)
         self._touch("W")
         self._estimation = None
 

@@ -8,8 +8,8 @@ One iteration = two passes over X on the device:
   pass B  weighted covariance (iva.py:493-499) + IP sweep (iva.py:500-518).
 `algorithm_spatial='ISS'` (iva.py:525-542, 758-775) shares both passes: the rank-1 updates are applied to W through
 quadratic forms of the same covariances (Y = W X is linear in W), so `demix_filter` stays available in the loop.
-`algorithm_spatial` in {'pairwise', 'IP2'} is not on the HIP path yet and raises
-NotImplementedError at call time; there is no CPU fallback.
+`algorithm_spatial in {'IP2', 'pairwise'}` (iva.py:544-599) is on the HIP path for AuxLaplaceIVA; AuxGaussIVA raises
+NotImplementedError for it exactly like the reference (iva.py:777-778).  There is no CPU fallback.
 """
 import numpy as np
 
@@ -162,8 +162,10 @@ class AuxIVAbase(IVAbase):
     def _require_supported(self):
         if self._KIND is None:
             raise NotImplementedError("Implement 'update_once' function.")
-        if self.algorithm_spatial not in ('IP', 'IP1', 'ISS'):
-            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path yet; use 'IP' or 'ISS' (no CPU fallback is provided).".format(self.algorithm_spatial))
+        if self.algorithm_spatial in ('pairwise', 'IP2') and self._KIND == _lib.IVA_GAUSS:
+            raise NotImplementedError("In progress...")  # iva.py:777-778
+        if self.algorithm_spatial not in ('IP', 'IP1', 'ISS', 'pairwise', 'IP2'):
+            raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path (no CPU fallback is provided).".format(self.algorithm_spatial))
 
     def _reset(self, **kwargs):
         super()._reset(**kwargs)
@@ -197,6 +199,9 @@ class AuxIVAbase(IVAbase):
                 callback(self)
 
         for idx in range(iteration):
+            if self.algorithm_spatial in ['pairwise', 'IP2']:
+                self._select_update_pair()
+
             self.update_once()
 
             if self.recordable_loss:
@@ -234,6 +239,8 @@ class AuxIVAbase(IVAbase):
             self.update_once_ip()
         elif self.algorithm_spatial == 'ISS':
             self.update_once_iss()
+        elif self.algorithm_spatial in ['pairwise', 'IP2']:
+            self.update_once_pairwise()
         else:
             self._require_supported()
 
@@ -245,11 +252,29 @@ class AuxIVAbase(IVAbase):
         """iva.py:525-542 / 758-775: weights from the current estimate, covariance, ISS sweep."""
         self._spatial_update(_lib.SPATIAL_ISS)
 
-    def _spatial_update(self, spatial):
+    def update_once_pairwise(self):
+        """iva.py:544-599: pairwise update of rows `update_pair`."""
+        self._require_supported()
+        self._spatial_update(_lib.SPATIAL_IP2, pair=self.update_pair)
+
+    def _select_update_pair(self):
+        """(0,1), (1,2), ..., (N-1,0)   (iva.py:370-382)."""
+        n_sources = self.n_sources
+
+        if self.update_pair is None:
+            m, n = 0, 1
+        else:
+            m, n = self.update_pair
+            m, n = m + 1, n + 1
+            m, n = m % n_sources, n % n_sources
+
+        self.update_pair = m, n
+
+    def _spatial_update(self, spatial, pair=(0, 1)):
         if self._r is None or self._r_src is not self._Wd:
             self._refresh_weights(with_loss=False)
         self._engine.auxiva_spatial_update(self._X, self._Wd, self._r, eps=self.eps, threshold=self.threshold,
-                                           status=self._status, spatial=spatial)
+                                           status=self._status, spatial=spatial, pair=pair)
         self._touch("W")
         self._estimation = None
         self._r = None

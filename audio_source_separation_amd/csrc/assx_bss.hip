@@ -93,6 +93,70 @@ __device__ __forceinline__ Cd group_shfl(Cd v, int src) {
   return cmake<double>(__shfl(v.x, src, GW), __shfl(v.y, src, GW));
 }
 
+// In-group Gauss-Jordan inverse with partial pivoting (LAPACK's pivot rule: first max of |re|+|im|) of the M x M
+// matrix whose element (i, j) lives in lane (i, j) of a GW-lane group.  Returns this lane's element of the inverse.
+template <int M, int GW>
+__device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singular) {
+  int piv[M];
+#pragma unroll
+  for (int c = 0; c < M; ++c) {
+    int p = c;
+    double best = -1.0;
+#pragma unroll
+    for (int r = c; r < M; ++r) {
+      const double m1 = cabs1(group_shfl<GW>(a, r * M + c));
+      if (m1 > best) {
+        best = m1;
+        p = r;
+      }
+    }
+    if (!(best > 0.0)) singular = true;
+    piv[c] = p;
+    const int src_i = (i == c) ? p : ((i == p) ? c : i);
+    a = group_shfl<GW>(a, src_i * M + j);  // row interchange c <-> p
+    const Cd pv = group_shfl<GW>(a, c * M + c);
+    const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
+    const Cd acj = group_shfl<GW>(a, c * M + j);
+    const Cd rcj = cmul((j == c) ? cmake<double>(1.0, 0.0) : acj, ipv);
+    const Cd fic = group_shfl<GW>(a, i * M + c);
+    if (i == c) {
+      a = rcj;
+    } else {
+      const Cd base = (j == c) ? cmake<double>(0.0, 0.0) : a;
+      a = cmake<double>(base.x - (fic.x * rcj.x - fic.y * rcj.y), base.y - (fic.x * rcj.y + fic.y * rcj.x));
+    }
+  }
+#pragma unroll
+  for (int c = M - 1; c >= 0; --c) {  // undo the row interchanges as column interchanges
+    const int p = piv[c];
+    const int src_j = (j == c) ? p : ((j == p) ? c : j);
+    a = group_shfl<GW>(a, i * M + src_j);
+  }
+  return a;
+}
+
+// cond_2(A) < thr from A (a0) and its inverse (ainv), element (i, j) per lane: Frobenius bounds, exact spectral
+// norms only inside the factor-M band (every lane gathers both matrices; rare).
+template <int M, int GW>
+__device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bool singular, double thr) {
+  constexpr int MM = M * M;
+  const double nA2 = group_sum<GW>(active ? cabs2(a0) : 0.0);
+  const double nI2 = group_sum<GW>(active ? cabs2(ainv) : 0.0);
+  const double condF = sqrt(nA2) * sqrt(nI2);
+  const bool amb = !singular && (condF == condF) && condF >= thr && condF < thr * (double)M;
+  bool ok = !singular && (condF == condF) && condF < thr;
+  if (__any(amb)) {
+    Cd ma[MM], mi[MM];
+#pragma unroll
+    for (int q = 0; q < MM; ++q) {
+      ma[q] = group_shfl<GW>(a0, q);
+      mi[q] = group_shfl<GW>(ainv, q);
+    }
+    if (amb) ok = spectral_norm_slow(ma, M) * spectral_norm_slow(mi, M) < thr;
+  }
+  return ok;
+}
+
 template <typename R, int M, bool FROM_PART>
 __global__ void __launch_bounds__(64)
     ip_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
@@ -150,61 +214,10 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
     for (int k = 0; k < M; ++k) cfma(a, group_shfl<GW>(w, i * M + k), group_shfl<GW>(u, k * M + j));
     const Cd a0 = a;
-    const double nA2 = group_sum<GW>(active ? cabs2(a) : 0.0);
-    // ---- in-place Gauss-Jordan inverse with partial pivoting (LAPACK's pivot rule: first max of |re|+|im|)
     bool singular = false;
-    int piv[M];
-#pragma unroll
-    for (int c = 0; c < M; ++c) {
-      int p = c;
-      double best = -1.0;
-#pragma unroll
-      for (int r = c; r < M; ++r) {
-        const double m1 = cabs1(group_shfl<GW>(a, r * M + c));
-        if (m1 > best) {
-          best = m1;
-          p = r;
-        }
-      }
-      if (!(best > 0.0)) singular = true;
-      piv[c] = p;
-      const int src_i = (i == c) ? p : ((i == p) ? c : i);
-      a = group_shfl<GW>(a, src_i * M + j);  // row interchange c <-> p
-      const Cd pv = group_shfl<GW>(a, c * M + c);
-      const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
-      const Cd acj = group_shfl<GW>(a, c * M + j);
-      const Cd rcj = cmul((j == c) ? cmake<double>(1.0, 0.0) : acj, ipv);
-      const Cd fic = group_shfl<GW>(a, i * M + c);
-      if (i == c) {
-        a = rcj;
-      } else {
-        const Cd base = (j == c) ? cmake<double>(0.0, 0.0) : a;
-        a = cmake<double>(base.x - (fic.x * rcj.x - fic.y * rcj.y), base.y - (fic.x * rcj.y + fic.y * rcj.x));
-      }
-    }
-#pragma unroll
-    for (int c = M - 1; c >= 0; --c) {  // undo the row interchanges as column interchanges
-      const int p = piv[c];
-      const int src_j = (j == c) ? p : ((j == p) ? c : j);
-      a = group_shfl<GW>(a, i * M + src_j);
-    }
-    const double nI2 = group_sum<GW>(active ? cabs2(a) : 0.0);
-    // ---- cond_2(WU) < threshold ?   (Frobenius bounds; exact spectral norms only in the factor-M band)
-    bool ok;
-    {
-      const double condF = sqrt(nA2) * sqrt(nI2);
-      const bool amb = !singular && (condF == condF) && condF >= thr && condF < thr * (double)M;
-      ok = !singular && (condF == condF) && condF < thr;
-      if (__any(amb)) {  // rare: every lane gathers both matrices and evaluates redundantly
-        Cd ma[MM], mi[MM];
-#pragma unroll
-        for (int q = 0; q < MM; ++q) {
-          ma[q] = group_shfl<GW>(a0, q);
-          mi[q] = group_shfl<GW>(a, q);
-        }
-        if (amb) ok = spectral_norm_slow(ma, M) * spectral_norm_slow(mi, M) < thr;
-      }
-    }
+    a = group_gj_inverse<M, GW>(a, i, j, singular);
+    // ---- cond_2(WU) < threshold ?
+    const bool ok = group_cond_below<M, GW>(a0, a, active, singular, thr);
     if (singular) flags |= ASSX_STATUS_SINGULAR;       // numpy.linalg.solve raises here
     else if (!ok) flags |= ASSX_STATUS_COND_REJECT;    // keep the old row (np.where(condition, ..., w_n_Hermite))
     // ---- w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
@@ -335,6 +348,159 @@ __global__ void __launch_bounds__(64)
       if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// (f1) IP2 / pairwise update of rows (pm, pn) (ilrma.py:566-633, iva.py:544-599).  Same lane-group layout.
+//      P_x = (W U_x)^{-1} [e_pm e_pn];  V_x = P_x^H U_x P_x (2x2);  eig(V_pn^{-1} V_pm), eigenvectors sorted by
+//      descending eigenvalue with LAPACK zgeev's convention (unit 2-norm, largest component real) so that W, not
+//      only |W|, matches the reference;  w_x = conj(P_x v_x / sqrt(v_x^H V_x v_x)).  Both rows use the OLD W.
+// ------------------------------------------------------------------------------------------
+template <typename R, int M, bool FROM_PART>
+__global__ void __launch_bounds__(64)
+    ip2_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
+                     Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
+                     int32_t* __restrict__ status, int B, int F, int pm, int pn) {
+  constexpr int N = M;
+  constexpr int MM = M * M;
+  constexpr int GW = next_pow2_c(MM);
+  constexpr int GPW = WAVE / GW;
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int e = lane & (GW - 1);
+  const long long grp = (long long)blockIdx.x * GPW + lane / GW;
+  const bool in_range = grp < (long long)B * F;
+  const long long bf = in_range ? grp : (long long)B * F - 1;
+  const bool active = e < MM;
+  const int i = active ? e / M : 0, j = active ? e % M : 0;
+  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
+
+  Cd w;
+  {
+    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
+    w = cmake<double>((double)v.x, (double)v.y);
+  }
+  auto load_u = [&](int src) -> Cd {
+    if (FROM_PART) {
+      const unsigned q_lo = (unsigned)bf * (unsigned)fp.len;
+      const int g_lo = (int)(q_lo / (unsigned)fp.L), g_hi = (int)((q_lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+      const int lo = i < j ? i : j, hi = i < j ? j : i;
+      const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
+      double re = 0.0, im = 0.0;
+      for (int g = g_lo; g <= g_hi; ++g) {
+        const int slot = (int)bf - (int)(((unsigned)g * (unsigned)fp.L) / (unsigned)fp.len);
+        const R* p = part + (((size_t)g * fp.S + slot) * N + src) * MM;
+        re += (double)p[base];
+        if (i != j) im += (double)p[base + 1];
+      }
+      if (i > j) im = -im;
+      return cmake<double>(re * inv_T, im * inv_T);
+    }
+    const Cx<R> v = U[(((size_t)b * N + src) * F + f) * MM + i * M + j];
+    return cmake<double>((double)v.x, (double)v.y);
+  };
+  int flags = 0;
+  const int col[2] = {pm, pn};
+  Cd ux[2], inv[2];
+  bool okx[2];
+  Cd V[2][2][2];  // V[x][a][b], x = 0 -> source pm, 1 -> source pn
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+    ux[x] = load_u(col[x]);
+    Cd a = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) cfma(a, group_shfl<GW>(w, i * M + k), group_shfl<GW>(ux[x], k * M + j));
+    const Cd a0 = a;
+    bool singular = false;
+    a = group_gj_inverse<M, GW>(a, i, j, singular);
+    okx[x] = group_cond_below<M, GW>(a0, a, active, singular, thr);
+    if (singular) flags |= ASSX_STATUS_SINGULAR;  // numpy.linalg.inv raises
+    else if (!okx[x]) flags |= ASSX_STATUS_COND_REJECT;
+    inv[x] = a;
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) {
+        const Cd pia = group_shfl<GW>(a, i * M + col[aa]);
+        const Cd pjb = group_shfl<GW>(a, j * M + col[bb]);
+        Cd term = cmul(cmul(cconj(pia), ux[x]), pjb);
+        if (!active) term = cmake<double>(0.0, 0.0);
+        V[x][aa][bb] = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
+      }
+  }
+  // VV = V_pn^{-1} V_pm  (2x2)
+  const Cd detn = csub(cmul(V[1][0][0], V[1][1][1]), cmul(V[1][0][1], V[1][1][0]));
+  if (detn.x == 0.0 && detn.y == 0.0) flags |= ASSX_STATUS_SINGULAR;
+  const Cd idet = cdiv(cmake<double>(1.0, 0.0), detn);
+  const Cd ni[2][2] = {{cmul(V[1][1][1], idet), cmul(cmake<double>(-V[1][0][1].x, -V[1][0][1].y), idet)},
+                       {cmul(cmake<double>(-V[1][1][0].x, -V[1][1][0].y), idet), cmul(V[1][0][0], idet)}};
+  Cd VV[2][2];
+#pragma unroll
+  for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) VV[aa][bb] = cadd(cmul(ni[aa][0], V[0][0][bb]), cmul(ni[aa][1], V[0][1][bb]));
+  // eigenvalues of the 2x2
+  const Cd htr = cscale(cadd(VV[0][0], VV[1][1]), 0.5);
+  const Cd det = csub(cmul(VV[0][0], VV[1][1]), cmul(VV[0][1], VV[1][0]));
+  const Cd disc = csqrt_principal(csub(cmul(htr, htr), det));
+  Cd lam[2] = {cadd(htr, disc), csub(htr, disc)};
+  // numpy argsort of complex = lexicographic (real, imag); order[::-1] -> largest first
+  const bool first_big = (lam[0].x > lam[1].x) || (lam[0].x == lam[1].x && lam[0].y >= lam[1].y);
+  if (!first_big) {
+    const Cd t = lam[0];
+    lam[0] = lam[1];
+    lam[1] = t;
+  }
+  Cd wrow[2];  // this lane's new W[pm][j] / W[pn][j]
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {  // x = 0: eigenvector of the larger eigenvalue -> row pm; x = 1 -> row pn
+    // eigenvector of VV for lam[x]: the better conditioned of [b, lam - a] and [lam - d, c]
+    const Cd c1[2] = {VV[0][1], csub(lam[x], VV[0][0])};
+    const Cd c2[2] = {csub(lam[x], VV[1][1]), VV[1][0]};
+    const double n1 = cabs2(c1[0]) + cabs2(c1[1]), n2 = cabs2(c2[0]) + cabs2(c2[1]);
+    Cd v[2] = {n1 >= n2 ? c1[0] : c2[0], n1 >= n2 ? c1[1] : c2[1]};
+    const double nrm = sqrt(n1 >= n2 ? n1 : n2);
+    v[0] = cscale(v[0], 1.0 / nrm);
+    v[1] = cscale(v[1], 1.0 / nrm);
+    // zgeev: rotate so that the component of largest modulus is real (first one on ties)
+    const int kbig = (cabs2(v[1]) > cabs2(v[0])) ? 1 : 0;
+    const double mag = sqrt(cabs2(v[kbig]));
+    const Cd rot = cscale(cconj(v[kbig]), 1.0 / mag);
+    v[0] = cmul(v[0], rot);
+    v[1] = cmul(v[1], rot);
+    v[kbig].y = 0.0;
+    // normalise by sqrt(v^H V_x v)
+    Cd q = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) cfma(q, cmul(cconj(v[aa]), V[x][aa][bb]), v[bb]);
+    const Cd den = csqrt_principal(q);
+    v[0] = cdiv(v[0], den);
+    v[1] = cdiv(v[1], den);
+    // w_x[c] = conj(P_x[c][0] v0 + P_x[c][1] v1), c = channel = this lane's column j
+    const Cd p0 = group_shfl<GW>(inv[x], j * M + pm);
+    const Cd p1 = group_shfl<GW>(inv[x], j * M + pn);
+    wrow[x] = cconj(cadd(cmul(p0, v[0]), cmul(p1, v[1])));
+  }
+  if (i == pm && okx[0] && !(flags & ASSX_STATUS_SINGULAR)) w = wrow[0];
+  if (i == pn && okx[1] && !(flags & ASSX_STATUS_SINGULAR)) w = wrow[1];
+
+  if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
+  if (pw) {
+    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
+    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const Cd wni = group_shfl<GW>(w, n * M + i);
+      const Cd wnj = group_shfl<GW>(w, n * M + j);
+      const Cd t1 = cmul(wni, c);
+      double term = t1.x * wnj.x + t1.y * wnj.y;
+      if (!active) term = 0.0;
+      const double sum = group_sum<GW>(term);
+      if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
+    }
+  }
+  if (flags && status && in_range && e == 0) atomicOr(&status[b], flags);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -926,6 +1092,21 @@ int run_iss(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, 
   return 0;
 }
 
+template <typename R, int M>
+int run_ip2(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
+            double thr, int32_t* status, int B, int F, int pm, int pn, hipStream_t st) {
+  constexpr int GPW = WAVE / next_pow2_c(M * M);
+  const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
+  if (part)
+    hipLaunchKernelGGL((ip2_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
+                       1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, pm, pn);
+  else
+    hipLaunchKernelGGL((ip2_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, pm, pn);
+  ASSX_LAUNCH_CHECK(ctx, "ip2_group_kernel");
+  return 0;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -982,6 +1163,21 @@ int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int3
   });
 }
 
+int assx_ip2_update(assx_ctx* ctx, const void* U, void* W, double threshold, int32_t* status, int pair_m, int pair_n,
+                    int B, int M, int F, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, U && W, ASSX_E_NULL, "assx_ip2_update: NULL array");
+  ASSX_REQUIRE(ctx, pair_m >= 0 && pair_m < M && pair_n >= 0 && pair_n < M && pair_m != pair_n, ASSX_E_ARG,
+               "bad update pair (%d, %d) for %d sources", pair_m, pair_n, M);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    return run_ip2<R, MM>(ctx, U, nullptr, FlatPart{}, 1, W, nullptr, nullptr, threshold, status, B, F, pair_m, pair_n,
+                          st);
+  });
+}
+
 int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, int M, int F, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, 1);
   ASSX_REQUIRE(ctx, U && W && n_frames >= 1, ASSX_E_NULL, "assx_iss_update: NULL array / bad n_frames");
@@ -994,7 +1190,8 @@ int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, 
 }
 
 int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double domain, double eps,
-                             void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+                             unsigned source_mask, void* ws, int B, int M, int F, int T, int K, int dtype,
+                             void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_source_update: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
@@ -1027,7 +1224,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     }
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_kernel");
     hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
-                       st, (const R*)ws, (R*)Tb, B, MM, F, K, a.fp, (R)eps, p2);
+                       st, (const R*)ws, (R*)Tb, B, MM, F, K, a.fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
     // ---- activation (reduce over f; uses the new basis)
     a.fp = flat_act(B, F, T);
@@ -1044,14 +1241,15 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     }
     ASSX_LAUNCH_CHECK(ctx, "act_stream_kernel");
     hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
-                       (const R*)ws, (R*)V, B, MM, F, K, T, a.fp, (R)eps, p2);
+                       (const R*)ws, (R*)V, B, MM, F, K, T, a.fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
     return 0;
   });
 }
 
-int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W, const void* Tb, const void* V,
-                              double domain, double eps, double threshold, void* U_out, const void* C,
+int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n, const void* X, void* W,
+                              const void* Tb, const void* V, double domain, double eps, double threshold, void* U_out,
+                              const void* C,
                               double* power_bins, int32_t* status, void* ws, int B, int M, int F, int T, int K,
                               int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
@@ -1060,8 +1258,11 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W
   ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
   ASSX_REQUIRE(ctx, (C == nullptr) == (power_bins == nullptr), ASSX_E_ARG,
                "assx_ilrma_spatial_update: C and power_bins must be given together");
-  ASSX_REQUIRE(ctx, spatial == ASSX_SPATIAL_IP || spatial == ASSX_SPATIAL_ISS, ASSX_E_ARG, "bad spatial algorithm %d",
+  ASSX_REQUIRE(ctx, spatial >= ASSX_SPATIAL_IP && spatial <= ASSX_SPATIAL_IP2, ASSX_E_ARG, "bad spatial algorithm %d",
                spatial);
+  ASSX_REQUIRE(ctx, spatial != ASSX_SPATIAL_IP2 || (pair_m >= 0 && pair_m < M && pair_n >= 0 && pair_n < M &&
+                                                    pair_m != pair_n),
+               ASSX_E_ARG, "bad update pair (%d, %d) for %d sources", pair_m, pair_n, M);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1075,6 +1276,8 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W
       ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
     }
     if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, B, F, st);
+    if (spatial == ASSX_SPATIAL_IP2)
+      return run_ip2<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, threshold, status, B, F, pair_m, pair_n, st);
     return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, threshold, status, B, F, st);
   });
 }
@@ -1264,9 +1467,9 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
   });
 }
 
-int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W, const void* r, double eps,
-                               double threshold, void* U_out, int32_t* status, void* ws, int B, int M, int F, int T,
-                               int dtype, void* stream) {
+int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n, const void* X, void* W, const void* r,
+                               double eps, double threshold, void* U_out, int32_t* status, void* ws, int B, int M, int F,
+                               int T, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_spatial_update: NULL array");
   hipStream_t st = (hipStream_t)stream;
@@ -1282,6 +1485,11 @@ int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* 
       ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
     }
     if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, B, F, st);
+    if (spatial == ASSX_SPATIAL_IP2) {
+      if (!(pair_m >= 0 && pair_m < MM && pair_n >= 0 && pair_n < MM && pair_m != pair_n))
+        return fail(ctx, ASSX_E_ARG, "bad update pair (%d, %d) for %d sources", pair_m, pair_n, MM);
+      return run_ip2<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, threshold, status, B, F, pair_m, pair_n, st);
+    }
     return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, threshold, status, B, F, st);
   });
 }

@@ -511,13 +511,14 @@ __global__ void __launch_bounds__(64, MINW)
 template <typename R>
 __global__ void __launch_bounds__(256) basis_stream_finalize_kernel(const R* __restrict__ part, R* __restrict__ Tb,
                                                                    int B, int N, int F, int K, FlatPart fp, R eps,
-                                                                   PowSpec p2) {
+                                                                   PowSpec p2, unsigned src_mask) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * N * F * K;
   if (idx >= total) return;
   const int k = idx % K;
   const int f = (idx / K) % F;
   const int n = (idx / ((size_t)K * F)) % N;
+  if (!((src_mask >> n) & 1u)) return;  // pairwise source-model update: only the selected sources move
   const int b = idx / ((size_t)K * F * N);
   const long long j = (long long)b * F + f;
   const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
@@ -813,13 +814,14 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
 template <typename R>
 __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __restrict__ part, R* __restrict__ V, int B,
                                                                  int N, int F, int K, int T, FlatPart fp, R eps,
-                                                                 PowSpec p2) {
+                                                                 PowSpec p2, unsigned src_mask) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * N * K * T;
   if (idx >= total) return;
   const int t = idx % T;
   const int k = (idx / T) % K;
   const int n = (idx / ((size_t)T * K)) % N;
+  if (!((src_mask >> n) & 1u)) return;
   const int b = idx / ((size_t)T * K * N);
   const int TBk = (T + WAVE - 1) / WAVE;
   const long long j = (long long)b * TBk + t / WAVE;

@@ -76,13 +76,21 @@ class Engine:
         return W
 
     # ------------------------------------------------------------------ ILRMA
-    def ilrma_source_update(self, X, W, Tb, V, domain=2, eps=1e-12):
+    def ilrma_source_update(self, X, W, Tb, V, domain=2, eps=1e-12, sources=None):
+        """sources: None = all, or an iterable of source indices (pairwise update)."""
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
+        mask = (1 << M) - 1 if sources is None else sum(1 << int(n) for n in set(sources))
         self._check(L.assx_ilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
-                                               ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
+                                               mask, ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_source_update")
+
+    def ip2_update(self, U, W, pair, threshold=1e12, status=None):
+        B, F, N, M = (int(s) for s in W.shape)
+        self._check(L.assx_ip2_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), int(pair[0]),
+                                      int(pair[1]), B, M, F, self.prec.code, self._st()), "assx_ip2_update")
+        return W
 
     def iss_update(self, U, W, n_frames):
         B, F, N, M = (int(s) for s in W.shape)
@@ -91,12 +99,12 @@ class Engine:
         return W
 
     def ilrma_spatial_update(self, X, W, Tb, V, domain=2, eps=1e-12, threshold=1e12, status=None, U_out=None,
-                             C=None, power_bins=None, spatial=_lib.SPATIAL_IP):
+                             C=None, power_bins=None, spatial=_lib.SPATIAL_IP, pair=(0, 1)):
         """C (B,F,M,M) + power_bins (B,N,F) float64: also emit the per-bin power statistic of the updated filters."""
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_ilrma_spatial_update(self.ctx, int(spatial), ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
+        self._check(L.assx_ilrma_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
                                                 float(threshold), ptr(U_out), ptr(C), ptr(power_bins), ptr(status),
                                                 ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_spatial_update")
@@ -164,10 +172,10 @@ class Engine:
         return r, loss
 
     def auxiva_spatial_update(self, X, W, r, eps=1e-12, threshold=1e12, status=None, U_out=None,
-                              spatial=_lib.SPATIAL_IP):
+                              spatial=_lib.SPATIAL_IP, pair=(0, 1)):
         B, M, F, T = self._dims(X)
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_auxiva_spatial_update(self.ctx, int(spatial), ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
+        self._check(L.assx_auxiva_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
                                                  ptr(U_out), ptr(status), ptr(ws), B, M, F, T, self.prec.code,
                                                  self._st()), "assx_auxiva_spatial_update")
 

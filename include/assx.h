@@ -56,7 +56,7 @@ enum { ASSX_W_NONE = 0, ASSX_W_NT = 1, ASSX_W_NFT = 2 };
 enum { ASSX_IVA_LAPLACE = 0, ASSX_IVA_GAUSS = 1 };
 
 /* spatial update algorithm (algorithm_spatial of the reference classes) */
-enum { ASSX_SPATIAL_IP = 0, ASSX_SPATIAL_ISS = 1 };
+enum { ASSX_SPATIAL_IP = 0, ASSX_SPATIAL_ISS = 1, ASSX_SPATIAL_IP2 = 2 };
 
 /* NMF divergence / algorithm */
 enum { ASSX_NMF_EUC = 0, ASSX_NMF_KL = 1, ASSX_NMF_IS_MM = 2, ASSX_NMF_IS_ME = 3 };
@@ -98,24 +98,31 @@ int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int3
  * expressed on the weighted covariances U (B,N,F,M,M) instead of on Y:  for n: v_s = w_s U_s w_n^H / w_n U_s w_n^H
  * (s != n), v_n = 1 - 1/sqrt(n_frames * w_n U_n w_n^H);  W[s,:] -= v_s W[n,:]. */
 int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, int M, int F, int dtype, void* stream);
+/* IP2 / pairwise update of rows (pair_m, pair_n), in place on W (src/bss/ilrma.py:599-631, src/bss/iva.py:567-597):
+ * P_x = (W U_x)^{-1}[e_m e_n], V_x = P_x^H U_x P_x, generalised 2x2 eigenproblem V_n^{-1} V_m, eigenvectors by descending
+ * eigenvalue (zgeev phase convention), cond guard per row. */
+int assx_ip2_update(assx_ctx* ctx, const void* U, void* W, double threshold, int32_t* status, int pair_m, int pair_n,
+                    int B, int M, int F, int dtype, void* stream);
 
 /* ---- (a2) ILRMA source model ----------------------------------------------------------- */
 /* GaussILRMA.update_source_model_basic, non-partitioned (src/bss/ilrma.py:356-366, 409-430):
  * P = |W x|^2 recomputed on the fly; IS-NMF (mm) basis update, then activation update with
- * the new basis.  Tb, V updated in place. */
+ * the new basis.  Tb, V updated in place.  source_mask: bit n set = source n is updated (all ones = every source;
+ * two bits = update_source_model_pairwise, src/bss/ilrma.py:432-481). */
 int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V,
-                             double domain, double eps, void* ws,
+                             double domain, double eps, unsigned source_mask, void* ws,
                              int B, int M, int F, int T, int K, int dtype, void* stream);
 
 /* ---- (a4+a5) ILRMA spatial model ------------------------------------------------------- */
 /* GaussILRMA.update_spatial_model_ip (src/bss/ilrma.py:483-535): r = max((Tb V)^(2/domain), eps)
  * rebuilt in-kernel from Tb, V (never materialised), covariance, then the IP sweep (spatial = ASSX_SPATIAL_IP) or
- * the ISS sweep (ASSX_SPATIAL_ISS, src/bss/ilrma.py:537-564).  W in place.
+ * the ISS sweep (ASSX_SPATIAL_ISS, src/bss/ilrma.py:537-564) or the pairwise update of rows (pair_m, pair_n)
+ * (ASSX_SPATIAL_IP2, src/bss/ilrma.py:566-633; pair_* ignored otherwise).  W in place.
  * U_out: optional (B,N,F,M,M) complex receiving the covariance; NULL = not materialised.
  * C, power_bins: optional pair.  C (B,F,M,M) = plain covariance of X; power_bins (B,N,F) float64 receives
  * w_n^H C_f w_n of the UPDATED filters, the per-bin share of the power-normalisation statistic
  * (src/bss/ilrma.py:298-306) -- emitted by the IP kernel so normalisation needs no further pass or launch. */
-int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W, const void* Tb, const void* V,
+int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n, const void* X, void* W, const void* Tb, const void* V,
                               double domain, double eps, double threshold, void* U_out,
                               const void* C, double* power_bins,
                               int32_t* status, void* ws,
@@ -161,7 +168,7 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
                         int B, int M, int F, int T, int dtype, void* stream);
 /* update_once_ip / update_once_iss given r (src/bss/iva.py:493-518, 525-542, 726-751, 758-775): covariance with
  * (N,T) weights + IP or ISS sweep. */
-int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, const void* X, void* W, const void* r, double eps, double threshold,
+int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n, const void* X, void* W, const void* r, double eps, double threshold,
                                void* U_out, int32_t* status, void* ws,
                                int B, int M, int F, int T, int dtype, void* stream);
 

@@ -332,6 +332,40 @@ def gen_iss():
              T_final=model.basis, V_final=model.activation, **snap.data)
 
 
+# ----------------------------------------------------------------------------
+# G6b: IP2 / pairwise spatial updates
+# ----------------------------------------------------------------------------
+def gen_ip2():
+    for M in (2, 3, 4):
+        F, T = 17, 48
+        X = convolutive_mixture(M, F, T, seed=700 + M)
+        snap = Snapshot((1, 2, 6), with_nmf=False)
+        model = AuxLaplaceIVA(algorithm_spatial="IP2", callbacks=snap)
+        Y = model(X, iteration=6)
+        save("ip2_auxlaplace_m%d" % M, X=X, iters=np.asarray((1, 2, 6)), loss=np.asarray(model.loss), Y_out=Y,
+             W_final=model.demix_filter, update_pair=np.asarray(model.update_pair), **snap.data)
+    seed = 750
+    for M, K, normalize, domain, alg in [(2, 2, "power", 2, "IP2"), (4, 4, "power", 2, "pairwise"),
+                                         (3, 3, "projection-back", 2, "IP2"), (4, 2, False, 1, "IP2")]:
+        seed += 1
+        F, T = 17, 48
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        T0 = np.random.rand(M, F, K)
+        V0 = np.random.rand(M, K, T)
+        np.random.set_state(state)
+        snap = Snapshot((1, 2, 6), with_nmf=True)
+        model = GaussILRMA(n_basis=K, domain=domain, normalize=normalize, algorithm_spatial=alg, callbacks=snap)
+        Y = model(X, iteration=6)
+        tag = "m%d_k%d_%s_d%s" % (M, K, {"power": "pow", "projection-back": "pb", False: "none"}[normalize],
+                                   str(domain).replace(".", ""))
+        save("ip2_ilrma_" + tag, X=X, M=M, K=K, domain=domain, normalize=np.array(str(normalize)), seed=seed, T0=T0,
+             V0=V0, alg=np.array(alg), iters=np.asarray((1, 2, 6)), loss=np.asarray(model.loss), Y_out=Y,
+             W_final=model.demix_filter, T_final=model.basis, V_final=model.activation,
+             update_pair=np.asarray(model.update_pair), **snap.data)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
         for name in sys.argv[1:]:

@@ -98,8 +98,7 @@ def test_gauss_ilrma_api_surface():
         GaussILRMA(partitioning=True)(X, iteration=1)
     with pytest.warns(UserWarning):
         GaussILRMA(algorithm_spatial="ISS")
-    with pytest.raises(NotImplementedError):
-        GaussILRMA(algorithm_spatial="IP2")(X, iteration=1)
+    assert GaussILRMA(algorithm_spatial="IP2").update_pair is None
     with pytest.raises(AssertionError):
         GaussILRMA(algorithm_spatial="IPA")
     with pytest.raises(AssertionError):
@@ -204,8 +203,9 @@ def test_auxiva_options_and_edges(kind):
     m = cls(algorithm_spatial="IP1", reference_id=2, recordable_loss=False)
     Y = m(g["X"], iteration=3)
     assert rel_err(Y, g["Y_ref2"]) < 1e-9 and m.loss is None
-    with pytest.raises(NotImplementedError):
-        cls(algorithm_spatial="IP2")(g["X"], iteration=1)
+    if kind == "gauss":
+        with pytest.raises(NotImplementedError):
+            cls(algorithm_spatial="IP2")(g["X"], iteration=1)
     with pytest.raises(ValueError):
         cls(algorithm_spatial="bogus")
     g = load_golden("edge_zeros_aux%s" % kind)
@@ -315,3 +315,39 @@ def test_gauss_ilrma_iss_golden(name):
             assert rel_err(snap.data["%s_%d" % (key, k)], g["%s_%d" % (key, k)]) < 1e-8, (key, k)
     np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
     assert rel_err(Y, g["Y_out"]) < 1e-8 and rel_err(model.demix_filter, g["W_final"]) < 1e-8
+
+
+IP2_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ip2_ilrma_*.npz")))
+
+
+@pytest.mark.parametrize("M", [2, 3, 4])
+def test_auxlaplace_ip2_golden(M):
+    from audio_source_separation_amd.bss.iva import AuxLaplaceIVA
+    g = load_golden("ip2_auxlaplace_m%d" % M)
+    iters = [int(k) for k in g["iters"]]
+    snap = Snap(iters, nmf=False)
+    model = AuxLaplaceIVA(algorithm_spatial="IP2", callbacks=snap)
+    Y = model(g["X"], iteration=max(iters))
+    assert tuple(model.update_pair) == tuple(int(v) for v in g["update_pair"])  # index bookkeeping: bit-exact
+    for k in iters:
+        assert rel_err(snap.data["W_%d" % k], g["W_%d" % k]) < 1e-8, k
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-8
+
+
+@pytest.mark.parametrize("name", IP2_ILRMA)
+def test_gauss_ilrma_ip2_golden(name):
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    snap = Snap(iters, nmf=True)
+    np.random.seed(int(g["seed"]))
+    model = GaussILRMA(n_basis=int(g["K"]), domain=float(g["domain"]), normalize=_norm(g),
+                       algorithm_spatial=str(g["alg"]), callbacks=snap)
+    Y = model(g["X"], iteration=max(iters))
+    assert tuple(model.update_pair) == tuple(int(v) for v in g["update_pair"])
+    for k in iters:
+        for key in ("W", "T", "V"):
+            assert rel_err(snap.data["%s_%d" % (key, k)], g["%s_%d" % (key, k)]) < 1e-8, (key, k)
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-8

@@ -310,3 +310,23 @@ def test_iss_update(eng, M, F, T):
     eng.iss_update(dev_c(eng, U[None]), Wd, T)
     Y = orc.iss_update(orc.separate(X, W), R)
     assert rel_err(orc.separate(X, host(Wd)[0]), Y) < tol(eng, 1e-10, 2e-3)
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES[:3])
+def test_ip2_update(eng, M, F, T):
+    """Pairwise update (assx_ip2_update) vs the oracle restatement (np.linalg.eig, argsort, parallel_sort)."""
+    X, W = mixture(M, F, T, 90), rand_filters(M, F, 91)
+    R = np.random.default_rng(92).random((M, T)) + 0.05
+    U = orc.weighted_covariance(X, R)
+    for pair in ((0, 1), (M - 1, 0)):
+        Wd = dev_c(eng, W[None])
+        st = eng.new_status(1)
+        eng.ip2_update(dev_c(eng, U[None]), Wd, pair, 1e12, st)
+        Wref, cm, cn = orc.ip2_update(W.copy(), U[pair[0]], U[pair[1]], pair[0], pair[1])
+        assert cm.all() and cn.all() and int(st.item()) == 0
+        got = host(Wd)[0]
+        # rows other than the pair are untouched, bit for bit
+        others = [n for n in range(M) if n not in pair]
+        stored = host(dev_c(eng, W[None]))[0]  # W as the kernel saw it (rounded to the storage dtype)
+        assert np.array_equal(got[:, others], stored[:, others])
+        assert rel_err(got, Wref) < tol(eng, 1e-9, 5e-3)

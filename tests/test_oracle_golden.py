@@ -200,3 +200,32 @@ def test_iss_ilrma(name):
         assert rel_err(W, g["W_%d" % k]) < 1e-9 and rel_err(T, g["T_%d" % k]) < 1e-9 and rel_err(V, g["V_%d" % k]) < 1e-9
     np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
     assert rel_err(res["Y"], g["Y_out"]) < 1e-9 and rel_err(res["W"], g["W_final"]) < 1e-9
+
+
+IP2_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ip2_ilrma_*.npz")))
+
+
+@pytest.mark.parametrize("M", [2, 3, 4])
+def test_ip2_auxlaplace(M):
+    g = load_golden("ip2_auxlaplace_m%d" % M)
+    iters = [int(k) for k in g["iters"]]
+    res = orc.auxlaplace_ip2(g["X"], max(iters), snapshots=iters)
+    for k in iters:
+        assert rel_err(res["snapshots"][k], g["W_%d" % k]) < 1e-9, k
+    np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(res["Y"], g["Y_out"]) < 1e-9
+    assert tuple(res["update_pair"]) == tuple(int(v) for v in g["update_pair"])  # integer bookkeeping: bit-exact
+
+
+@pytest.mark.parametrize("name", IP2_ILRMA)
+def test_ip2_ilrma(name):
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    res = orc.gauss_ilrma_ip2(g["X"], max(iters), g["T0"], g["V0"], domain=float(g["domain"]), normalize=_norm(g),
+                              snapshots=iters)
+    for k in iters:
+        W, T, V = res["snapshots"][k]
+        assert rel_err(W, g["W_%d" % k]) < 1e-9 and rel_err(T, g["T_%d" % k]) < 1e-9 and rel_err(V, g["V_%d" % k]) < 1e-9
+    np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(res["Y"], g["Y_out"]) < 1e-9
+    assert tuple(res["update_pair"]) == tuple(int(v) for v in g["update_pair"])
