@@ -11,8 +11,9 @@ the reference, `demix_filter` therefore stays available during the loop instead 
 
 `algorithm_spatial in {'IP2', 'pairwise'}` (ilrma.py:432-481, 566-646) is on the HIP path as well.
 
-Not yet on the HIP path: `partitioning=True` -- raises NotImplementedError at call
-time instead of silently falling back to the CPU.
+`partitioning=True` (shared bases + latent variables, ilrma.py:79-95, 368-408, 313-320; domain 2 only as in the
+reference) is on the HIP path: the streaming kernels run on the per-source expansion Z[n,k] T[f,k] of the shared model
+and small kernels fold their partial sums into the Z / T / V updates (csrc/assx_partition.hpp).
 """
 import warnings
 
@@ -36,6 +37,7 @@ class ILRMAbase(DeviceState):
     demix_filter = DeviceArray("W", complex_=True)
     basis = DeviceArray("T", complex_=False)
     activation = DeviceArray("V", complex_=False)
+    latent = DeviceArray("Z", complex_=False)
 
     def __init__(self, n_basis=10, partitioning=False, normalize=True, algorithm_spatial='IP', callbacks=None,
                  recordable_loss=True, eps=EPS, *, dtype='float64', device=None):
@@ -69,8 +71,6 @@ class ILRMAbase(DeviceState):
 
     # ------------------------------------------------------------------ device plumbing
     def _require_supported(self):
-        if self.partitioning:
-            raise NotImplementedError("partitioning=True is not on the HIP path yet (no CPU fallback is provided).")
         if self.algorithm_spatial not in ('IP', 'IP1', 'ISS', 'IP2', 'pairwise'):
             raise NotImplementedError("algorithm_spatial='{}' is not on the HIP path (no CPU fallback is provided).".format(self.algorithm_spatial))
 
@@ -114,10 +114,18 @@ class ILRMAbase(DeviceState):
             self._set_dev("W", W.repeat(B, n_bins, 1, 1).contiguous())
         # else: the existing filter (previous call or user-supplied) is the warm start (ilrma.py:70-72)
 
-        shape_T = (n_sources, n_bins, n_basis)
-        shape_V = (n_sources, n_basis, n_frames)
-        if self._batched:
-            shape_T, shape_V = (B,) + shape_T, (B,) + shape_V
+        lead = (B,) if self._batched else ()
+        if self.partitioning:
+            # latent, then basis, then activation from the global NumPy RNG (ilrma.py:78-95)
+            if not hasattr(self, 'latent'):
+                variance_latent = 1e-2
+                Z = np.random.rand(*(lead + (n_sources, n_basis))) * variance_latent + 1 / n_sources
+                Zsum = Z.sum(axis=-2, keepdims=True)
+                Zsum[Zsum < self.eps] = self.eps
+                self.latent = Z / Zsum
+            shape_T, shape_V = lead + (n_bins, n_basis), lead + (n_basis, n_frames)
+        else:
+            shape_T, shape_V = lead + (n_sources, n_bins, n_basis), lead + (n_sources, n_basis, n_frames)
         # global NumPy RNG, basis first then activation, exactly as ilrma.py:97-104
         if not hasattr(self, 'basis'):
             self.basis = np.random.rand(*shape_T)
@@ -138,6 +146,24 @@ class ILRMAbase(DeviceState):
     @property
     def _Vd(self):
         return self._dev("V", False)
+
+    @property
+    def _Zd(self):
+        return self._dev("Z", False)
+
+    def _model(self):
+        """(basis, activation) device tensors in the per-source layout (B,N,F,K) / (B,N,K,T) every kernel takes.
+        With a partitioning function this is the expansion Z[n,k] T[f,k] / V[k,t] of the shared model, rebuilt on
+        every use (a few hundred KB) so host-side assignments to latent / basis / activation are always honoured."""
+        if not self.partitioning:
+            return self._Td, self._Vd
+        eng = self._engine
+        B, N, F, T, K = self._X.shape[0], self.n_sources, self.n_bins, self.n_frames, int(self._Td.shape[-1])
+        if getattr(self, "_Teff", None) is None or tuple(self._Teff.shape) != (B, N, F, K) \
+                or tuple(self._Veff.shape) != (B, N, K, T):
+            self._Teff, self._Veff = eng.empty((B, N, F, K)), eng.empty((B, N, K, T))
+        eng.ilrma_expand_partitioned(self._Zd, self._Td, self._Vd, self._Teff, self._Veff)
+        return self._Teff, self._Veff
 
     # ------------------------------------------------------------------ reference API
     @property
@@ -234,6 +260,9 @@ class GaussILRMA(ILRMAbase):
         self.threshold = threshold
         self.power_statistic = power_statistic
 
+        if self.partitioning:
+            assert domain == 2, "Not support domain = {}".format(domain)  # ilrma.py:369, 490
+
         if self.algorithm_spatial == 'ISS':
             warnings.warn("in progress", UserWarning)  # as the reference does (ilrma.py:197-198)
 
@@ -284,6 +313,9 @@ class GaussILRMA(ILRMAbase):
 
     def _reset(self, **kwargs):
         super()._reset(**kwargs)
+        if self.partitioning:
+            assert self.domain == 2, "Not support domain = {}".format(self.domain)
+        self._Teff = self._Veff = None
         self._C = None
         self._pbins = None
         self._power = self._engine.empty((self._X.shape[0], self.n_sources))
@@ -309,13 +341,20 @@ class GaussILRMA(ILRMAbase):
 
         if self.normalize:
             if self.normalize == 'power':
-                if self.power_statistic == 'covariance':
+                if self.partitioning:
+                    # Z / a^2 renormalised over sources, T takes the column sums (ilrma.py:313-320)
+                    eng.ilrma_normalize_power_bins_partitioned(self._Wd, self._Zd, self._Td, self._power_bins(),
+                                                               self.n_frames, eps=eps)
+                    self._touch("Z")
+                elif self.power_statistic == 'covariance':
                     # the IP kernel already emitted w_n^H C_f w_n per bin (update_spatial_model)
                     eng.ilrma_normalize_power_bins(self._Wd, self._Td, self._pbins, domain=domain, eps=eps)
                 else:
                     eng.demix_power(self._X, self._Wd, out=self._power)
                     eng.ilrma_normalize_power(self._Wd, self._Td, self._power, domain=domain, eps=eps)
             elif self.normalize == 'projection-back':
+                if self.partitioning:
+                    raise NotImplementedError("Not support 'projection-back' based normalization for partitioninig function. Choose 'power' based normalization.")
                 scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
                 eng.ilrma_normalize_pb(self._Wd, self._Td, scale, domain=domain)
             else:
@@ -331,9 +370,19 @@ class GaussILRMA(ILRMAbase):
             if self.partitioning:
                 raise NotImplementedError("Not support partitioning function.")
             sources = self.update_pair
+        if self.partitioning:
+            Teff, Veff = self._model()
+            self._engine.ilrma_source_update_partitioned(self._X, self._Wd, self._Zd, self._Td, self._Vd, Teff, Veff,
+                                                         eps=self.eps)
+            self._touch("Z", "T", "V")
+            return
         self._engine.ilrma_source_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
                                          sources=sources)
         self._touch("T", "V")
+
+    def _power_bins(self):
+        """Per-bin power statistic w_n^H C_f w_n of the current filters (emitted by the spatial update)."""
+        return self._pbins
 
     def _select_update_pair(self):
         """(0,1), (1,2), ..., (N-1,0)   (ilrma.py:635-646)."""
@@ -352,7 +401,7 @@ class GaussILRMA(ILRMAbase):
         """Weighted covariance + iterative projection (ilrma.py:483-535) or ISS sweep (ilrma.py:537-564)."""
         eng = self._engine
         C = pbins = None
-        if self.normalize == 'power' and self.power_statistic == 'covariance':
+        if self.normalize == 'power' and (self.power_statistic == 'covariance' or self.partitioning):
             if self._C is None:  # plain covariance of X: constant over the iterations, one pass per call
                 B, M, F, _ = self._X.shape
                 self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
@@ -363,7 +412,8 @@ class GaussILRMA(ILRMAbase):
             spatial = _lib.SPATIAL_ISS
         elif self.algorithm_spatial in ['pairwise', 'IP2']:
             spatial, pair = _lib.SPATIAL_IP2, self.update_pair
-        eng.ilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
+        Tb, V = self._model()
+        eng.ilrma_spatial_update(self._X, self._Wd, Tb, V, domain=self.domain, eps=self.eps,
                                  threshold=self.threshold, status=self._status, C=C, power_bins=pbins, spatial=spatial,
                                  pair=pair)
         self._touch("W")
@@ -371,7 +421,8 @@ class GaussILRMA(ILRMAbase):
 
     def _record_loss(self):
         """Append the current loss without a host sync (the value stays in HBM until `loss` is read)."""
-        loss = self._engine.ilrma_loss(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps)
+        Tb, V = self._model()
+        loss = self._engine.ilrma_loss(self._X, self._Wd, Tb, V, domain=self.domain, eps=self.eps)
         if isinstance(self.loss, LazyLossList):
             self.loss.append_device(loss, self._batched)
         else:  # a user replaced `loss` by a plain list
@@ -379,7 +430,8 @@ class GaussILRMA(ILRMAbase):
 
     def compute_negative_loglikelihood(self):
         """sum(P/R + log R) - 2 T sum_f log|det W_f| (ilrma.py:648-677).  Syncs to return a Python float."""
-        loss = self._engine.ilrma_loss(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps)
+        Tb, V = self._model()
+        loss = self._engine.ilrma_loss(self._X, self._Wd, Tb, V, domain=self.domain, eps=self.eps)
         self._check_status()
         if self._batched:
             return to_numpy(loss, np.float64)

@@ -17,6 +17,7 @@
 #include "assx_common.hpp"
 #include "assx_small_linalg.hpp"
 #include "assx_stream.hpp"
+#include "assx_partition.hpp"
 
 using namespace assx;
 
@@ -1107,6 +1108,54 @@ int run_ip2(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, 
   return 0;
 }
 
+// source-model partial sums (reduce over t): part[g][slot][n][k][num|den]
+template <typename R, int MM>
+int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
+                      double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out) {
+  NmfArgs<R> a;
+  a.d = Dims{B, F, T, K};
+  a.eps = (R)eps;
+  a.p1 = make_pow((domain + 2.0) / domain);
+  a.fp = flat_basis(B, F, T);
+  *fp_out = a.fp;
+  const bool d2 = a.p1.mode == POW_SQUARE, k4 = K <= KU;
+  const dim3 gb(a.fp.G), bb(64);
+#define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
+  hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, (const Cx<R>*)X, \
+                     (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
+  if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
+  else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
+  else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
+  else BASIS_LAUNCH(false, false, 2, 1, 1);
+#undef BASIS_LAUNCH
+  ASSX_LAUNCH_CHECK(ctx, "basis_stream_kernel");
+  return 0;
+}
+
+// source-model partial sums (reduce over f): part[g][slot][n][k][num|den][64 frames]
+template <typename R, int MM>
+int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
+                    double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out) {
+  NmfArgs<R> a;
+  a.d = Dims{B, F, T, K};
+  a.eps = (R)eps;
+  a.p1 = make_pow((domain + 2.0) / domain);
+  a.fp = flat_act(B, F, T);
+  *fp_out = a.fp;
+  const bool d2 = a.p1.mode == POW_SQUARE, k4 = K <= KU;
+  const dim3 ga(a.fp.G), ba(64 * ACT_NH);
+#define ACT_LAUNCH(K4V, D2V, DXV, MW) \
+  hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
+                     (const R*)Tb, (const R*)V, (R*)ws, a)
+  if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
+  else if (k4) ACT_LAUNCH(true, false, 2, 1);
+  else if (d2) ACT_LAUNCH(false, true, 4, 1);
+  else ACT_LAUNCH(false, false, 2, 1);
+#undef ACT_LAUNCH
+  ASSX_LAUNCH_CHECK(ctx, "act_stream_kernel");
+  return 0;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1200,49 +1249,101 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    const PowSpec p1 = make_pow((domain + 2.0) / domain), p2 = make_pow(domain / (domain + 2.0));
-    NmfArgs<R> a;
-    a.d = Dims{B, F, T, K};
-    a.eps = (R)eps;
-    a.p1 = p1;
-    const bool d2 = p1.mode == POW_SQUARE;
-    const bool k4 = K <= KU;
-    const Cx<R>* Xp = (const Cx<R>*)X;
-    const Cx<R>* Wp = (const Cx<R>*)W;
-    // ---- basis (reduce over t)
-    a.fp = flat_basis(B, F, T);
-    {
-      const dim3 gb(a.fp.G), bb(64);
-#define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
-  hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, Xp, Wp, (const R*)Tb, \
-                     (const R*)V, (R*)ws, a)
-      if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
-      else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
-      else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
-      else BASIS_LAUNCH(false, false, 2, 1, 1);
-#undef BASIS_LAUNCH
-    }
-    ASSX_LAUNCH_CHECK(ctx, "basis_stream_kernel");
+    const PowSpec p2 = make_pow(domain / (domain + 2.0));
+    FlatPart fp;
+    int rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp);
+    if (rc) return rc;
     hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
-                       st, (const R*)ws, (R*)Tb, B, MM, F, K, a.fp, (R)eps, p2, source_mask);
+                       st, (const R*)ws, (R*)Tb, B, MM, F, K, fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
-    // ---- activation (reduce over f; uses the new basis)
-    a.fp = flat_act(B, F, T);
-    {
-      const dim3 ga(a.fp.G), ba(64 * ACT_NH);
-#define ACT_LAUNCH(K4V, D2V, DXV, MW) \
-  hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, Xp, Wp, (const R*)Tb, \
-                     (const R*)V, (R*)ws, a)
-      if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
-      else if (k4) ACT_LAUNCH(true, false, 2, 1);
-      else if (d2) ACT_LAUNCH(false, true, 4, 1);
-      else ACT_LAUNCH(false, false, 2, 1);
-#undef ACT_LAUNCH
-    }
-    ASSX_LAUNCH_CHECK(ctx, "act_stream_kernel");
+    rc = run_act_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp);  // uses the new basis
+    if (rc) return rc;
     hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
-                       (const R*)ws, (R*)V, B, MM, F, K, T, a.fp, (R)eps, p2, source_mask);
+                       (const R*)ws, (R*)V, B, MM, F, K, T, fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
+    return 0;
+  });
+}
+
+int assx_ilrma_expand_partitioned(assx_ctx* ctx, const void* Z, const void* Tb, const void* V, void* Teff, void* Veff,
+                                  int B, int M, int F, int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, Z && Tb && V && (Teff || Veff), ASSX_E_NULL, "assx_ilrma_expand_partitioned: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t total = (size_t)B * M * F * K + (size_t)B * M * K * T;
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((part_expand_kernel<double>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const double*)Z,
+                       (const double*)Tb, (const double*)V, (double*)Teff, (double*)Veff, B, M, F, K, T);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((part_expand_kernel<float>), dim3(blocks_for(total, 256)), dim3(256), 0, st, (const float*)Z,
+                       (const float*)Tb, (const float*)V, (float*)Teff, (float*)Veff, B, M, F, K, T);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "part_expand_kernel");
+  return 0;
+}
+
+int assx_ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W, void* Z, void* Tb, void* V,
+                                         void* Teff, void* Veff, double eps, void* ws, int B, int M, int F, int T,
+                                         int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Z && Tb && V && Teff && Veff && ws, ASSX_E_NULL,
+               "assx_ilrma_source_update_partitioned: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const size_t nT = (size_t)B * MM * F * K, nV = (size_t)B * MM * K * T;
+    auto expand = [&](bool with_v) -> int {
+      hipLaunchKernelGGL((part_expand_kernel<R>), dim3(blocks_for(with_v ? nT + nV : nT, 256)), dim3(256), 0, st,
+                         (const R*)Z, (const R*)Tb, (const R*)V, (R*)Teff, with_v ? (R*)Veff : (R*)nullptr, B, MM, F,
+                         K, T);
+      ASSX_LAUNCH_CHECK(ctx, "part_expand_kernel");
+      return 0;
+    };
+    FlatPart fp;
+    int rc;
+    // ---- latent variables (ilrma.py:368-387)
+    if ((rc = expand(true))) return rc;
+    if ((rc = run_basis_partial<R, MM>(ctx, X, W, Teff, Veff, 2.0, eps, ws, B, F, T, K, st, &fp))) return rc;
+    hipLaunchKernelGGL((part_latent_kernel<R, MM>), dim3(K, B), dim3(256), 0, st, (const R*)ws, (const R*)Tb, (R*)Z, F,
+                       K, fp, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_latent_kernel");
+    // ---- bases (ilrma.py:389-397)
+    if ((rc = expand(false))) return rc;
+    if ((rc = run_basis_partial<R, MM>(ctx, X, W, Teff, Veff, 2.0, eps, ws, B, F, T, K, st, &fp))) return rc;
+    hipLaunchKernelGGL((part_basis_kernel<R>), dim3(blocks_for((size_t)B * F * K, 256)), dim3(256), 0, st,
+                       (const R*)ws, (const R*)Z, (R*)Tb, B, MM, F, K, fp, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_basis_kernel");
+    // ---- activations (ilrma.py:399-408)
+    if ((rc = expand(false))) return rc;
+    if ((rc = run_act_partial<R, MM>(ctx, X, W, Teff, Veff, 2.0, eps, ws, B, F, T, K, st, &fp))) return rc;
+    hipLaunchKernelGGL((part_act_kernel<R>), dim3(blocks_for((size_t)B * K * T, 256)), dim3(256), 0, st, (const R*)ws,
+                       (R*)V, B, MM, F, K, T, fp, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_act_kernel");
+    return expand(true);  // leave (Teff, Veff) consistent with the updated (Z, T, V)
+  });
+}
+
+int assx_ilrma_normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins,
+                                                double eps, void* ws, int B, int M, int F, int K, int dtype,
+                                                void* stream) {
+  CHECK_COMMON(ctx, B, M, F, 1);
+  ASSX_REQUIRE(ctx, W && Z && Tb && power_bins && ws, ASSX_E_NULL,
+               "assx_ilrma_normalize_power_bins_partitioned: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const size_t per_b = (size_t)F * MM * MM + (size_t)F * K;
+    hipLaunchKernelGGL((part_normalize_power_kernel<R, MM>), dim3(blocks_for(per_b, 256), B), dim3(256),
+                       (size_t)K * sizeof(R), st, (Cx<R>*)W, (R*)ws, (const R*)Z, (R*)Tb, power_bins, F, K, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_normalize_power_kernel");
+    hipError_t e = hipMemcpyAsync(Z, ws, (size_t)B * MM * K * sizeof(R), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(ctx, (int)e, "hipMemcpyAsync(Z): %s", hipGetErrorString(e));
     return 0;
   });
 }

@@ -8,7 +8,7 @@ pids=()
 for src in assx_api assx_bss assx_nmf; do
   stale=0
   [ -f "$src.o" ] || stale=1
-  for dep in "$src.hip" assx_common.hpp assx_small_linalg.hpp assx_stream.hpp assx_nmf_mfma.hpp ../../include/assx.h build.sh; do
+  for dep in "$src.hip" *.hpp ../../include/assx.h build.sh; do
     [ "$dep" -nt "$src.o" ] && stale=1
   done
   if [ "$stale" = 1 ]; then

@@ -86,6 +86,33 @@ class Engine:
                                                mask, ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_source_update")
 
+    # ---- partitioning function (shared bases + latent variables), domain 2
+    def ilrma_expand_partitioned(self, Z, Tb, V, Teff, Veff):
+        """Teff (B,N,F,K) = Z[n,k] Tb[f,k], Veff (B,N,K,T) = V[k,t]; either output may be None."""
+        B, N, K = (int(s) for s in Z.shape)
+        F, T = int(Tb.shape[1]), int(V.shape[2])
+        self._check(L.assx_ilrma_expand_partitioned(self.ctx, ptr(Z), ptr(Tb), ptr(V), ptr(Teff), ptr(Veff), B, N, F,
+                                                    T, K, self.prec.code, self._st()),
+                    "assx_ilrma_expand_partitioned")
+
+    def ilrma_source_update_partitioned(self, X, W, Z, Tb, V, Teff, Veff, eps=1e-12):
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_ilrma_source_update_partitioned(self.ctx, ptr(X), ptr(W), ptr(Z), ptr(Tb), ptr(V),
+                                                           ptr(Teff), ptr(Veff), float(eps), ptr(ws), B, M, F, T, K,
+                                                           self.prec.code, self._st()),
+                    "assx_ilrma_source_update_partitioned")
+
+    def ilrma_normalize_power_bins_partitioned(self, W, Z, Tb, power_bins, n_frames, eps=1e-12):
+        B, F, N, M = (int(s) for s in W.shape)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, int(n_frames), K)
+        self._check(L.assx_ilrma_normalize_power_bins_partitioned(self.ctx, ptr(W), ptr(Z), ptr(Tb), ptr(power_bins),
+                                                                  float(eps), ptr(ws), B, M, F, K, self.prec.code,
+                                                                  self._st()),
+                    "assx_ilrma_normalize_power_bins_partitioned")
+
     def ip2_update(self, U, W, pair, threshold=1e12, status=None):
         B, F, N, M = (int(s) for s in W.shape)
         self._check(L.assx_ip2_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), int(pair[0]),

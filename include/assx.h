@@ -113,6 +113,25 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
                              double domain, double eps, unsigned source_mask, void* ws,
                              int B, int M, int F, int T, int K, int dtype, void* stream);
 
+/* ---- (f1) partitioning function: shared bases Tb (B,F,K), activations V (B,K,T), latent Z (B,N,K) ----------
+ * GaussILRMA(partitioning=True), domain == 2 (src/bss/ilrma.py:79-95 init, 368-408 updates, 490-495 variance).
+ * The model enters every other entry point through its per-source expansion
+ *     Teff (B,N,F,K) = Z[n,k] Tb[f,k],   Veff (B,N,K,T) = V[k,t]
+ * (pass Teff/Veff as Tb/V to assx_ilrma_spatial_update and assx_ilrma_loss).  Either output may be NULL. */
+int assx_ilrma_expand_partitioned(assx_ctx* ctx, const void* Z, const void* Tb, const void* V, void* Teff, void* Veff,
+                                  int B, int M, int F, int T, int K, int dtype, void* stream);
+/* update_source_model_basic, partitioning branch (src/bss/ilrma.py:368-408): Z (then Z /= Z.sum(axis=0)), Tb, V in
+ * place, in that order, each from the model as updated so far.  Teff/Veff are caller-owned scratch of the shapes above
+ * and hold the expansion of the UPDATED model on return. */
+int assx_ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W, void* Z, void* Tb, void* V,
+                                         void* Teff, void* Veff, double eps, void* ws,
+                                         int B, int M, int F, int T, int K, int dtype, void* stream);
+/* 'power' normalisation with latent variables (src/bss/ilrma.py:313-320): W[:,n,:] /= a_n; Z' = Z / a_n^2;
+ * Tb *= sum_n Z'; Z = Z' / sum_n Z'.  power_bins as for assx_ilrma_normalize_power_bins. */
+int assx_ilrma_normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins,
+                                                double eps, void* ws, int B, int M, int F, int K, int dtype,
+                                                void* stream);
+
 /* ---- (a4+a5) ILRMA spatial model ------------------------------------------------------- */
 /* GaussILRMA.update_spatial_model_ip (src/bss/ilrma.py:483-535): r = max((Tb V)^(2/domain), eps)
  * rebuilt in-kernel from Tb, V (never materialised), covariance, then the IP sweep (spatial = ASSX_SPATIAL_IP) or

@@ -366,6 +366,40 @@ def gen_ip2():
              update_pair=np.asarray(model.update_pair), **snap.data)
 
 
+# ----------------------------------------------------------------------------
+# G6c: partitioning function (shared bases + latent Z)   (ilrma.py:79-95, 368-408, 313-320)
+# ----------------------------------------------------------------------------
+def gen_part():
+    seed = 800
+    for M, K, normalize, alg in [(2, 3, "power", "IP"), (3, 4, "power", "IP"), (4, 4, False, "IP"), (3, 3, "power", "ISS")]:
+        seed += 1
+        F, T = 17, 48
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        Z0 = np.random.rand(M, K) * 1e-2 + 1 / M
+        Z0 = Z0 / Z0.sum(axis=0)
+        T0 = np.random.rand(F, K)
+        V0 = np.random.rand(K, T)
+        np.random.set_state(state)
+        snap_iters = (1, 2, 5)
+
+        class SnapZ(Snapshot):
+            def __call__(self, model):
+                super().__call__(model)
+                if self.count in self.iters:
+                    self.data["Z_%d" % self.count] = model.latent.copy()
+
+        snap = SnapZ(snap_iters, with_nmf=True)
+        model = GaussILRMA(n_basis=K, partitioning=True, normalize=normalize, algorithm_spatial=alg, callbacks=snap)
+        Y = model(X, iteration=5)
+        tag = "m%d_k%d_%s_%s" % (M, K, {"power": "pow", False: "none"}[normalize], alg.lower())
+        save("part_ilrma_" + tag, X=X, M=M, K=K, normalize=np.array(str(normalize)), alg=np.array(alg), seed=seed,
+             Z0=Z0, T0=T0, V0=V0, iters=np.asarray(snap_iters), loss=np.asarray(model.loss), Y_out=Y,
+             W_final=model.demix_filter, Z_final=model.latent, T_final=model.basis, V_final=model.activation,
+             **snap.data)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
         for name in sys.argv[1:]:

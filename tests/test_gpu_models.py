@@ -94,8 +94,12 @@ def test_gauss_ilrma_api_surface():
     # separate() helper and the unsupported variants
     Ysep = model.separate(X, model.demix_filter)
     assert rel_err(Ysep, orc.separate(X, model.demix_filter)) < 1e-13
+    with pytest.raises(NotImplementedError):  # as the reference (ilrma.py:324-325, 451-453)
+        GaussILRMA(partitioning=True, normalize="projection-back")(X, iteration=1)
     with pytest.raises(NotImplementedError):
-        GaussILRMA(partitioning=True)(X, iteration=1)
+        GaussILRMA(partitioning=True, algorithm_spatial="IP2")(X, iteration=1)
+    with pytest.raises(AssertionError):
+        GaussILRMA(partitioning=True, domain=1)
     with pytest.warns(UserWarning):
         GaussILRMA(algorithm_spatial="ISS")
     assert GaussILRMA(algorithm_spatial="IP2").update_pair is None
@@ -351,3 +355,60 @@ def test_gauss_ilrma_ip2_golden(name):
             assert rel_err(snap.data["%s_%d" % (key, k)], g["%s_%d" % (key, k)]) < 1e-8, (key, k)
     np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
     assert rel_err(Y, g["Y_out"]) < 1e-8
+
+
+PART_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "part_ilrma_*.npz")))
+
+
+@pytest.mark.parametrize("name", PART_FILES)
+def test_gauss_ilrma_partitioning_golden(name):
+    """GaussILRMA(partitioning=True): shared bases + latent variables (ilrma.py:79-95, 368-408, 313-320)."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+
+    class SnapZ(Snap):
+        def __call__(self, model):
+            super().__call__(model)
+            if self.count in self.iters:
+                self.data["Z_%d" % self.count] = model.latent.copy()
+
+    snap = SnapZ(iters, nmf=True)
+    np.random.seed(int(g["seed"]))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = GaussILRMA(n_basis=int(g["K"]), partitioning=True, normalize=_norm(g), algorithm_spatial=str(g["alg"]),
+                           callbacks=snap)
+    Y = model(g["X"], iteration=max(iters))
+    assert model.latent.shape == g["Z_final"].shape and model.basis.shape == g["T_final"].shape
+    assert model.activation.shape == g["V_final"].shape
+    for k in iters:
+        for key in ("W", "Z", "T", "V"):
+            assert rel_err(snap.data["%s_%d" % (key, k)], g["%s_%d" % (key, k)]) < 1e-8, (key, k)
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-8
+    np.testing.assert_allclose(model.latent.sum(axis=0), 1.0, rtol=1e-12)
+    assert repr(model).startswith("Gauss-ILRMA(n_basis=%d, domain=2, partitioning=True" % int(g["K"]))
+
+
+def test_gauss_ilrma_partitioning_batched_f32():
+    """Two utterances in one call == two separate calls; float32 storage tracks float64."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    g = load_golden("part_ilrma_m3_k4_pow_ip")
+    X = g["X"]
+    Xb = np.stack([X, X[:, ::-1].copy()])
+    Z0 = np.stack([g["Z0"], g["Z0"][::-1].copy()])
+    T0, V0 = np.stack([g["T0"], g["T0"] + 0.1]), np.stack([g["V0"], g["V0"] + 0.2])
+    mb = GaussILRMA(n_basis=int(g["K"]), partitioning=True)
+    Yb = mb(Xb, iteration=3, latent=Z0.copy(), basis=T0.copy(), activation=V0.copy())
+    for b in range(2):
+        m1 = GaussILRMA(n_basis=int(g["K"]), partitioning=True)
+        Y1 = m1(Xb[b], iteration=3, latent=Z0[b].copy(), basis=T0[b].copy(), activation=V0[b].copy())
+        assert rel_err(Yb[b], Y1) < 1e-12
+        assert rel_err(mb.latent[b], m1.latent) < 1e-12 and rel_err(mb.basis[b], m1.basis) < 1e-12
+        np.testing.assert_allclose(np.asarray(mb.loss)[:, b], m1.loss, rtol=1e-12)
+    m32 = GaussILRMA(n_basis=int(g["K"]), partitioning=True, dtype="float32")
+    m32(X, iteration=2, latent=g["Z0"].copy(), basis=g["T0"].copy(), activation=g["V0"].copy())
+    assert rel_err(m32.latent, g["Z_2"]) < 1e-3 and rel_err(m32.basis, g["T_2"]) < 1e-3
+    np.testing.assert_allclose(m32.loss, g["loss"][:3], rtol=1e-4)

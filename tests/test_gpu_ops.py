@@ -330,3 +330,47 @@ def test_ip2_update(eng, M, F, T):
         stored = host(dev_c(eng, W[None]))[0]  # W as the kernel saw it (rounded to the storage dtype)
         assert np.array_equal(got[:, others], stored[:, others])
         assert rel_err(got, Wref) < tol(eng, 1e-9, 5e-3)
+
+
+@pytest.mark.parametrize("M,K", [(2, 3), (3, 4), (4, 4), (4, 7)])
+def test_partitioned_source_update(eng, M, K):
+    """Z, T, V updates of the partitioning branch (ilrma.py:368-408) vs the oracle; B = 2 utterances."""
+    F, T = 21, 150
+    rng = np.random.default_rng(70 + M + K)
+    Xs = [mixture(M, F, T, 71 + b) for b in range(2)]
+    Ws = [rand_filters(M, F, 73 + b) for b in range(2)]
+    Z = rng.random((2, M, K)) + 0.1
+    Z /= Z.sum(axis=1, keepdims=True)
+    Tb, V = rng.random((2, F, K)) + 0.05, rng.random((2, K, T)) + 0.05
+    Zd, Td, Vd = dev_r(eng, Z), dev_r(eng, Tb), dev_r(eng, V)
+    Teff, Veff = eng.empty((2, M, F, K)), eng.empty((2, M, K, T))
+    eng.ilrma_source_update_partitioned(dev_c(eng, np.stack(Xs)), dev_c(eng, np.stack(Ws)), Zd, Td, Vd, Teff, Veff)
+    for b in range(2):
+        Z1, T1, V1 = orc.part_source_update(np.abs(orc.separate(Xs[b], Ws[b])) ** 2, Z[b], Tb[b], V[b])
+        assert rel_err(host(Zd)[b], Z1) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
+        # the expansion left behind describes the updated model
+        assert rel_err(host(Teff)[b], Z1[:, None, :] * T1[None]) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Veff)[b], np.broadcast_to(V1, (M,) + V1.shape)) < tol(eng, 1e-11, 5e-5)
+
+
+def test_partitioned_expand_and_normalize(eng):
+    M, F, K, T = 3, 11, 5, 20
+    rng = np.random.default_rng(80)
+    Z, Tb, V = rng.random((2, M, K)), rng.random((2, F, K)), rng.random((2, K, T))
+    W = rng.standard_normal((2, F, M, M)) + 1j * rng.standard_normal((2, F, M, M))
+    pb = rng.random((2, M, F)) + 0.1
+    Teff, Veff = eng.empty((2, M, F, K)), eng.empty((2, M, K, T))
+    eng.ilrma_expand_partitioned(dev_r(eng, Z), dev_r(eng, Tb), dev_r(eng, V), Teff, Veff)
+    sr = 0 if eng.prec.name == "float64" else 1e-6
+    assert rel_err(host(Teff), Z[:, :, None, :] * Tb[:, None]) <= sr
+    assert rel_err(host(Veff), np.broadcast_to(V[:, None], (2, M, K, T))) <= sr
+    Wd, Zd, Td = dev_c(eng, W), dev_r(eng, Z), dev_r(eng, Tb)
+    eng.ilrma_normalize_power_bins_partitioned(Wd, Zd, Td, torch.from_numpy(pb).to(eng.dev), T)
+    aux = np.sqrt(pb.mean(axis=2))  # (B, N)
+    Zaux = Z / aux[:, :, None] ** 2
+    Zs = Zaux.sum(axis=1, keepdims=True)
+    assert rel_err(host(Zd), Zaux / Zs) < tol(eng, 1e-13, 1e-5)
+    assert rel_err(host(Td), Tb * Zs) < tol(eng, 1e-13, 1e-5)
+    assert rel_err(host(Wd), W / aux[:, None, :, None]) < tol(eng, 1e-13, 1e-5)

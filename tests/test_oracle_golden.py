@@ -229,3 +229,32 @@ def test_ip2_ilrma(name):
     np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
     assert rel_err(res["Y"], g["Y_out"]) < 1e-9
     assert tuple(res["update_pair"]) == tuple(int(v) for v in g["update_pair"])
+
+
+PART_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "part_ilrma_*.npz")))
+
+
+@pytest.mark.parametrize("name", PART_ILRMA)
+def test_partitioned_ilrma(name):
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    res = orc.gauss_ilrma_partitioned(g["X"], max(iters), g["Z0"], g["T0"], g["V0"], normalize=_norm(g),
+                                      algorithm_spatial=str(g["alg"]), snapshots=iters)
+    for k in iters:
+        W, Z, T, V = res["snapshots"][k]
+        for got, key in ((W, "W"), (Z, "Z"), (T, "T"), (V, "V")):
+            assert rel_err(got, g["%s_%d" % (key, k)]) < 1e-9, (key, k)
+    np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(res["Y"], g["Y_out"]) < 1e-9
+
+
+def test_partitioned_rng_order():
+    """latent, then basis, then activation from the global RNG (ilrma.py:79-95)."""
+    g = load_golden("part_ilrma_m3_k4_pow_ip")
+    M, K = int(g["M"]), int(g["K"])
+    F, T = g["X"].shape[1:]
+    np.random.seed(int(g["seed"]))
+    Z = np.random.rand(M, K) * 1e-2 + 1 / M
+    Z = Z / Z.sum(axis=0)
+    assert np.array_equal(Z, g["Z0"]) and np.array_equal(np.random.rand(F, K), g["T0"])
+    assert np.array_equal(np.random.rand(K, T), g["V0"])
