@@ -50,6 +50,9 @@ SIGNATURES = {
     "assx_ilrma_normalize_power_bins": (_i, [_vp, _vp, _vp, _vp, _d, _d, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_normalize_pb": (_i, [_vp, _vp, _vp, _vp, _d, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_tilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_tilrma_spatial_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_tilrma_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_auxiva_weights": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_auxiva_spatial_update": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back_scale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

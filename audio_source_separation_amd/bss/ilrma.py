@@ -436,3 +436,142 @@ class GaussILRMA(ILRMAbase):
         if self._batched:
             return to_numpy(loss, np.float64)
         return np.float64(loss.item())
+
+
+class tILRMA(ILRMAbase):
+    """
+    Reference: "Independent low-rank matrix analysis based on complex student's t-distribution for blind audio source separation"
+    See: https://ieeexplore.ieee.org/document/8168129
+    (reference implementation: ilrma.py:713-1020; IP spatial update, domain 2, no partitioning function)
+    """
+
+    def __init__(self, n_basis=10, nu=1, domain=2, partitioning=False, normalize='power', algorithm_spatial='IP',
+                 reference_id=0, callbacks=None, recordable_loss=True, eps=EPS, *, dtype='float64', device=None):
+        """
+        Args:
+            nu: degree of freedom. nu = 1: Cauchy distribution, nu -> infty: Gaussian distribution.
+            normalize <str>: 'power': power based normalization.
+        """
+        super().__init__(n_basis=n_basis, partitioning=partitioning, normalize=normalize,
+                         algorithm_spatial=algorithm_spatial, callbacks=callbacks, recordable_loss=recordable_loss,
+                         eps=eps, dtype=dtype, device=device)
+
+        self.nu = nu
+        self.domain = domain
+        self.reference_id = reference_id
+
+        assert self.algorithm_spatial == 'IP', "Supports only IP-based spatial update."
+
+    def __call__(self, input, iteration=100, **kwargs):
+        """
+        Args:
+            input (n_channels, n_bins, n_frames)
+        Returns:
+            output (n_channels, n_bins, n_frames)
+        """
+        self.input = input
+
+        self._reset(**kwargs)
+
+        if self.recordable_loss:
+            self._record_loss()
+
+        self._run_callbacks()
+
+        for idx in range(iteration):
+            self.update_once()
+
+            if self.recordable_loss:
+                self._record_loss()
+
+            self._run_callbacks()
+
+        eng = self._engine
+        scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
+        Y = eng.demix(self._X, self._Wd, scale=scale)
+        self._check_status()
+
+        if isinstance(input, torch.Tensor):
+            output = Y if self._batched else Y[0]
+        else:
+            output = to_numpy(Y, np.complex128)
+            output = output if self._batched else output[0]
+        self.estimation = output
+
+        return output
+
+    def _reset(self, **kwargs):
+        super()._reset(**kwargs)
+        self._C = None
+        self._pbins = None
+        self._Xi = None
+
+    def __repr__(self):
+        s = "t-ILRMA("
+        s += "n_basis={n_basis}"
+        s += ", nu={nu}"
+        s += ", domain={domain}"
+        s += ", partitioning={partitioning}"
+        s += ", normalize={normalize}"
+        s += ", algorithm_spatial={algorithm_spatial}"
+        s += ")"
+
+        return s.format(**self.__dict__)
+
+    def update_once(self):
+        eps = self.eps
+        eng = self._engine
+
+        self.update_source_model()
+        self.update_spatial_model()
+
+        if self.normalize:
+            if self.normalize == 'power':
+                if self.partitioning:  # unreachable in the reference too: the source update raises first
+                    raise NotImplementedError("Only support when `partitioning=False` ")
+                # T / aux**2 whatever `domain` says (ilrma.py:869-870)
+                eng.ilrma_normalize_power_bins(self._Wd, self._Td, self._pbins, domain=2, eps=eps)
+            else:
+                raise ValueError("Not support normalization based on {}. Choose 'power' or 'projection-back'".format(self.normalize))
+            self._touch("W", "T")
+            self._estimation = None
+
+    def update_source_model(self):
+        """IS-NMF updates on the harmonic statistic (ilrma.py:880-922)."""
+        assert self.domain == 2, "Only domain = 2 is supported."
+        if self.partitioning:
+            raise NotImplementedError("Only support when `partitioning=False` ")
+        self._engine.tilrma_source_update(self._X, self._Wd, self._Td, self._Vd, self.nu, eps=self.eps)
+        self._touch("T", "V")
+
+    def update_spatial_model(self):
+        """Xi-weighted covariance + IP without a condition guard (ilrma.py:926-983)."""
+        eng = self._engine
+        B, M, F, T = (int(s) for s in self._X.shape)
+        C = pbins = None
+        if self.normalize == 'power':
+            if self._C is None:
+                self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
+                self._pbins = eng.empty((B, M, F), dtype=torch.float64)
+            C, pbins = self._C, self._pbins
+        if self._Xi is None:
+            self._Xi = eng.empty((B, M, F, T))
+        eng.tilrma_spatial_update(self._X, self._Wd, self._Td, self._Vd, self.nu, self._Xi, eps=self.eps,
+                                  status=self._status, C=C, power_bins=pbins)
+        self._touch("W")
+        self._estimation = None
+
+    def _record_loss(self):
+        loss = self._engine.tilrma_loss(self._X, self._Wd, self._Td, self._Vd, self.nu, eps=self.eps)
+        if isinstance(self.loss, LazyLossList):
+            self.loss.append_device(loss, self._batched)
+        else:
+            self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
+
+    def compute_negative_loglikelihood(self):
+        """sum (1 + nu/2) log(1 + (2/nu) P/R) + log R - 2 T sum_f log|det W_f|   (ilrma.py:991-1018)."""
+        loss = self._engine.tilrma_loss(self._X, self._Wd, self._Td, self._Vd, self.nu, eps=self.eps)
+        self._check_status()
+        if self._batched:
+            return to_numpy(loss, np.float64)
+        return np.float64(loss.item())

@@ -162,7 +162,7 @@ template <typename R, int M, bool FROM_PART>
 __global__ void __launch_bounds__(64)
     ip_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
                     Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
-                    int32_t* __restrict__ status, int B, int F) {
+                    int32_t* __restrict__ status, int B, int F, double den_floor) {
   constexpr int N = M;
   constexpr int MM = M * M;
   constexpr int GW = next_pow2_c(MM);
@@ -227,7 +227,8 @@ __global__ void __launch_bounds__(64)
     Cd term = cmul(cmul(cconj(wi), u), wj);
     if (!active) term = cmake<double>(0.0, 0.0);
     const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
-    const Cd den = csqrt_principal(q);
+    Cd den = csqrt_principal(q);
+    if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
     if (ok && !singular && i == n) w = cdiv(cconj(wj), den);
   }
 
@@ -915,6 +916,37 @@ inline void f_split(int B, int F, int T, int* FS, int* fchunk) {
   *fchunk = chunk;
 }
 
+// t-ILRMA auxiliary weights (ilrma.py:946-958): Xi[n,f,t] = (nu max(R, eps) + 2 |y_n|^2) / (nu + 2), R = T V,
+// y = W x with the filters BEFORE the sweep.  Materialised (B,N,F,T): the covariance kernel then runs in its
+// "weights given" form.
+template <typename R, int M>
+__global__ void __launch_bounds__(256) tilrma_xi_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                       const R* __restrict__ Tb, const R* __restrict__ V,
+                                                       R* __restrict__ Xi, Dims d, R nu, R eps) {
+  constexpr int N = M;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = blockIdx.y, b = blockIdx.z;
+  if (t >= d.T) return;
+  const size_t FT = (size_t)d.F * d.T;
+  Cx<R> x[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) x[m] = X[((size_t)b * M + m) * FT + (size_t)f * d.T + t];
+  const Cx<R>* wp = W + ((size_t)b * d.F + f) * (N * M);
+  const R inv = fast_rcp(nu + (R)2);
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+    for (int m = 0; m < M; ++m) cfma(y, wp[n * M + m], x[m]);
+    const R* tbn = Tb + (((size_t)b * N + n) * d.F + f) * d.K;
+    const R* vn = V + ((size_t)b * N + n) * d.K * d.T + t;
+    R tv = 0;
+    for (int k = 0; k < d.K; ++k) tv = fma(tbn[k], vn[(size_t)k * d.T], tv);
+    tv = floor_eps<R>(tv, eps);
+    Xi[((size_t)b * N + n) * FT + (size_t)f * d.T + t] = fma(nu, tv, (R)2 * cabs2(y)) * inv;
+  }
+}
+
 struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte aligned
   size_t part;     // reduction partials (largest user: activation update)
   size_t u;        // dense U (B,N,F,M,M) complex
@@ -1065,15 +1097,15 @@ int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb,
 
 template <typename R, int M>
 int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
-           double thr, int32_t* status, int B, int F, hipStream_t st) {
+           double thr, int32_t* status, int B, int F, hipStream_t st, double den_floor = 0.0) {
   constexpr int GPW = WAVE / next_pow2_c(M * M);
   const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
   if (part)
     hipLaunchKernelGGL((ip_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
-                       1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F);
+                       1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor);
   else
     hipLaunchKernelGGL((ip_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
-                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F);
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor);
   ASSX_LAUNCH_CHECK(ctx, "ip_group_kernel");
   return 0;
 }
@@ -1111,8 +1143,10 @@ int run_ip2(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, 
 // source-model partial sums (reduce over t): part[g][slot][n][k][num|den]
 template <typename R, int MM>
 int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
-                      double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out) {
+                      double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out,
+                      double nu = -1.0 /* >= 0: t-ILRMA harmonic statistic (domain 2) */) {
   NmfArgs<R> a;
+  a.nu = (R)nu;
   a.d = Dims{B, F, T, K};
   a.eps = (R)eps;
   a.p1 = make_pow((domain + 2.0) / domain);
@@ -1123,7 +1157,12 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
 #define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
   hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
-  if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
+  if (nu >= 0.0) {
+    if (k4) hipLaunchKernelGGL((basis_stream_kernel<R, MM, true, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
+                               (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+    else hipLaunchKernelGGL((basis_stream_kernel<R, MM, false, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
+                            (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+  } else if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
   else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
   else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
   else BASIS_LAUNCH(false, false, 2, 1, 1);
@@ -1135,8 +1174,10 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
 // source-model partial sums (reduce over f): part[g][slot][n][k][num|den][64 frames]
 template <typename R, int MM>
 int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
-                    double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out) {
+                    double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out,
+                    double nu = -1.0) {
   NmfArgs<R> a;
+  a.nu = (R)nu;
   a.d = Dims{B, F, T, K};
   a.eps = (R)eps;
   a.p1 = make_pow((domain + 2.0) / domain);
@@ -1147,7 +1188,12 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
 #define ACT_LAUNCH(K4V, D2V, DXV, MW) \
   hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
                      (const R*)Tb, (const R*)V, (R*)ws, a)
-  if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
+  if (nu >= 0.0) {
+    if (k4) hipLaunchKernelGGL((act_stream_kernel<R, MM, true, true, 3, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
+                               (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+    else hipLaunchKernelGGL((act_stream_kernel<R, MM, false, true, 4, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
+                            (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+  } else if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
   else if (k4) ACT_LAUNCH(true, false, 2, 1);
   else if (d2) ACT_LAUNCH(false, true, 4, 1);
   else ACT_LAUNCH(false, false, 2, 1);
@@ -1496,10 +1542,11 @@ int assx_ilrma_normalize_pb(assx_ctx* ctx, void* W, void* Tb, const void* scale,
   return 0;
 }
 
-int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
-                    double eps, double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const void* W, const void* Tb,
+                           const void* V, double domain, double nu, double eps, double* loss, void* ws, int B, int M,
+                           int F, int T, int K, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
-  ASSX_REQUIRE(ctx, X && W && Tb && V && loss && ws, ASSX_E_NULL, "assx_ilrma_loss: NULL array");
+  ASSX_REQUIRE(ctx, X && W && Tb && V && loss && ws, ASSX_E_NULL, "%s: NULL array", who);
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   hipStream_t st = (hipStream_t)stream;
   const WsLayout L = ws_layout(B, M, F, T, K, dtype);
@@ -1512,17 +1559,21 @@ int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
     a.fp = flat_loss(F, T);
     a.eps = (R)eps;
     a.p1 = make_pow(1.0);
+    a.nu = (R)nu;
     const PowSpec p2d = make_pow(2.0 / domain);
     const bool d2 = p2d.mode == POW_ID, k4 = K <= KU;
     const int lstride = a.fp.G + F;  // [G data-term partials | F log-det terms] per utterance
     const dim3 grid(a.fp.G, B), blk(64);
-#define LOSS_LAUNCH(K4V, D2V, DXV, DWV, MW)                                                                     \
-  hipLaunchKernelGGL((loss_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), grid, blk, 0, st, (const Cx<R>*)X,      \
+#define LOSS_LAUNCH(K4V, D2V, DXV, DWV, MW, TDV)                                                                \
+  hipLaunchKernelGGL((loss_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW, TDV>), grid, blk, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lstride, a, p2d)
-    if (k4 && d2) LOSS_LAUNCH(true, true, 4, 1, 2);
-    else if (k4) LOSS_LAUNCH(true, false, 2, 1, 1);
-    else if (d2) LOSS_LAUNCH(false, true, 4, 1, 2);
-    else LOSS_LAUNCH(false, false, 2, 1, 1);
+    if (nu >= 0.0) {
+      if (k4) LOSS_LAUNCH(true, true, 4, 1, 1, true);
+      else LOSS_LAUNCH(false, true, 4, 1, 1, true);
+    } else if (k4 && d2) LOSS_LAUNCH(true, true, 4, 1, 2, false);
+    else if (k4) LOSS_LAUNCH(true, false, 2, 1, 1, false);
+    else if (d2) LOSS_LAUNCH(false, true, 4, 1, 2, false);
+    else LOSS_LAUNCH(false, false, 2, 1, 1, false);
 #undef LOSS_LAUNCH
     ASSX_LAUNCH_CHECK(ctx, "loss_stream_kernel");
     hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W,
@@ -1532,6 +1583,69 @@ int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
                        loss, (size_t)lstride, 1.0);
     ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
     return 0;
+  });
+}
+
+int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
+                    double eps, double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+  return ilrma_loss_impl(ctx, "assx_ilrma_loss", X, W, Tb, V, domain, -1.0, eps, loss, ws, B, M, F, T, K, dtype, stream);
+}
+
+// ---- t-ILRMA (ilrma.py:713-1020) -------------------------------------------------------------
+int assx_tilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double nu, double eps,
+                     double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+  ASSX_REQUIRE(ctx, ctx == nullptr || nu > 0.0, ASSX_E_ARG, "nu must be > 0, got %g", nu);
+  return ilrma_loss_impl(ctx, "assx_tilrma_loss", X, W, Tb, V, 2.0, nu, eps, loss, ws, B, M, F, T, K, dtype, stream);
+}
+
+int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double nu, double eps,
+                              void* ws, int B, int M, int F, int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_tilrma_source_update: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  ASSX_REQUIRE(ctx, nu >= 0.0, ASSX_E_ARG, "nu must be >= 0, got %g", nu);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const PowSpec p2 = make_pow(0.5);
+    FlatPart fp;
+    int rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, 2.0, eps, ws, B, F, T, K, st, &fp, nu);
+    if (rc) return rc;
+    hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
+                       st, (const R*)ws, (R*)Tb, B, MM, F, K, fp, (R)eps, p2, ~0u);
+    ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
+    rc = run_act_partial<R, MM>(ctx, X, W, Tb, V, 2.0, eps, ws, B, F, T, K, st, &fp, nu);
+    if (rc) return rc;
+    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
+                       (const R*)ws, (R*)V, B, MM, F, K, T, fp, (R)eps, p2, ~0u);
+    ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
+    return 0;
+  });
+}
+
+int assx_tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double nu,
+                               double eps, void* Xi, const void* C, double* power_bins, int32_t* status, void* ws,
+                               int B, int M, int F, int T, int K, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && Tb && V && Xi && ws, ASSX_E_NULL, "assx_tilrma_spatial_update: NULL array");
+  ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  ASSX_REQUIRE(ctx, nu >= 0.0, ASSX_E_ARG, "nu must be >= 0, got %g", nu);
+  ASSX_REQUIRE(ctx, (C == nullptr) == (power_bins == nullptr), ASSX_E_ARG,
+               "assx_tilrma_spatial_update: C and power_bins must be given together");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    hipLaunchKernelGGL((tilrma_xi_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
+                       (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)Xi, Dims{B, F, T, K}, (R)nu, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "tilrma_xi_kernel");
+    FlatPart fp;
+    // Xi is used as is (the reference does not floor it): eps = 0 in the covariance pass
+    int rc = run_cov_partial<R, MM>(ctx, WK_NFT, X, Xi, nullptr, nullptr, 1, 2.0, 0.0, ws, B, F, T, st, &fp);
+    if (rc) return rc;
+    // inverse without a condition-number guard (ilrma.py:968-976); the normaliser is floored at eps
+    return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, INFINITY, status, B, F, st, eps);
   });
 }
 

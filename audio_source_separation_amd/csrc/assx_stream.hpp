@@ -345,9 +345,17 @@ struct NmfArgs {
   FlatPart fp;
   R eps;
   PowSpec p1;  // (domain+2)/domain
+  R nu;        // t-ILRMA degree of freedom (TD instantiations only)
 };
 
-template <typename R, int M, bool K4, bool D2, int DXT, int DWT, int MINW = 1>
+// t-ILRMA (ilrma.py:905-909): harmonic = 1 / (2/((2+nu) TV) + nu/((2+nu) P)), evaluated as (2+nu) TV P / (2 P + nu TV)
+// so that P == 0 gives 0 (as 1/inf does in the reference) without an inf/NaN detour through the reciprocal.
+template <typename R>
+__device__ __forceinline__ R t_harmonic(R P, R tv, R nu) {
+  return ((R)2 + nu) * tv * P * fast_rcp(fma(nu, tv, (R)2 * P));
+}
+
+template <typename R, int M, bool K4, bool D2, int DXT, int DWT, int MINW = 1, bool TD = false>
 __global__ void __launch_bounds__(64, MINW)
     basis_stream_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
                         const R* __restrict__ V, R* __restrict__ part, NmfArgs<R> a) {
@@ -466,7 +474,7 @@ __global__ void __launch_bounds__(64, MINW)
             Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
             for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
-            const R P = cabs2(y);
+            R P = cabs2(y);
             R tv = 0;
             if (K4) {
 #pragma unroll
@@ -477,6 +485,7 @@ __global__ void __launch_bounds__(64, MINW)
               for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
             }
             tv = floor_eps<R>(tv, a.eps);
+            if (TD) P = t_harmonic<R>(P, tv, a.nu);
             R inv = fast_rcp(tv);                                 // TV_inverse
             R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);   // division = P / TV**((d+2)/d)
             if (ragged && t >= T) {
@@ -538,7 +547,7 @@ __global__ void __launch_bounds__(256) basis_stream_finalize_kernel(const R* __r
 //      Same streaming structure as the basis kernel, one float64 accumulator per lane.  The flat partition is
 //      per utterance (blockIdx.y) so a partial never mixes utterances: lpart[b][g].
 // ------------------------------------------------------------------------------------------
-template <typename R, int M, bool K4, bool D2, int DXT, int DWT, int MINW = 1>
+template <typename R, int M, bool K4, bool D2, int DXT, int DWT, int MINW = 1, bool TD = false>
 __global__ void __launch_bounds__(64, MINW)
     loss_stream_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
                        const R* __restrict__ V, double* __restrict__ lpart, int lstride, NmfArgs<R> a, PowSpec p2d) {
@@ -555,6 +564,9 @@ __global__ void __launch_bounds__(64, MINW)
   // log per lane at the end instead of N per frame.
   double lm = 1.0;
   int le = 0;
+  // t-ILRMA (ilrma.py:1015-1016): sum (1 + nu/2) log(1 + (2/nu) P/R) carried the same way
+  double tm = 1.0;
+  int te = 0;
   if (q0 < q1) {
     const int nblk = (int)(q1 - q0);
     Cursor cc;
@@ -644,7 +656,7 @@ __global__ void __launch_bounds__(64, MINW)
           const Cursor cur = cc;
           advance(cc, TBk, F);
           const int t = cur.tb * WAVE + lane;
-          double term = 0.0, rprod = 1.0;
+          double term = 0.0, rprod = 1.0, tprod = 1.0;
 #pragma unroll
           for (int n = 0; n < N; ++n) {
             Cx<R> y = cmake<R>(0, 0);
@@ -660,7 +672,8 @@ __global__ void __launch_bounds__(64, MINW)
               for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(unsigned)(n * K + k) * (unsigned)T + tc], tv);
             }
             const R r = floor_eps<R>(D2 ? tv : powspec<R>(tv, p2d), a.eps);
-            term += (double)(cabs2(y) * fast_rcp(r));
+            if (TD) tprod *= fma((double)((R)2 * fast_rcp(a.nu)), (double)(cabs2(y) * fast_rcp(r)), 1.0);
+            else term += (double)(cabs2(y) * fast_rcp(r));
             rprod *= (double)r;
           }
           if (t < T) {
@@ -668,6 +681,10 @@ __global__ void __launch_bounds__(64, MINW)
             int e;
             lm = frexp(lm * rprod, &e);
             le += e;
+            if (TD) {
+              tm = frexp(tm * tprod, &e);
+              te += e;
+            }
           }
           if (cc.tb == 0 && it + 1 < nblk) load_rows(cc);
         }
@@ -675,6 +692,7 @@ __global__ void __launch_bounds__(64, MINW)
     }
   }
   acc += (double)le * 0.6931471805599453 + log(lm);
+  if (TD) acc += (1.0 + 0.5 * (double)a.nu) * ((double)te * 0.6931471805599453 + log(tm));
   acc = wave_allreduce_sum<double>(acc);
   if (lane == 0) lpart[(size_t)b * lstride + g] = acc;
 }
@@ -686,7 +704,7 @@ __global__ void __launch_bounds__(64, MINW)
 // ------------------------------------------------------------------------------------------
 constexpr int ACT_NH = 2;
 
-template <typename R, int M, bool K4, bool D2, int DXT, int MINW = 1>
+template <typename R, int M, bool K4, bool D2, int DXT, int MINW = 1, bool TD = false>
 __global__ void __launch_bounds__(64 * ACT_NH, MINW)
     act_stream_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
                       const R* __restrict__ V, R* __restrict__ part, NmfArgs<R> a) {
@@ -759,7 +777,7 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
               Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
               for (int m = 0; m < M; ++m) cfma(y, wp[n * M + m], x[m]);
-              const R P = cabs2(y);
+              R P = cabs2(y);
               const R* tbn = Tb + (((size_t)b * N + n) * F + f) * K;
               R tk[KU];
               R tv = 0;
@@ -776,6 +794,7 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
                 for (int kk = 0; kk < KU; ++kk) tk[kk] = (k0 + kk < K) ? tbn[k0 + kk] : (R)0;
               }
               tv = floor_eps<R>(tv, a.eps);
+              if (TD) P = t_harmonic<R>(P, tv, a.nu);
               const R inv = fast_rcp(tv);
               const R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);
 #pragma unroll

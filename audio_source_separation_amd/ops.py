@@ -188,6 +188,34 @@ class Engine:
                                       ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_loss")
         return loss
 
+    # ------------------------------------------------------------------ t-ILRMA
+    def tilrma_source_update(self, X, W, Tb, V, nu, eps=1e-12):
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_tilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
+                                                ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
+                    "assx_tilrma_source_update")
+
+    def tilrma_spatial_update(self, X, W, Tb, V, nu, Xi, eps=1e-12, status=None, C=None, power_bins=None):
+        """Xi: scratch (B,N,F,T) reals receiving the auxiliary weights."""
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_tilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
+                                                 ptr(Xi), ptr(C), ptr(power_bins), ptr(status), ptr(ws), B, M, F, T,
+                                                 K, self.prec.code, self._st()), "assx_tilrma_spatial_update")
+        return W
+
+    def tilrma_loss(self, X, W, Tb, V, nu, eps=1e-12, out=None):
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        loss = out if out is not None else self.empty((B,), dtype=torch.float64)
+        ws = self._scratch(B, M, F, T, K)
+        self._check(L.assx_tilrma_loss(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps), ptr(loss),
+                                       ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_tilrma_loss")
+        return loss
+
     # ------------------------------------------------------------------ AuxIVA
     def auxiva_weights(self, X, W, kind, eps=1e-12, with_loss=False, out=None):
         B, M, F, T = self._dims(X)

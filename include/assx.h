@@ -177,6 +177,23 @@ int assx_ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
                     double domain, double eps, double* loss, void* ws,
                     int B, int M, int F, int T, int K, int dtype, void* stream);
 
+/* ---- (f1) t-ILRMA (src/bss/ilrma.py:713-1020), domain 2, IP ------------------------------------------------
+ * Source model (src/bss/ilrma.py:899-922): the IS-NMF updates of assx_ilrma_source_update with P replaced by the
+ * harmonic statistic 1 / (2/((2+nu) TV) + nu/((2+nu) P)). */
+int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double nu, double eps,
+                              void* ws, int B, int M, int F, int T, int K, int dtype, void* stream);
+/* Spatial model (src/bss/ilrma.py:926-983): Xi = (nu max(TV, eps) + 2 |W x|^2) / (nu + 2) with the filters before the
+ * sweep, U_n = mean_t x x^H / Xi_n, then for every source w = (W U_n)^{-1} e_n (no condition-number guard),
+ * W[n] = conj(w) / max(sqrt(w^H U_n w), eps).  Xi: caller-owned scratch (B,N,F,T) reals.  C / power_bins as for
+ * assx_ilrma_spatial_update. */
+int assx_tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double nu,
+                               double eps, void* Xi, const void* C, double* power_bins, int32_t* status, void* ws,
+                               int B, int M, int F, int T, int K, int dtype, void* stream);
+/* tILRMA.compute_negative_loglikelihood (src/bss/ilrma.py:991-1018):
+ * sum (1 + nu/2) log(1 + (2/nu) P/R) + log R  -  2 T sum_f log|det W_f|.  loss: (B,) float64. */
+int assx_tilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double nu, double eps,
+                     double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream);
+
 /* ---- AuxIVA ----------------------------------------------------------------------------- */
 /* r[b,n,t] from the current filters (src/bss/iva.py:489-491 Laplace sqrt(sum_f|y|^2),
  * 722-724 Gauss mean_f|y|^2; not floored), and in the same pass the data term of

@@ -40,7 +40,7 @@ sys.path.insert(0, REFERENCE_SRC)
 from algorithm.nmf import EUCNMF, KLNMF, ISNMF  # noqa: E402
 from algorithm.projection_back import projection_back  # noqa: E402
 from bss.iva import AuxLaplaceIVA, AuxGaussIVA  # noqa: E402
-from bss.ilrma import GaussILRMA  # noqa: E402
+from bss.ilrma import GaussILRMA, tILRMA  # noqa: E402
 
 warnings.simplefilter("ignore")
 
@@ -398,6 +398,30 @@ def gen_part():
              Z0=Z0, T0=T0, V0=V0, iters=np.asarray(snap_iters), loss=np.asarray(model.loss), Y_out=Y,
              W_final=model.demix_filter, Z_final=model.latent, T_final=model.basis, V_final=model.activation,
              **snap.data)
+
+
+# ----------------------------------------------------------------------------
+# G6d: t-ILRMA (ilrma.py:713-1020)
+# ----------------------------------------------------------------------------
+def gen_tilrma():
+    seed = 900
+    for M, K, nu, normalize in [(2, 2, 1, "power"), (3, 4, 5, "power"), (4, 4, 100, "power"), (4, 6, 2.5, False)]:
+        seed += 1
+        F, T = 17, 72
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        T0 = np.random.rand(M, F, K)
+        V0 = np.random.rand(M, K, T)
+        np.random.set_state(state)
+        snap_iters = (1, 2, 5)
+        snap = Snapshot(snap_iters, with_nmf=True)
+        model = tILRMA(n_basis=K, nu=nu, normalize=normalize, callbacks=snap)
+        Y = model(X, iteration=5)
+        tag = "m%d_k%d_nu%s_%s" % (M, K, str(nu).replace(".", "p"), {"power": "pow", False: "none"}[normalize])
+        save("tilrma_" + tag, X=X, M=M, K=K, nu=float(nu), normalize=np.array(str(normalize)), seed=seed, T0=T0, V0=V0,
+             iters=np.asarray(snap_iters), loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter,
+             T_final=model.basis, V_final=model.activation, **snap.data)
 
 
 if __name__ == "__main__":

@@ -412,3 +412,52 @@ def test_gauss_ilrma_partitioning_batched_f32():
     m32(X, iteration=2, latent=g["Z0"].copy(), basis=g["T0"].copy(), activation=g["V0"].copy())
     assert rel_err(m32.latent, g["Z_2"]) < 1e-3 and rel_err(m32.basis, g["T_2"]) < 1e-3
     np.testing.assert_allclose(m32.loss, g["loss"][:3], rtol=1e-4)
+
+
+TILRMA_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "tilrma_*.npz")))
+
+
+@pytest.mark.parametrize("name", TILRMA_FILES)
+def test_tilrma_golden(name):
+    """tILRMA (ilrma.py:713-1020) against the reference's snapshots."""
+    from audio_source_separation_amd.bss.ilrma import tILRMA
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    snap = Snap(iters, nmf=True)
+    np.random.seed(int(g["seed"]))
+    model = tILRMA(n_basis=int(g["K"]), nu=float(g["nu"]), normalize=_norm(g), callbacks=snap)
+    Y = model(g["X"], iteration=max(iters))
+    for k in iters:
+        for key in ("W", "T", "V"):
+            assert rel_err(snap.data["%s_%d" % (key, k)], g["%s_%d" % (key, k)]) < 1e-8, (key, k)
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-8
+    assert repr(model).startswith("t-ILRMA(n_basis=%d, nu=" % int(g["K"]))
+    np.testing.assert_allclose(model.compute_negative_loglikelihood(), g["loss"][-1], rtol=1e-9)
+
+
+def test_tilrma_surface_and_f32():
+    from audio_source_separation_amd.bss.ilrma import tILRMA
+    g = load_golden("tilrma_m3_k4_nu5_pow")
+    X = g["X"]
+    with pytest.raises(AssertionError):
+        tILRMA(algorithm_spatial="ISS")
+    with pytest.raises(NotImplementedError):
+        tILRMA(partitioning=True)(X, iteration=1)
+    with pytest.raises(AssertionError):
+        tILRMA(domain=1)(X, iteration=1)
+    with pytest.raises(ValueError):
+        tILRMA(normalize="projection-back")(X, iteration=1)
+    m32 = tILRMA(n_basis=int(g["K"]), nu=float(g["nu"]), dtype="float32")
+    m32(X, iteration=2, basis=g["T0"].copy(), activation=g["V0"].copy())
+    assert rel_err(m32.basis, g["T_2"]) < 1e-3 and rel_err(m32.demix_filter, g["W_2"]) < 1e-2
+    np.testing.assert_allclose(m32.loss, g["loss"][:3], rtol=1e-4)
+    # batched == per-utterance
+    Xb = np.stack([X, X[::-1].copy()])
+    T0, V0 = np.stack([g["T0"], g["T0"] + 0.1]), np.stack([g["V0"], g["V0"] + 0.2])
+    mb = tILRMA(n_basis=int(g["K"]), nu=float(g["nu"]))
+    Yb = mb(Xb, iteration=2, basis=T0.copy(), activation=V0.copy())
+    for b in range(2):
+        m1 = tILRMA(n_basis=int(g["K"]), nu=float(g["nu"]))
+        Y1 = m1(Xb[b], iteration=2, basis=T0[b].copy(), activation=V0[b].copy())
+        assert rel_err(Yb[b], Y1) < 1e-12 and rel_err(mb.basis[b], m1.basis) < 1e-12

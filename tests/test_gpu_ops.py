@@ -374,3 +374,26 @@ def test_partitioned_expand_and_normalize(eng):
     assert rel_err(host(Zd), Zaux / Zs) < tol(eng, 1e-13, 1e-5)
     assert rel_err(host(Td), Tb * Zs) < tol(eng, 1e-13, 1e-5)
     assert rel_err(host(Wd), W / aux[:, None, :, None]) < tol(eng, 1e-13, 1e-5)
+
+
+@pytest.mark.parametrize("M,K,nu", [(2, 2, 1.0), (3, 4, 5.0), (4, 4, 100.0), (4, 7, 2.5)])
+def test_tilrma_stages(eng, M, K, nu):
+    """t-ILRMA source model, spatial model and loss, one stage at a time, vs the oracle (ilrma.py:880-1018)."""
+    F, T = 19, 150
+    X, W = mixture(M, F, T, 90 + M), rand_filters(M, F, 91)
+    rng = np.random.default_rng(92)
+    Tb, V = rng.random((M, F, K)) + 0.05, rng.random((M, K, T)) + 0.05
+    Xd, Wd, Td, Vd = dev_c(eng, X[None]), dev_c(eng, W[None]), dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    got = float(eng.tilrma_loss(Xd, Wd, Td, Vd, nu).item())
+    np.testing.assert_allclose(got, orc.tilrma_loss(X, W, Tb, V, nu), rtol=tol(eng, 1e-12, 1e-5))
+    eng.tilrma_source_update(Xd, Wd, Td, Vd, nu)
+    T1, V1 = orc.tilrma_source_update(np.abs(orc.separate(X, W)) ** 2, Tb, V, nu)
+    assert rel_err(host(Td)[0], T1) < tol(eng, 1e-11, 5e-5)
+    assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
+    Xi = eng.empty((1, M, F, T))
+    st = eng.new_status(1)
+    Td, Vd = dev_r(eng, T1[None]), dev_r(eng, V1[None])
+    eng.tilrma_spatial_update(Xd, Wd, Td, Vd, nu, Xi, status=st)
+    W1, _ = orc.tilrma_spatial_update(X, W, T1, V1, nu)
+    assert int(st.item()) == 0
+    assert rel_err(host(Wd)[0], W1) < tol(eng, 1e-9, 2e-3)

@@ -258,3 +258,19 @@ def test_partitioned_rng_order():
     Z = Z / Z.sum(axis=0)
     assert np.array_equal(Z, g["Z0"]) and np.array_equal(np.random.rand(F, K), g["T0"])
     assert np.array_equal(np.random.rand(K, T), g["V0"])
+
+
+TILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "tilrma_*.npz")))
+
+
+@pytest.mark.parametrize("name", TILRMA)
+def test_tilrma(name):
+    g = load_golden(name)
+    iters = [int(k) for k in g["iters"]]
+    res = orc.tilrma(g["X"], max(iters), g["T0"], g["V0"], nu=float(g["nu"]), normalize=_norm(g), snapshots=iters)
+    for k in iters:
+        W, T, V = res["snapshots"][k]
+        for got, key in ((W, "W"), (T, "T"), (V, "V")):
+            assert rel_err(got, g["%s_%d" % (key, k)]) < 1e-9, (key, k)
+    np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(res["Y"], g["Y_out"]) < 1e-9
