@@ -1071,8 +1071,20 @@ int run_cov_partial(assx_ctx* ctx, int wk, const void* X, const void* r, const v
     case WK_NT: COV_LAUNCH(WK_NT, true, true, LSX, 3, 1, 2); break;
     case WK_NFT: COV_LAUNCH(WK_NFT, true, true, LSX, 3, 1, 2); break;
     default:
-      if (K <= KU && d2) COV_LAUNCH(WK_TV, true, true, LSX, (sizeof(R) == 8 ? 2 : 4), 1, 2);
-      else if (K <= KU) COV_LAUNCH(WK_TV, true, false, LSX, 2, 1, 1);
+      // K <= 4: activation tile through the LDS-direct ring (VTileDma), X slots refilled in place; ASSX_COV_VDMA=0
+      // selects the plain vector-load form of the same kernel (kept for A/B measurements)
+      if (K <= KU) {
+        static const int vdma = env_int("ASSX_COV_VDMA", 1);
+        constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, M * KU>::TILE_BYTES;
+        if (vdma && d2)
+          hipLaunchKernelGGL((cov_stream_kernel<R, M, WK_TV, true, true, 1, 2, 1, 2, true>), grid, dim3(64), vlds, st,
+                             (const Cx<R>*)X, (const R*)r, (const R*)Tb, (const R*)V, (R*)ws, a);
+        else if (vdma)
+          hipLaunchKernelGGL((cov_stream_kernel<R, M, WK_TV, true, false, 1, 2, 1, 1, true>), grid, dim3(64), vlds, st,
+                             (const Cx<R>*)X, (const R*)r, (const R*)Tb, (const R*)V, (R*)ws, a);
+        else if (d2) COV_LAUNCH(WK_TV, true, true, LSX, (sizeof(R) == 8 ? 2 : 4), 1, 2);
+        else COV_LAUNCH(WK_TV, true, false, LSX, 2, 1, 1);
+      }
       else if (d2) COV_LAUNCH(WK_TV, false, true, LSX, 4, 1, 1);
       else COV_LAUNCH(WK_TV, false, false, LSX, 2, 1, 1);
   }
@@ -1157,15 +1169,25 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
 #define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
   hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
+  static const int vdma = env_int("ASSX_BASIS_VDMA", 1);
+  constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, MM * KU>::TILE_BYTES;
+#define BASIS_VD(D2V, MW, TDV) \
+  hipLaunchKernelGGL((basis_stream_vd_kernel<R, MM, D2V, 2, MW, TDV>), gb, bb, vlds, st, (const Cx<R>*)X, \
+                     (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
   if (nu >= 0.0) {
-    if (k4) hipLaunchKernelGGL((basis_stream_kernel<R, MM, true, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
+    if (k4 && vdma) BASIS_VD(true, 2, true);
+    else if (k4) hipLaunchKernelGGL((basis_stream_kernel<R, MM, true, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
                                (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
     else hipLaunchKernelGGL((basis_stream_kernel<R, MM, false, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+  } else if (k4 && vdma) {
+    if (d2) BASIS_VD(true, 2, false);
+    else BASIS_VD(false, 1, false);
   } else if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
   else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
   else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
   else BASIS_LAUNCH(false, false, 2, 1, 1);
+#undef BASIS_VD
 #undef BASIS_LAUNCH
   ASSX_LAUNCH_CHECK(ctx, "basis_stream_kernel");
   return 0;

@@ -85,6 +85,109 @@ template <typename R>
 __device__ __forceinline__ R ld_so(const R* base, unsigned byte_off) {
   return *reinterpret_cast<const R*>(reinterpret_cast<const char*>(base) + byte_off);
 }
+// ---- buffer addressing (gfx950 raw buffers).  address = descriptor base (wave-uniform, SGPR quad) + soffset
+// (wave-uniform 32-bit) + voffset (per-lane 32-bit): a streaming kernel keeps ONE descriptor per array, the per-row
+// strides as scalar byte offsets and a single per-lane byte offset per block, so a load costs no address VALU at all
+// (the flat `global_load` form needs a 64-bit per-lane add -- or an SGPR pair -- per row).  Offsets are 32-bit:
+// callers guarantee that an utterance's slice of each array is < 4 GiB.
+#if defined(__HIP_DEVICE_COMPILE__)
+// Hide a wave-uniform value from loop-invariant code motion: the row offsets derived from it are then recomputed
+// with a few SALU adds next to the loads instead of being kept live across the whole loop -- where they (with the
+// per-bin constants already resident in SGPRs) overflow the scalar register file and come back as v_readlane +
+// 5 wait states per load.
+__device__ __forceinline__ unsigned sgpr_opaque(unsigned v) {
+  asm volatile("" : "+s"(v));
+  return v;
+}
+// Tie a load's per-lane offset to a value computed earlier (no instruction is emitted): the optimiser may otherwise
+// hoist a ring-slot refill above the last read of the slot, which forces the new data into other registers and a
+// copy -- behind a full vmcnt(0) drain -- at the loop back-edge.
+template <typename R>
+__device__ __forceinline__ unsigned order_after(unsigned voff, R dep) {
+  asm volatile("" : "+v"(voff) : "v"(dep));
+  return voff;
+}
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ BufRsrc make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+// descriptor with the exact extent: loads past `bytes` return zeros (saturates at 4 GiB - 1)
+__device__ __forceinline__ BufRsrc make_rsrc_sized(const void* base, size_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0,
+                                           (int)(bytes > 0xffffffffull ? 0xffffffffull : bytes), 0x00020000);
+}
+typedef unsigned int buf_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int buf_u4 __attribute__((ext_vector_type(4)));
+template <typename R>
+__device__ __forceinline__ Vec2<R> buf_ldv(BufRsrc r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ Vec2<double> buf_ldv<double>(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(Vec2<double>, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+template <>
+__device__ __forceinline__ Vec2<float> buf_ldv<float>(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(Vec2<float>, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+// ---- ring-slot refill that lands in the register the slot already occupies.  The compiler sees an in/out operand,
+// so the new block cannot be given other registers (which would come back as copies at the loop back-edge, behind a
+// vmcnt(0) drain).  The load is invisible to the compiler's vmcnt model: the consumer must call wait_slot<N>() with
+// N = the number of VMEM instructions issued after this refill that may still be in flight.
+__device__ __forceinline__ buf_u4 make_rsrc_words(const void* base, size_t bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  buf_u4 r;
+  r.x = (unsigned)a;
+  r.y = (unsigned)(a >> 32) & 0xffffu;
+  r.z = bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes;
+  r.w = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void buf_ldv_tied(Vec2<double>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void buf_ldv_tied(Vec2<float>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N, typename R>
+__device__ __forceinline__ void wait_slot(Vec2<R> (&x)[2]) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "n"(N) : "memory");
+}
+template <int N, typename R>
+__device__ __forceinline__ void wait_slot(Vec2<R> (&x)[3]) {
+  asm volatile("s_waitcnt vmcnt(%3)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]) : "n"(N) : "memory");
+}
+template <int N, typename R>
+__device__ __forceinline__ void wait_slot(Vec2<R> (&x)[4]) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]) : "n"(N) : "memory");
+}
+template <typename R>
+__device__ __forceinline__ R buf_ld(BufRsrc r, unsigned voff, unsigned soff);
+template <>
+__device__ __forceinline__ double buf_ld<double>(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+template <>
+__device__ __forceinline__ float buf_ld<float>(BufRsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+#else  // host pass: declarations only, so that the kernel templates parse
+struct BufRsrc {};
+__device__ unsigned sgpr_opaque(unsigned v);
+template <typename R>
+__device__ unsigned order_after(unsigned voff, R dep);
+__device__ BufRsrc make_rsrc(const void* base);
+__device__ BufRsrc make_rsrc_sized(const void* base, size_t bytes);
+typedef unsigned int buf_u4 __attribute__((ext_vector_type(4)));
+__device__ buf_u4 make_rsrc_words(const void* base, size_t bytes);
+template <typename R>
+__device__ void buf_ldv_tied(Vec2<R>& dst, buf_u4 rsrc, unsigned voff, unsigned soff);
+template <int N, typename R, int M>
+__device__ void wait_slot(Vec2<R> (&x)[M]);
+template <typename R>
+__device__ Vec2<R> buf_ldv(BufRsrc r, unsigned voff, unsigned soff);
+template <typename R>
+__device__ R buf_ld(BufRsrc r, unsigned voff, unsigned soff);
+#endif
+
 template <typename R>
 __device__ __forceinline__ Cx<R> cadd(Cx<R> a, Cx<R> b) { return cmake<R>(a.x + b.x, a.y + b.y); }
 template <typename R>
@@ -236,5 +339,38 @@ __device__ __forceinline__ bool scatter_leader() {  // one lane per value index 
 // dispatch helpers ---------------------------------------------------------------------------
 template <int V>
 using IntC = std::integral_constant<int, V>;
+template <bool V>
+using BoolC = std::integral_constant<bool, V>;
+// compile-time loop: fn(IntC<0>()), ..., fn(IntC<N-1>())
+template <int N, int I = 0, typename Fn>
+__host__ __device__ __forceinline__ void static_for(Fn&& fn) {
+  if constexpr (I < N) {
+    fn(IntC<I>());
+    static_for<N, I + 1>(fn);
+  }
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Program-order fence for register values: every instruction producing one of a[0..N) is emitted before this point
+// and every consumer after it (no code is generated).  Used to keep the arithmetic that reads a ring slot above the
+// refill of that slot -- plain arithmetic is otherwise free to sink below an asm statement, which keeps the old
+// block live across the refill and forces the new one into other registers.
+template <int B, typename R, int N>
+__device__ __forceinline__ void value_fence_from(R (&a)[N]) {
+  if constexpr (B < N) {
+    asm volatile("" : "+v"(a[B]), "+v"(a[B + 1]), "+v"(a[B + 2]), "+v"(a[B + 3]));
+    value_fence_from<B + 4>(a);
+  }
+}
+template <typename R, int N>
+__device__ __forceinline__ void value_fence(R (&a)[N]) {
+  static_assert(N % 4 == 0, "fence works in groups of 4 values");
+  value_fence_from<0>(a);
+}
+#else
+template <typename R, int N>
+__device__ void value_fence(R (&a)[N]);
+#endif
+
 
 }  // namespace assx

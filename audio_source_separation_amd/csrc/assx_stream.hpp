@@ -81,6 +81,123 @@ constexpr int DX = 4;  // X prefetch depth in 64-frame blocks: keeps >= 4 KB of 
                        // ~50 KB per CU are needed to cover HBM latency at 6 TB/s)
 constexpr int DW = 2;  // prefetch depth of the weight inputs (L2-resident)
 
+
+// ------------------------------------------------------------------------------------------
+// Activation tile through LDS-direct loads (gfx950 `buffer_load_dwordx4 ... lds`).
+//
+// The streaming kernels need, per 64-frame block, NROW = N*KU rows of V (one value per lane and row).  As ordinary
+// vector loads these are the youngest entries of the in-order vmcnt queue exactly when they are needed, so waiting
+// for them also drains every older X load: the X ring never has more than one block in flight however deep it is
+// declared, and a deeper V ring costs 32 VGPRs per stage that the f64 kernels do not have.  Landing the tile in a
+// wave-private LDS ring instead costs no registers: the tile of block i+2 is requested while block i is consumed,
+// `s_waitcnt vmcnt(NI + 2M)` then leaves the X loads of the next two blocks and the next tile in flight.
+// 16 bytes per lane: one instruction covers RPI rows of 64 frames; lane L of instruction j lands at
+// tile + j*RPI*ROW_BYTES + L*16, i.e. the LDS image is simply [row][frame].  Frames past the end of a row read into
+// the next row (or zeros past the end of the buffer: the descriptor carries the exact size) and belong to lanes the
+// kernels mask anyway.
+// ------------------------------------------------------------------------------------------
+template <typename R, int NROW>
+struct VTileDma {
+  static constexpr int LPR = WAVE * (int)sizeof(R) / 16;  // lanes per row
+  static constexpr int RPI = WAVE / LPR;                   // rows per instruction
+  static constexpr int NI = NROW / RPI;                    // instructions per tile
+  static constexpr int ROW_BYTES = WAVE * (int)sizeof(R);
+  static constexpr int TILE_BYTES = NROW * ROW_BYTES;
+  static constexpr int NP = NROW / 2;                      // ds_read2st64 pairs per lane
+  static_assert(NROW % RPI == 0 && NROW % 2 == 0 && (NP == 4 || NP == 6 || NP == 8), "tile geometry");
+  unsigned vro[NI];  // this lane's byte offset (row start + piece) inside the utterance's V, per instruction
+
+  // LDS row rho = n*KU + kk holds V row n*K + min(kk, K-1) (rows beyond K duplicate the last one; their basis is 0)
+  __device__ __forceinline__ void init(int lane, int K, unsigned t_row) {
+    const int grp = lane / LPR, piece = lane % LPR;
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int rho = j * RPI + grp;
+      const int n = rho / KU, kk = rho % KU;
+      vro[j] = (unsigned)(n * K + (kk < K ? kk : K - 1)) * t_row + (unsigned)piece * 16u;
+    }
+  }
+  // request the tile of frame block tb (soff = tb * 64 * sizeof(R)) into the LDS slot at `slot` (wave-uniform)
+  __device__ __forceinline__ void issue(BufRsrc rv, unsigned char* slot, unsigned soff) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (__attribute__((address_space(3))) void*)(slot + j * RPI * ROW_BYTES),
+                                               16, (int)vro[j], (int)soff, 0, 0);
+#endif
+  }
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// this lane's value of every row of a landed tile: o[p] = (row 2p, row 2p+1).  One asm block: the reads and the
+// lgkmcnt wait must not be separated from each other by the scheduler.
+__device__ __forceinline__ void vtile_read(unsigned addr, Vec2<double> (&o)[8]) {
+  asm volatile(
+      "ds_read2st64_b64 %0, %8 offset0:0 offset1:1\n\tds_read2st64_b64 %1, %8 offset0:2 offset1:3\n\t"
+      "ds_read2st64_b64 %2, %8 offset0:4 offset1:5\n\tds_read2st64_b64 %3, %8 offset0:6 offset1:7\n\t"
+      "ds_read2st64_b64 %4, %8 offset0:8 offset1:9\n\tds_read2st64_b64 %5, %8 offset0:10 offset1:11\n\t"
+      "ds_read2st64_b64 %6, %8 offset0:12 offset1:13\n\tds_read2st64_b64 %7, %8 offset0:14 offset1:15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void vtile_read(unsigned addr, Vec2<double> (&o)[6]) {
+  asm volatile(
+      "ds_read2st64_b64 %0, %6 offset0:0 offset1:1\n\tds_read2st64_b64 %1, %6 offset0:2 offset1:3\n\t"
+      "ds_read2st64_b64 %2, %6 offset0:4 offset1:5\n\tds_read2st64_b64 %3, %6 offset0:6 offset1:7\n\t"
+      "ds_read2st64_b64 %4, %6 offset0:8 offset1:9\n\tds_read2st64_b64 %5, %6 offset0:10 offset1:11\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void vtile_read(unsigned addr, Vec2<double> (&o)[4]) {
+  asm volatile(
+      "ds_read2st64_b64 %0, %4 offset0:0 offset1:1\n\tds_read2st64_b64 %1, %4 offset0:2 offset1:3\n\t"
+      "ds_read2st64_b64 %2, %4 offset0:4 offset1:5\n\tds_read2st64_b64 %3, %4 offset0:6 offset1:7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void vtile_read(unsigned addr, Vec2<float> (&o)[8]) {
+  asm volatile(
+      "ds_read2st64_b32 %0, %8 offset0:0 offset1:1\n\tds_read2st64_b32 %1, %8 offset0:2 offset1:3\n\t"
+      "ds_read2st64_b32 %2, %8 offset0:4 offset1:5\n\tds_read2st64_b32 %3, %8 offset0:6 offset1:7\n\t"
+      "ds_read2st64_b32 %4, %8 offset0:8 offset1:9\n\tds_read2st64_b32 %5, %8 offset0:10 offset1:11\n\t"
+      "ds_read2st64_b32 %6, %8 offset0:12 offset1:13\n\tds_read2st64_b32 %7, %8 offset0:14 offset1:15\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void vtile_read(unsigned addr, Vec2<float> (&o)[6]) {
+  asm volatile(
+      "ds_read2st64_b32 %0, %6 offset0:0 offset1:1\n\tds_read2st64_b32 %1, %6 offset0:2 offset1:3\n\t"
+      "ds_read2st64_b32 %2, %6 offset0:4 offset1:5\n\tds_read2st64_b32 %3, %6 offset0:6 offset1:7\n\t"
+      "ds_read2st64_b32 %4, %6 offset0:8 offset1:9\n\tds_read2st64_b32 %5, %6 offset0:10 offset1:11\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ void vtile_read(unsigned addr, Vec2<float> (&o)[4]) {
+  asm volatile(
+      "ds_read2st64_b32 %0, %4 offset0:0 offset1:1\n\tds_read2st64_b32 %1, %4 offset0:2 offset1:3\n\t"
+      "ds_read2st64_b32 %2, %4 offset0:4 offset1:5\n\tds_read2st64_b32 %3, %4 offset0:6 offset1:7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(addr)
+      : "memory");
+}
+
+constexpr int VDMA_SLOTS = 2;  // LDS ring depth of the V tile (8 waves x 2 x 8 KiB = 128 KiB of the CU's 160 KiB)
+
 template <int M>
 __host__ __device__ constexpr int herm_pair_base(int m, int l) {  // requires m < l
   return M + 2 * (m * M - m * (m + 1) / 2 + (l - m - 1));
@@ -110,7 +227,7 @@ struct CovArgs {
 // and 8 weight inputs per lane instead of 64 and 16, which is what lets the TV-weighted f64 kernel keep 2 waves
 // per SIMD without spilling.  The unit of the flat partition is a block of FB = 64 / LS frames.
 // Latency is covered by the DXT-deep X prefetch ring (and a DWT-deep ring of the weight inputs), not by occupancy.
-template <typename R, int M, int WK, bool K4, bool D2, int LS, int DXT, int DWT, int MINW = 1>
+template <typename R, int M, int WK, bool K4, bool D2, int LS, int DXT, int DWT, int MINW = 1, bool VDMA = false>
 __global__ void __launch_bounds__(64, MINW)
     cov_stream_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ rw /* WK_NT (B,N,T) | WK_NFT (B,N,F,T) */,
                       const R* __restrict__ Tb /* WK_TV (B,N,F,K) */, const R* __restrict__ V /* WK_TV (B,N,K,T) */,
@@ -124,6 +241,10 @@ __global__ void __launch_bounds__(64, MINW)
   constexpr int NV = next_pow2_c(NACC);
   static_assert(NV <= FB, "accumulators per lane must not exceed the lanes of a group");
   constexpr int NWV = (WK == WK_TV) ? KU : 1;  // prefetched weight inputs per (source, frame)
+  constexpr bool VD = VDMA && WK == WK_TV && K4;  // V tile through the LDS-direct ring (see VTileDma)
+  static_assert(!VD || (LS == 1 && DXT >= 2), "the LDS ring path walks whole 64-frame blocks");
+  using VT = VTileDma<R, (VD ? SPL * KU : 16)>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vlds[];  // VD: VDMA_SLOTS tiles, wave-private
   const int lane = threadIdx.x & (WAVE - 1);
   const int fl = lane & (FB - 1);              // frame within the block
   const int s0 = (lane / FB) * SPL;            // first source of this lane group
@@ -146,39 +267,82 @@ __global__ void __launch_bounds__(64, MINW)
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0;
 
-  auto issue_x = [&](const Cursor& c, Vec2<R>(&x)[M]) {
+  // Buffer addressing: one descriptor per array (rebased per utterance), per-row strides as wave-uniform byte
+  // offsets (SGPRs, constant for the whole kernel), ONE per-lane byte offset per block.
+  const unsigned x_row = (unsigned)FT * (unsigned)sizeof(Cx<R>);  // X row m starts m * F * T complex in
+  const unsigned t_row = (unsigned)T * (unsigned)sizeof(R);       // one (source, component) row of V / r(n,t)
+
+  // `after`: a value the refill must not overtake (see order_after) -- the last accumulator fed from the slot
+  auto issue_x = [&](const Cursor& c, Vec2<R>(&x)[M], R after) {
     const int t = c.tb * FB + fl;
     const unsigned tc = (unsigned)(t < T ? t : T - 1);
-    // row base = wave-uniform 64-bit pointer (SGPR pair), lane part = 32-bit frame offset: the loads use the
-    // SGPR-base + VGPR-offset addressing form and need no per-lane 64-bit address arithmetic
-    const Cx<R>* xb = X + (size_t)c.b * M * FT;
+    const BufRsrc rx = make_rsrc(X + (size_t)c.b * M * FT);
+    const unsigned voff = order_after(((unsigned)c.f * (unsigned)T + tc) * (unsigned)sizeof(Cx<R>), after);
+    unsigned so = 0;
+    const unsigned step = sgpr_opaque(x_row);
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      const Cx<R>* row = xb + (size_t)((unsigned)(m * F + c.f) * (unsigned)T);
-      x[m] = ldv_so<R>(row, tc * (unsigned)sizeof(Cx<R>));
+      x[m] = buf_ldv<R>(rx, voff, so);
+      so += step;
+    }
+  };
+  // VD path: the refill lands in the registers the slot already occupies (buf_ldv_tied); waits are explicit
+  auto issue_x_tied = [&](const Cursor& c, Vec2<R>(&x)[M]) {
+    const int t = c.tb * FB + fl;
+    const unsigned tc = (unsigned)(t < T ? t : T - 1);
+    const buf_u4 rx = make_rsrc_words(X + (size_t)c.b * M * FT, ~(size_t)0);
+    const unsigned voff = ((unsigned)c.f * (unsigned)T + tc) * (unsigned)sizeof(Cx<R>);
+    unsigned so = 0;
+    const unsigned step = sgpr_opaque(x_row);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      buf_ldv_tied(x[m], rx, voff, so);
+      so += step;
     }
   };
   auto issue_w = [&](const Cursor& c, R(&wv)[SPL][NWV]) {
     const int t = c.tb * FB + fl;
     const unsigned tc = (unsigned)(t < T ? t : T - 1);
+    if (WK == WK_NT) {
+      const BufRsrc rr = make_rsrc(rw + ((size_t)c.b * N + s0) * T);
+      unsigned so = 0;
+      const unsigned step = sgpr_opaque(t_row);
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) {
-      const int n = s0 + j;
-      if (WK == WK_NT) {
-        const R* row = rw + ((size_t)c.b * N + n) * T;
-        wv[j][0] = ld_so<R>(row, tc * (unsigned)sizeof(R));
-      } else if (WK == WK_NFT) {
-        const R* row = rw + (size_t)c.b * N * FT + (size_t)((unsigned)(n * F + c.f) * (unsigned)T);
-        wv[j][0] = ld_so<R>(row, tc * (unsigned)sizeof(R));
-      } else if (WK == WK_TV && K4) {
-        const R* vb = V + (size_t)c.b * N * K * T;
+      for (int j = 0; j < SPL; ++j) {
+        wv[j][0] = buf_ld<R>(rr, tc * (unsigned)sizeof(R), so);
+        so += step;
+      }
+    } else if (WK == WK_NFT) {
+      const BufRsrc rr = make_rsrc(rw + ((size_t)c.b * N + s0) * FT);
+      const unsigned voff = ((unsigned)c.f * (unsigned)T + tc) * (unsigned)sizeof(R);
+      unsigned so = 0;
+      const unsigned step = sgpr_opaque((unsigned)FT * (unsigned)sizeof(R));
+#pragma unroll
+      for (int j = 0; j < SPL; ++j) {
+        wv[j][0] = buf_ld<R>(rr, voff, so);
+        so += step;
+      }
+    } else if (WK == WK_TV && K4) {
+      const BufRsrc rv = make_rsrc(V + ((size_t)c.b * N + s0) * K * T);
+      unsigned so = 0;
+      const unsigned step = sgpr_opaque(t_row);
+#pragma unroll
+      for (int j = 0; j < SPL; ++j)
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk) {
-          const R* row = vb + (size_t)((unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T);
-          wv[j][kk] = ld_so<R>(row, tc * (unsigned)sizeof(R));
+          wv[j][kk] = buf_ld<R>(rv, tc * (unsigned)sizeof(R), so);
+          if (kk < K - 1 || kk == KU - 1) so += step;  // rows beyond K re-read row K-1 (their basis entry is 0)
         }
-      }
     }
+  };
+  VT vt;
+  if (VD) vt.init(lane, K, t_row);
+  // LDS byte address of this lane's column of slot 0
+  const unsigned vlds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)vlds + (unsigned)lane * (unsigned)sizeof(R);
+  auto issue_vtile = [&](const Cursor& c, int slot) {
+    // exact size in the descriptor: a tile reaching past the end of V reads zeros
+    const BufRsrc rv = make_rsrc_sized(V + (size_t)c.b * N * K * T, (size_t)(a.d.B - c.b) * N * K * T * sizeof(R));
+    vt.issue(rv, vlds + slot * VT::TILE_BYTES, (unsigned)c.tb * (unsigned)VT::ROW_BYTES);
   };
   R tbr[SPL][KU];
   auto load_basis_row = [&](const Cursor& c) {
@@ -197,14 +361,17 @@ __global__ void __launch_bounds__(64, MINW)
 
   Vec2<R> xq[DXT][M];
   R wq[DWT][SPL][NWV];
+  if (VD) {  // the tiles go first: they must be OLDER than the X loads issued with them (in-order vmcnt)
 #pragma unroll
-  for (int j = 0; j < DXT; ++j) {
-    if (j < nblk) {
-      issue_x(px, xq[j]);
-      advance(px, TBk, F);
+    for (int j = 0; j < VDMA_SLOTS; ++j) {
+      if (j < nblk) {
+        issue_vtile(pw, j);
+        advance(pw, TBk, F);
+      }
     }
   }
-  if (WK != WK_NONE) {
+  if (WK != WK_NONE && !VD) {  // weights before X, as in the steady state (the loop-header merge of the compiler's
+                               // vmcnt model takes the stricter of the two orders -- forever)
 #pragma unroll
     for (int j = 0; j < DWT; ++j) {
       if (j < nblk) {
@@ -213,95 +380,157 @@ __global__ void __launch_bounds__(64, MINW)
       }
     }
   }
-  load_basis_row(cc);
-
-  for (int it0 = 0; it0 < nblk; it0 += DXT) {
 #pragma unroll
-    for (int j = 0; j < DXT; ++j) {
-      const int it = it0 + j;
-      if (it < nblk) {  // (a `break` here would defeat the unroll and push the ring into scratch)
-        Cx<R> x[M];
-        R wv[SPL][NWV];
+  for (int j = 0; j < DXT; ++j) {
+    if (j < nblk) {
+      if (VD) {
 #pragma unroll
-        for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
-#pragma unroll
-        for (int q = 0; q < SPL; ++q)
-#pragma unroll
-          for (int i = 0; i < NWV; ++i) wv[q][i] = wq[j % DWT][q][i];
-        if (it + DXT < nblk) {
-          issue_x(px, xq[j]);
-          advance(px, TBk, F);
-        }
-        if (WK != WK_NONE && it + DWT < nblk) {
-          issue_w(pw, wq[j % DWT]);
-          advance(pw, TBk, F);
-        }
-        const Cursor cur = cc;
-        advance(cc, TBk, F);
-        const bool more = it + 1 < nblk;
-
-        // ---- consume block `cur`: weights first (frees the weight inputs), Hermitian products once, then one
-        //      weighted accumulate per source
-        const int t = cur.tb * FB + fl;
-        R wgt[SPL];
-#pragma unroll
-        for (int q = 0; q < SPL; ++q) {
-          if (WK == WK_NONE) {
-            wgt[q] = 1;
-          } else {
-            R r;
-            if (WK == WK_TV) {
-              R tv = 0;
-              if (K4) {
-#pragma unroll
-                for (int kk = 0; kk < KU; ++kk) tv = fma(tbr[q][kk], wv[q][kk], tv);
-              } else {
-                const R* tbn = Tb + (((size_t)cur.b * N + s0 + q) * F + cur.f) * K;
-                const R* vb = V + ((size_t)cur.b * N + s0 + q) * K * T + (t < T ? t : T - 1);
-                for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
-              }
-              r = D2 ? tv : powspec<R>(tv, a.p2d);  // R = (T V)^(2/domain), floored AFTER the power (ilrma.py:499-509)
-            } else {
-              r = wv[q][0];
-            }
-            wgt[q] = fast_rcp(floor_eps<R>(r, a.eps));
-          }
-          if (ragged && t >= T) wgt[q] = 0;
-        }
-        // each Hermitian product is formed once and fanned into every source's accumulator right away, so the
-        // M*M products are never all live (saves ~28 VGPRs in f64 -- the margin that keeps 2 waves per SIMD)
-#pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const R pd = cabs2(x[m]);
-#pragma unroll
-          for (int q = 0; q < SPL; ++q) acc[q * HM + m] = fma(wgt[q], pd, acc[q * HM + m]);
-        }
-#pragma unroll
-        for (int m = 0; m < M; ++m)
-#pragma unroll
-          for (int l = m + 1; l < M; ++l) {
-            const Cx<R> pr = cmulc(x[m], x[l]);
-            const int hb = herm_pair_base<M>(m, l);
-#pragma unroll
-            for (int q = 0; q < SPL; ++q) {
-              acc[q * HM + hb] = fma(wgt[q], pr.x, acc[q * HM + hb]);
-              acc[q * HM + hb + 1] = fma(wgt[q], pr.y, acc[q * HM + hb + 1]);
-            }
-          }
-
-        if (cc.tb == 0 || !more) {  // the bin is complete (or the range ends): flush the partial record
-          const R tot = wave_reduce_scatter<R, NV, FB>(acc);
-          const int i = scatter_index<NV, FB>();
-          const int slot = cur.b * F + cur.f - bf_first;
-          if (scatter_leader<NV, FB>() && i < NACC)
-            part[(((size_t)g * a.fp.S + slot) * N + s0) * HM + i] = tot;
-#pragma unroll
-          for (int q = 0; q < NV; ++q) acc[q] = 0;
-          if (more) load_basis_row(cc);
-        }
+        for (int m = 0; m < M; ++m) xq[j][m] = Vec2<R>{0, 0};
+        issue_x_tied(px, xq[j]);
+      } else {
+        issue_x(px, xq[j], (R)0);
       }
+      advance(px, TBk, F);
     }
   }
+  load_basis_row(cc);
+
+  // One block: consume ring slot J, refill it.  STEADY: every refill is known to be in range, so the block is
+  // straight-line code -- the compiler's vmcnt bookkeeping stays exact (with conditional refills it merges the
+  // "not issued" path in and drains the whole queue at every wait, which silently collapses the prefetch ring).
+  auto block = [&](auto jc, auto mode, const int it) {
+    constexpr int j = decltype(jc)::value;
+    constexpr bool STEADY = decltype(mode)::value != 0;  // 0: drain, 1: steady state, 2: first trip (after the prologue)
+    constexpr bool FIRST = decltype(mode)::value == 2;
+    const Cursor cur = cc;
+    advance(cc, TBk, F);
+    const bool more = STEADY || it + 1 < nblk;
+
+    // ---- consume block `cur` straight out of its ring slots: weights first, then the slot is refilled (no
+    //      register copies); Hermitian products once, one weighted accumulate per source, then the X slot is
+    //      refilled
+    const int t = cur.tb * FB + fl;
+    if (VD) {
+      // tile `it` was requested two blocks ago; younger than it are at most the next tile and the X loads of
+      // two blocks (fewer near the end of the range, where everything is drained instead)
+      if (STEADY || it + DXT - 1 < nblk) wait_vmcnt<VT::NI + 2 * M>();
+      else wait_vmcnt<0>();
+      Vec2<R> vv[VT::NP];
+      vtile_read(vlds0 + (unsigned)(it & (VDMA_SLOTS - 1)) * (unsigned)VT::TILE_BYTES, vv);
+#pragma unroll
+      for (int q = 0; q < SPL; ++q)
+#pragma unroll
+        for (int kk = 0; kk < KU; kk += 2) {
+          wq[0][q][kk] = vv[(q * KU + kk) / 2].x;
+          wq[0][q][kk + 1] = vv[(q * KU + kk) / 2].y;
+        }
+    }
+    R wgt[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+      if (WK == WK_NONE) {
+        wgt[q] = 1;
+      } else {
+        R r;
+        if (WK == WK_TV) {
+          R tv = 0;
+          if (K4) {
+#pragma unroll
+            for (int kk = 0; kk < KU; ++kk) tv = fma(tbr[q][kk], wq[VD ? 0 : j % DWT][q][kk], tv);
+          } else {
+            const R* tbn = Tb + (((size_t)cur.b * N + s0 + q) * F + cur.f) * K;
+            const R* vb = V + ((size_t)cur.b * N + s0 + q) * K * T + (t < T ? t : T - 1);
+            for (int k = 0; k < K; ++k) tv = fma(tbn[k], vb[(size_t)k * T], tv);
+          }
+          r = D2 ? tv : powspec<R>(tv, a.p2d);  // R = (T V)^(2/domain), floored AFTER the power (ilrma.py:499-509)
+        } else {
+          r = wq[j % DWT][q][0];
+        }
+        wgt[q] = fast_rcp(floor_eps<R>(r, a.eps));
+      }
+    }
+    if (ragged && cur.tb == TBk - 1) {  // wave-uniform: only the last block of a bin can hold idle lanes
+#pragma unroll
+      for (int q = 0; q < SPL; ++q)
+        if (t >= T) wgt[q] = 0;
+    }
+    if (VD) {
+      if (STEADY || it + VDMA_SLOTS < nblk) {  // this wave has consumed tile `it`: its slot takes tile it + 2
+        issue_vtile(pw, it & (VDMA_SLOTS - 1));
+        advance(pw, TBk, F);
+      }
+    } else if (WK != WK_NONE && (STEADY || it + DWT < nblk)) {
+      issue_w(pw, wq[j % DWT]);
+      advance(pw, TBk, F);
+    }
+    // each Hermitian product is formed once and fanned into every source's accumulator right away, so the
+    // M*M products are never all live
+    if (VD) {
+      // slot `it` was refilled DXT blocks ago; younger: per block in between one tile + one X block, plus the tile
+      // just requested
+      // (first trip: the slot was filled by the prologue, followed only by the other slots' X blocks)
+      if (FIRST) wait_slot<(DXT - 1) * M + VT::NI>(xq[j]);
+      else if (STEADY) wait_slot<(DXT - 1) * (VT::NI + M) + VT::NI>(xq[j]);
+      else wait_slot<0>(xq[j]);
+    }
+    {
+      Cx<R> x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const R pd = cabs2(x[m]);
+#pragma unroll
+        for (int q = 0; q < SPL; ++q) acc[q * HM + m] = fma(wgt[q], pd, acc[q * HM + m]);
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int l = m + 1; l < M; ++l) {
+          const Cx<R> pr = cmulc(x[m], x[l]);
+          const int hb = herm_pair_base<M>(m, l);
+#pragma unroll
+          for (int q = 0; q < SPL; ++q) {
+            acc[q * HM + hb] = fma(wgt[q], pr.x, acc[q * HM + hb]);
+            acc[q * HM + hb + 1] = fma(wgt[q], pr.y, acc[q * HM + hb + 1]);
+          }
+        }
+    }
+    // the refill must stay BELOW the last use of the slot: hoisted above it, the new block lands in other registers
+    // and comes back as a copy at the loop back-edge -- behind a full vmcnt(0) drain
+    __builtin_amdgcn_sched_barrier(0);
+    if (VD) value_fence(acc);  // every accumulate that read the slot is above this line
+    if (STEADY || it + DXT < nblk) {
+      if (VD) issue_x_tied(px, xq[j]);
+      else issue_x(px, xq[j], acc[NACC - 1]);
+      advance(px, TBk, F);
+    }
+
+    if (cc.tb == 0 || !more) {  // the bin is complete (or the range ends): flush the partial record
+      const R tot = wave_reduce_scatter<R, NV, FB>(acc);
+      const int i = scatter_index<NV, FB>();
+      const int slot = cur.b * F + cur.f - bf_first;
+      if (scatter_leader<NV, FB>() && i < NACC)
+        part[(((size_t)g * a.fp.S + slot) * N + s0) * HM + i] = tot;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = 0;
+      if (more) load_basis_row(cc);
+    }
+  };
+
+  // steady state: whole trips of DXT blocks whose refills (X: it + DXT; weights / tile: it + 2 at most) all exist
+  int it0 = 0;
+  if (2 * DXT <= nblk) {
+    static_for<DXT>([&](auto jc) { block(jc, IntC<2>(), decltype(jc)::value); });
+    it0 = DXT;
+  }
+  for (; it0 + 2 * DXT <= nblk; it0 += DXT)
+    static_for<DXT>([&](auto jc) { block(jc, IntC<1>(), it0 + decltype(jc)::value); });
+  // drain: the last blocks, refills guarded
+  for (; it0 < nblk; it0 += DXT)
+    static_for<DXT>([&](auto jc) {
+      if (it0 + decltype(jc)::value < nblk) block(jc, IntC<0>(), it0 + decltype(jc)::value);
+    });
 }
 
 // sum the records covering each bin, scale by 1/T, expand packed Hermitian -> dense U (B,N,F,M,M)
@@ -514,6 +743,188 @@ __global__ void __launch_bounds__(64, MINW)
       }
     }
   }
+}
+
+// K <= KU form of basis_stream_kernel with the activation tile through the LDS-direct ring (VTileDma) and the X
+// slots refilled in place (buf_ldv_tied): same partition, same records, same arithmetic.  All VMEM waits are
+// explicit; per block the issue order is [tile it+2] ... [X it+DXT], which fixes the vmcnt distances used below.
+template <typename R, int M, bool D2, int DXT, int MINW, bool TD>
+__global__ void __launch_bounds__(64, MINW)
+    basis_stream_vd_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
+                           const R* __restrict__ V, R* __restrict__ part, NmfArgs<R> a) {
+  constexpr int N = M;
+  constexpr int NACC = N * KU * 2;
+  constexpr int NV = next_pow2_c(NACC);
+  static_assert(NV <= WAVE && DXT >= 2, "accumulators / ring depth");
+  using VT = VTileDma<R, N * KU>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vlds[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
+  const size_t FT = (size_t)F * T;
+  const int g = blockIdx.x;
+  const long long q0 = (long long)g * a.fp.L;
+  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  if (q0 >= q1) return;
+  const int nblk = (int)(q1 - q0);
+  const int bf_first = (int)(q0 / TBk);
+  Cursor cc;
+  cc.tb = (int)(q0 - (long long)bf_first * TBk);
+  cc.b = bf_first / F;
+  cc.f = bf_first - cc.b * F;
+  Cursor px = cc, pw = cc;
+  const unsigned x_row = (unsigned)FT * (unsigned)sizeof(Cx<R>);
+  const unsigned t_row = (unsigned)T * (unsigned)sizeof(R);
+
+  R acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0;
+
+  auto issue_x_tied = [&](const Cursor& c, Vec2<R>(&x)[M]) {
+    const int t = c.tb * WAVE + lane;
+    const unsigned tc = (unsigned)(t < T ? t : T - 1);
+    const buf_u4 rx = make_rsrc_words(X + (size_t)c.b * M * FT, ~(size_t)0);
+    const unsigned voff = ((unsigned)c.f * (unsigned)T + tc) * (unsigned)sizeof(Cx<R>);
+    unsigned so = 0;
+    const unsigned step = sgpr_opaque(x_row);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      buf_ldv_tied(x[m], rx, voff, so);
+      so += step;
+    }
+  };
+  VT vt;
+  vt.init(lane, K, t_row);
+  const unsigned vlds0 =
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)vlds + (unsigned)lane * (unsigned)sizeof(R);
+  auto issue_vtile = [&](const Cursor& c, int slot) {
+    const BufRsrc rv = make_rsrc_sized(V + (size_t)c.b * N * K * T, (size_t)(a.d.B - c.b) * N * K * T * sizeof(R));
+    vt.issue(rv, vlds + slot * VT::TILE_BYTES, (unsigned)c.tb * (unsigned)VT::ROW_BYTES);
+  };
+  Cx<R> w[N][M];  // demixing rows of the bin: wave-uniform, SGPRs (scalar loads)
+  R tbr[N][KU];   // basis rows of the bin: wave-uniform too, but held in VGPRs (broadcast vector loads) -- together
+                  // with w they would overflow the scalar file and come back as two v_readlane per use
+  const unsigned zero_v = order_after(0u, lane);  // a zero the compiler cannot prove uniform
+  auto load_rows = [&](const Cursor& cu) {  // once per bin
+    const Cx<R>* wp = W + ((size_t)cu.b * F + cu.f) * (N * M);
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int m = 0; m < M; ++m) w[n][m] = wp[n * M + m];
+    const BufRsrc rt = make_rsrc(Tb + (size_t)cu.b * N * F * K);
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const unsigned so = (unsigned)((n * F + cu.f) * K) * (unsigned)sizeof(R);
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) {
+        const R v = buf_ld<R>(rt, zero_v + (unsigned)((kk < K ? kk : 0) * (int)sizeof(R)), so);
+        tbr[n][kk] = (kk < K) ? v : (R)0;
+      }
+    }
+  };
+
+  Vec2<R> xq[DXT][M];
+#pragma unroll
+  for (int j = 0; j < VDMA_SLOTS; ++j) {  // tiles first: older than every X load issued with them
+    if (j < nblk) {
+      issue_vtile(pw, j);
+      advance(pw, TBk, F);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < DXT; ++j) {
+    if (j < nblk) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) xq[j][m] = Vec2<R>{0, 0};
+      issue_x_tied(px, xq[j]);
+      advance(px, TBk, F);
+    }
+  }
+  load_rows(cc);
+
+  auto block = [&](auto jc, auto mode, const int it) {
+    constexpr int j = decltype(jc)::value;
+    constexpr bool STEADY = decltype(mode)::value != 0;  // 0: drain, 1: steady state, 2: first trip
+    constexpr bool FIRST = decltype(mode)::value == 2;
+    const Cursor cur = cc;
+    advance(cc, TBk, F);
+    const bool more = STEADY || it + 1 < nblk;
+    const int t = cur.tb * WAVE + lane;
+
+    // tile `it` (requested two blocks ago): younger are at most the next tile and two X blocks
+    if (STEADY || it + DXT - 1 < nblk) wait_vmcnt<VT::NI + 2 * M>();
+    else wait_vmcnt<0>();
+    Vec2<R> vv[VT::NP];
+    vtile_read(vlds0 + (unsigned)(it & (VDMA_SLOTS - 1)) * (unsigned)VT::TILE_BYTES, vv);
+    if (STEADY || it + VDMA_SLOTS < nblk) {  // the slot is free again: request tile it + 2
+      issue_vtile(pw, it & (VDMA_SLOTS - 1));
+      advance(pw, TBk, F);
+    }
+    // X slot `it` (refilled DXT blocks ago)
+    if (FIRST) wait_slot<(DXT - 1) * M + VT::NI>(xq[j]);
+    else if (STEADY) wait_slot<(DXT - 1) * (VT::NI + M) + VT::NI>(xq[j]);
+    else wait_slot<0>(xq[j]);
+
+    Cx<R> x[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
+    const R live = (t < T) ? (R)1 : (R)0;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+      for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+      R P = cabs2(y);
+      R v[KU];
+#pragma unroll
+      for (int kk = 0; kk < KU; kk += 2) {
+        v[kk] = vv[(n * KU + kk) / 2].x;
+        v[kk + 1] = vv[(n * KU + kk) / 2].y;
+      }
+      R tv = 0;
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) tv = fma(tbr[n][kk], v[kk], tv);
+      tv = floor_eps<R>(tv, a.eps);
+      if (TD) P = t_harmonic<R>(P, tv, a.nu);
+      R inv = fast_rcp(tv);                                 // TV_inverse
+      R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);   // division = P / TV**((d+2)/d)
+      inv *= live;  // frames past the end of the utterance contribute nothing (one multiply, not four selects)
+      D *= live;
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk) {
+        acc[(n * KU + kk) * 2 + 0] = fma(D, v[kk], acc[(n * KU + kk) * 2 + 0]);
+        acc[(n * KU + kk) * 2 + 1] = fma(inv, v[kk], acc[(n * KU + kk) * 2 + 1]);
+      }
+    }
+    value_fence(acc);  // every read of the slot is above this line
+    if (STEADY || it + DXT < nblk) {
+      issue_x_tied(px, xq[j]);
+      advance(px, TBk, F);
+    }
+
+    if (cc.tb == 0 || !more) {
+      const R tot = wave_reduce_scatter<R, NV>(acc);
+      const int i = scatter_index<NV>();
+      const int slot = cur.b * F + cur.f - bf_first;
+      const int n = i / (2 * KU), k = (i >> 1) % KU;
+      if (scatter_leader<NV>() && i < NACC && k < K)
+        part[(((size_t)g * a.fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2 + (i & 1)] = tot;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) acc[q] = 0;
+      if (more) load_rows(cc);
+    }
+  };
+
+  int it0 = 0;
+  if (2 * DXT <= nblk) {
+    static_for<DXT>([&](auto jc) { block(jc, IntC<2>(), decltype(jc)::value); });
+    it0 = DXT;
+  }
+  for (; it0 + 2 * DXT <= nblk; it0 += DXT)
+    static_for<DXT>([&](auto jc) { block(jc, IntC<1>(), it0 + decltype(jc)::value); });
+  for (; it0 < nblk; it0 += DXT)
+    static_for<DXT>([&](auto jc) {
+      if (it0 + decltype(jc)::value < nblk) block(jc, IntC<0>(), it0 + decltype(jc)::value);
+    });
 }
 
 // T *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:417-419)
