@@ -1210,15 +1210,24 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
 #define ACT_LAUNCH(K4V, D2V, DXV, MW) \
   hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
                      (const R*)Tb, (const R*)V, (R*)ws, a)
+  static const int vdma = env_int("ASSX_ACT_VDMA", 1);
+#define ACT_VD(D2V, DXV, MW, TDV) \
+  hipLaunchKernelGGL((act_stream_vd_kernel<R, MM, D2V, DXV, MW, TDV>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
+                     (const R*)Tb, (const R*)V, (R*)ws, a)
   if (nu >= 0.0) {
-    if (k4) hipLaunchKernelGGL((act_stream_kernel<R, MM, true, true, 3, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
+    if (k4 && vdma) ACT_VD(true, 3, 2, true);
+    else if (k4) hipLaunchKernelGGL((act_stream_kernel<R, MM, true, true, 3, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
                                (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
     else hipLaunchKernelGGL((act_stream_kernel<R, MM, false, true, 4, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+  } else if (k4 && vdma) {
+    if (d2) ACT_VD(true, 3, 2, false);
+    else ACT_VD(false, 2, 1, false);
   } else if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
   else if (k4) ACT_LAUNCH(true, false, 2, 1);
   else if (d2) ACT_LAUNCH(false, true, 4, 1);
   else ACT_LAUNCH(false, false, 2, 1);
+#undef ACT_VD
 #undef ACT_LAUNCH
   ASSX_LAUNCH_CHECK(ctx, "act_stream_kernel");
   return 0;

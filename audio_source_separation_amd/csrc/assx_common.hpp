@@ -147,6 +147,17 @@ __device__ __forceinline__ void buf_ldv_tied(Vec2<double>& dst, buf_u4 rsrc, uns
 __device__ __forceinline__ void buf_ldv_tied(Vec2<float>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
   asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// one dword per lane, global -> LDS (lane L lands at lds_addr + 4 L), invisible to the compiler's vmcnt model like
+// buf_ldv_tied.  M0 carries the LDS address; nothing else in these kernels uses M0.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void buf_dword_to_lds(unsigned lds_addr, buf_u4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+               :
+               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory", "m0");
+}
+#pragma clang diagnostic pop
 template <int N, typename R>
 __device__ __forceinline__ void wait_slot(Vec2<R> (&x)[2]) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "n"(N) : "memory");
@@ -182,6 +193,7 @@ template <typename R>
 __device__ void buf_ldv_tied(Vec2<R>& dst, buf_u4 rsrc, unsigned voff, unsigned soff);
 template <int N, typename R, int M>
 __device__ void wait_slot(Vec2<R> (&x)[M]);
+__device__ void buf_dword_to_lds(unsigned lds_addr, buf_u4 rsrc, unsigned voff, unsigned soff);
 template <typename R>
 __device__ Vec2<R> buf_ldv(BufRsrc r, unsigned voff, unsigned soff);
 template <typename R>

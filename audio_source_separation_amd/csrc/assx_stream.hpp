@@ -1240,6 +1240,172 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   }
 }
 
+// K <= KU form of act_stream_kernel.  Every block is a new bin, so the bin's wave-uniform constants -- the N x M
+// demixing rows and the N x K basis rows, 384 bytes in f64 -- change every block: as scalar loads they cannot be
+// prefetched (two sets do not fit the scalar file; one set already spills) and their latency lands on every block.
+// Here they ride an LDS ring: one dword-per-lane LDS-direct load per array and bin, requested DXT bins ahead together
+// with the bin's X block, read back as broadcast LDS loads.  X slots are refilled in place; the only VMEM wait per
+// block is explicit: per bin the issue order is [W row][T rows][X], so a slot is DXT-1 whole bins old when consumed.
+constexpr int ACT_RING_SLOT = 512;  // bytes per bin: W rows at 0 (<= 256), T rows at 256 (<= 128)
+
+template <typename R, int M, bool D2, int DXT, int MINW, bool TD>
+__global__ void __launch_bounds__(64 * ACT_NH, MINW)
+    act_stream_vd_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
+                         const R* __restrict__ V, R* __restrict__ part, NmfArgs<R> a) {
+  constexpr int N = M;
+  constexpr int NACC = N * KU * 2;
+  constexpr int NISS = 2 + M;  // VMEM instructions per bin
+  static_assert(N * M * 2 * (int)sizeof(R) <= 256 && N * KU * (int)sizeof(R) <= 256, "ring slot layout");
+  __shared__ R lds[(ACT_NH - 1) * NACC * WAVE];
+  __shared__ __attribute__((aligned(16))) unsigned char ring[ACT_NH * DXT * ACT_RING_SLOT];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int F = a.d.F, T = a.d.T, K = a.d.K;
+  const int TBk = (T + WAVE - 1) / WAVE;
+  const size_t FT = (size_t)F * T;
+  const int g = blockIdx.x;
+  const long long q0 = (long long)g * a.fp.L;
+  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  if (q0 >= q1) return;
+  const long long bt_first = q0 / F;
+  const long long bt_last = (q1 - 1) / F;
+  const unsigned x_row = (unsigned)FT * (unsigned)sizeof(Cx<R>);
+  unsigned char* myring = ring + h * (DXT * ACT_RING_SLOT);
+  const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)myring;
+  // per-lane source offsets of the two LDS-direct loads (lanes past the end re-read the last dword)
+  const int w_dwords = N * M * 2 * (int)sizeof(R) / 4;
+  const unsigned voff_w = (unsigned)(lane < w_dwords ? lane : w_dwords - 1) * 4u;
+  // basis rows land as [n][KU]: lane = (n, kk, dword of the value); components kk >= K and sources n >= N point
+  // past the end of the descriptor and read zeros, so the consumer needs no `kk < K` tests
+  constexpr int DPV = (int)sizeof(R) / 4;  // dwords per value
+  const int tn = lane / (KU * DPV), tkk = (lane / DPV) % KU;
+  const unsigned voff_t = (tn < N && tkk < K)
+                              ? ((unsigned)tn * (unsigned)F * (unsigned)K + (unsigned)tkk) * (unsigned)sizeof(R) +
+                                    (unsigned)(lane % DPV) * 4u
+                              : 0xfffffff0u;
+
+  for (long long bt = bt_first; bt <= bt_last; ++bt) {  // segments of the range, one frame block each
+    const int b = (int)(bt / TBk), tb = (int)(bt - (long long)b * TBk);
+    const int fa = (int)((q0 > bt * F ? q0 : bt * F) - bt * F);
+    const int fb = (int)((q1 < (bt + 1) * F ? q1 : (bt + 1) * F) - bt * F);
+    const int t = tb * WAVE + lane;
+    const unsigned tc = (unsigned)(t < T ? t : T - 1);
+    R v[N][KU];
+    {
+      const BufRsrc rv = make_rsrc(V + (size_t)b * N * K * T);
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk)
+          v[n][kk] = buf_ld<R>(rv, tc * (unsigned)sizeof(R),
+                               (unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T * (unsigned)sizeof(R));
+    }
+    // the activation columns must have landed before the ring starts: the compiler would otherwise wait for them
+    // with vmcnt(0) inside the loop -- on every trip, since its model merges the loop entry with the back-edge --
+    // and drain the ring (whose loads it cannot see) each time
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < N; ++n) value_fence(v[n]);
+    R acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0;
+
+    const buf_u4 rx = make_rsrc_words(X + (size_t)b * M * FT, ~(size_t)0);
+    const buf_u4 rw = make_rsrc_words(W + (size_t)b * F * N * M, ~(size_t)0);
+    const buf_u4 rt = make_rsrc_words(Tb + (size_t)b * N * F * K, (size_t)N * F * K * sizeof(R));  // exact: OOB = 0
+    // this wave's bins: fa + h, fa + h + ACT_NH, ...
+    const int nmine = (fb - fa - h + ACT_NH - 1) / ACT_NH;
+    auto issue_bin = [&](int f, int slot, Vec2<R>(&x)[M]) {
+      const unsigned la = ring0 + (unsigned)slot * (unsigned)ACT_RING_SLOT;
+      buf_dword_to_lds(la, rw, voff_w, (unsigned)f * (unsigned)(N * M * 2 * (int)sizeof(R)));
+      buf_dword_to_lds(la + 256u, rt, voff_t, (unsigned)f * (unsigned)K * (unsigned)sizeof(R));
+      const unsigned voff = ((unsigned)f * (unsigned)T + tc) * (unsigned)sizeof(Cx<R>);
+      unsigned so = 0;
+      const unsigned step = sgpr_opaque(x_row);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        buf_ldv_tied(x[m], rx, voff, so);
+        so += step;
+      }
+    };
+    Vec2<R> xq[DXT][M];
+#pragma unroll
+    for (int j = 0; j < DXT; ++j)
+      if (j < nmine) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) xq[j][m] = Vec2<R>{0, 0};
+        issue_bin(fa + h + j * ACT_NH, j, xq[j]);
+      }
+
+    auto block = [&](auto jc, auto steady, const int it) {
+      constexpr int j = decltype(jc)::value;
+      constexpr bool STEADY = decltype(steady)::value;
+      const int f = fa + h + it * ACT_NH;
+      if (STEADY) wait_slot<(DXT - 1) * NISS>(xq[j]);  // the bin's W / T rows are older than its X block
+      else wait_slot<0>(xq[j]);
+      Cx<R> x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
+      const Cx<R>* lw = reinterpret_cast<const Cx<R>*>(myring + j * ACT_RING_SLOT);
+      const R* lt = reinterpret_cast<const R*>(myring + j * ACT_RING_SLOT + 256);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) cfma(y, lw[n * M + m], x[m]);
+        R P = cabs2(y);
+        R tk[KU];
+        R tv = 0;
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+          tk[kk] = lt[n * KU + kk];
+          tv = fma(tk[kk], v[n][kk], tv);
+        }
+        tv = floor_eps<R>(tv, a.eps);
+        if (TD) P = t_harmonic<R>(P, tv, a.nu);
+        const R inv = fast_rcp(tv);
+        const R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+          acc[(n * KU + kk) * 2 + 0] = fma(tk[kk], D, acc[(n * KU + kk) * 2 + 0]);
+          acc[(n * KU + kk) * 2 + 1] = fma(tk[kk], inv, acc[(n * KU + kk) * 2 + 1]);
+        }
+        // one source's rows live at a time: hoisting every LDS read to the top of the block costs 96 VGPRs
+        if (n + 1 < N && (n & 1)) __builtin_amdgcn_sched_barrier(0);
+      }
+      value_fence(acc);  // every read of the slot (registers and LDS) is above this line
+      if (STEADY || it + DXT < nmine) issue_bin(f + DXT * ACT_NH, j, xq[j]);
+    };
+    int it0 = 0;
+    for (; it0 + 2 * DXT <= nmine; it0 += DXT)
+      static_for<DXT>([&](auto jc) { block(jc, BoolC<true>(), it0 + decltype(jc)::value); });
+    for (; it0 < nmine; it0 += DXT)
+      static_for<DXT>([&](auto jc) {
+        if (it0 + decltype(jc)::value < nmine) block(jc, BoolC<false>(), it0 + decltype(jc)::value);
+      });
+
+    // combine the ACT_NH bin streams through LDS, then one coalesced partial record per (n, k, num|den)
+    if (h > 0) {
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) lds[((h - 1) * NACC + i) * WAVE + lane] = acc[i];
+    }
+    __syncthreads();
+    if (h == 0) {
+      const int slot = (int)(bt - bt_first);
+      R* out = part + ((size_t)g * a.fp.S + slot) * (size_t)(N * 2 * K) * WAVE + lane;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) {
+        R tot = acc[i];
+#pragma unroll
+        for (int hh = 1; hh < ACT_NH; ++hh) tot += lds[((hh - 1) * NACC + i) * WAVE + lane];
+        const int n = i / (2 * KU), k = (i >> 1) % KU;
+        if (k < K) out[(size_t)(n * 2 * K + k * 2 + (i & 1)) * WAVE] = tot;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // V *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:426-428)
 template <typename R>
 __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __restrict__ part, R* __restrict__ V, int B,
