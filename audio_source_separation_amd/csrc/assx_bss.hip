@@ -980,7 +980,7 @@ inline FlatPart flat_basis(int B, int F, int T) {  // basis_stream_kernel: 1 wav
   return make_flat((long long)B * F * tblocks(T), tblocks(T), g_target(8));
 }
 inline FlatPart flat_act(int B, int F, int T) {    // act_stream_kernel: ACT_NH waves per workgroup, 2 waves/SIMD
-  return make_flat((long long)B * tblocks(T) * F, F, g_target(4));
+  return make_flat((long long)B * tblocks(T) * F, F, g_target(8 / ACT_NH));
 }
 
 inline FlatPart flat_loss(int F, int T) {  // loss_stream_kernel: per-utterance partition (grid.y = B)

@@ -1113,7 +1113,7 @@ __global__ void __launch_bounds__(64, MINW)
 //      bins of the same frame block, each wave handling all N sources; the streams are combined through LDS.
 //      items = (b, tb, f), len = F.   part[g][slot][n][k][{num,den}][64]
 // ------------------------------------------------------------------------------------------
-constexpr int ACT_NH = 2;
+constexpr int ACT_NH = 4;
 
 template <typename R, int M, bool K4, bool D2, int DXT, int MINW = 1, bool TD = false>
 __global__ void __launch_bounds__(64 * ACT_NH, MINW)
