@@ -1598,13 +1598,23 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
 #define LOSS_LAUNCH(K4V, D2V, DXV, DWV, MW, TDV)                                                                \
   hipLaunchKernelGGL((loss_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW, TDV>), grid, blk, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lstride, a, p2d)
-    if (nu >= 0.0) {
+    static const int vdma = env_int("ASSX_LOSS_VDMA", 1);
+    constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, MM * KU>::TILE_BYTES;
+#define LOSS_VD(D2V, MW, TDV)                                                                                    \
+  hipLaunchKernelGGL((loss_stream_vd_kernel<R, MM, D2V, 2, MW, TDV>), grid, blk, vlds, st, (const Cx<R>*)X,      \
+                     (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lstride, a, p2d)
+    if (k4 && vdma) {
+      if (nu >= 0.0) LOSS_VD(true, 2, true);
+      else if (d2) LOSS_VD(true, 2, false);
+      else LOSS_VD(false, 1, false);
+    } else if (nu >= 0.0) {
       if (k4) LOSS_LAUNCH(true, true, 4, 1, 1, true);
       else LOSS_LAUNCH(false, true, 4, 1, 1, true);
     } else if (k4 && d2) LOSS_LAUNCH(true, true, 4, 1, 2, false);
     else if (k4) LOSS_LAUNCH(true, false, 2, 1, 1, false);
     else if (d2) LOSS_LAUNCH(false, true, 4, 1, 2, false);
     else LOSS_LAUNCH(false, false, 2, 1, 1, false);
+#undef LOSS_VD
 #undef LOSS_LAUNCH
     ASSX_LAUNCH_CHECK(ctx, "loss_stream_kernel");
     hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W,

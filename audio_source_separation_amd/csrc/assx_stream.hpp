@@ -1108,6 +1108,166 @@ __global__ void __launch_bounds__(64, MINW)
   if (lane == 0) lpart[(size_t)b * lstride + g] = acc;
 }
 
+// K <= KU form of loss_stream_kernel on the LDS-direct activation ring (same pipeline as basis_stream_vd_kernel).
+template <typename R, int M, bool D2, int DXT, int MINW, bool TD>
+__global__ void __launch_bounds__(64, MINW)
+    loss_stream_vd_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
+                          const R* __restrict__ V, double* __restrict__ lpart, int lstride, NmfArgs<R> a, PowSpec p2d) {
+  constexpr int N = M;
+  static_assert(DXT >= 2, "ring depth");
+  using VT = VTileDma<R, N * KU>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char vlds[];
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
+  const size_t FT = (size_t)F * T;
+  const int g = blockIdx.x, b = blockIdx.y;
+  const long long q0 = (long long)g * a.fp.L;
+  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  double acc = 0.0;
+  double lm = 1.0, tm = 1.0;  // running mantissa products of R and of 1 + (2/nu) P/R (see loss_stream_kernel)
+  int le = 0, te = 0;
+  if (q0 < q1) {
+    const int nblk = (int)(q1 - q0);
+    Cursor cc;
+    cc.f = (int)(q0 / TBk);
+    cc.tb = (int)(q0 - (long long)cc.f * TBk);
+    cc.b = b;
+    Cursor px = cc, pw = cc;
+    const unsigned x_row = (unsigned)FT * (unsigned)sizeof(Cx<R>);
+    const unsigned t_row = (unsigned)T * (unsigned)sizeof(R);
+    const buf_u4 rx = make_rsrc_words(X + (size_t)b * M * FT, ~(size_t)0);
+    const BufRsrc rv = make_rsrc_sized(V + (size_t)b * N * K * T, (size_t)(a.d.B - b) * N * K * T * sizeof(R));
+    auto issue_x_tied = [&](const Cursor& c, Vec2<R>(&x)[M]) {
+      const int t = c.tb * WAVE + lane;
+      const unsigned tc = (unsigned)(t < T ? t : T - 1);
+      const unsigned voff = ((unsigned)c.f * (unsigned)T + tc) * (unsigned)sizeof(Cx<R>);
+      unsigned so = 0;
+      const unsigned step = sgpr_opaque(x_row);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        buf_ldv_tied(x[m], rx, voff, so);
+        so += step;
+      }
+    };
+    VT vt;
+    vt.init(lane, K, t_row);
+    const unsigned vlds0 =
+        (unsigned)(size_t)(__attribute__((address_space(3))) void*)vlds + (unsigned)lane * (unsigned)sizeof(R);
+    auto issue_vtile = [&](const Cursor& c, int slot) {
+      vt.issue(rv, vlds + slot * VT::TILE_BYTES, (unsigned)c.tb * (unsigned)VT::ROW_BYTES);
+    };
+    Cx<R> w[N][M];
+    R tbr[N][KU];
+    const unsigned zero_v = order_after(0u, lane);
+    auto load_rows = [&](const Cursor& cu) {  // once per bin: w -> SGPRs, basis rows -> VGPRs (see basis_stream_vd_kernel)
+      const Cx<R>* wp = W + ((size_t)b * F + cu.f) * (N * M);
+#pragma unroll
+      for (int n = 0; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < M; ++m) w[n][m] = wp[n * M + m];
+      const BufRsrc rt = make_rsrc(Tb + (size_t)b * N * F * K);
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const unsigned so = (unsigned)((n * F + cu.f) * K) * (unsigned)sizeof(R);
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) {
+          const R v = buf_ld<R>(rt, zero_v + (unsigned)((kk < K ? kk : 0) * (int)sizeof(R)), so);
+          tbr[n][kk] = (kk < K) ? v : (R)0;
+        }
+      }
+    };
+    Vec2<R> xq[DXT][M];
+#pragma unroll
+    for (int j = 0; j < VDMA_SLOTS; ++j) {
+      if (j < nblk) {
+        issue_vtile(pw, j);
+        advance(pw, TBk, F);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < DXT; ++j) {
+      if (j < nblk) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) xq[j][m] = Vec2<R>{0, 0};
+        issue_x_tied(px, xq[j]);
+        advance(px, TBk, F);
+      }
+    }
+    load_rows(cc);
+
+    auto block = [&](auto jc, auto mode, const int it) {
+      constexpr int j = decltype(jc)::value;
+      constexpr bool STEADY = decltype(mode)::value != 0;
+      constexpr bool FIRST = decltype(mode)::value == 2;
+      const Cursor cur = cc;
+      advance(cc, TBk, F);
+      const int t = cur.tb * WAVE + lane;
+      if (STEADY || it + DXT - 1 < nblk) wait_vmcnt<VT::NI + 2 * M>();
+      else wait_vmcnt<0>();
+      Vec2<R> vv[VT::NP];
+      vtile_read(vlds0 + (unsigned)(it & (VDMA_SLOTS - 1)) * (unsigned)VT::TILE_BYTES, vv);
+      if (STEADY || it + VDMA_SLOTS < nblk) {
+        issue_vtile(pw, it & (VDMA_SLOTS - 1));
+        advance(pw, TBk, F);
+      }
+      if (FIRST) wait_slot<(DXT - 1) * M + VT::NI>(xq[j]);
+      else if (STEADY) wait_slot<(DXT - 1) * (VT::NI + M) + VT::NI>(xq[j]);
+      else wait_slot<0>(xq[j]);
+      Cx<R> x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
+      double term = 0.0, rprod = 1.0, tprod = 1.0;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+        R tv = 0;
+#pragma unroll
+        for (int kk = 0; kk < KU; kk += 2) {
+          tv = fma(tbr[n][kk], vv[(n * KU + kk) / 2].x, tv);
+          tv = fma(tbr[n][kk + 1], vv[(n * KU + kk) / 2].y, tv);
+        }
+        const R r = floor_eps<R>(D2 ? tv : powspec<R>(tv, p2d), a.eps);
+        if (TD) tprod *= fma((double)((R)2 * fast_rcp(a.nu)), (double)(cabs2(y) * fast_rcp(r)), 1.0);
+        else term += (double)(cabs2(y) * fast_rcp(r));
+        rprod *= (double)r;
+      }
+      if (t < T) {
+        acc += term;
+        int e;
+        lm = frexp(lm * rprod, &e);
+        le += e;
+        if (TD) {
+          tm = frexp(tm * tprod, &e);
+          te += e;
+        }
+      }
+      asm volatile("" : "+v"(acc), "+v"(lm), "+v"(tm));  // the slot has been read: the refill may follow
+      if (STEADY || it + DXT < nblk) {
+        issue_x_tied(px, xq[j]);
+        advance(px, TBk, F);
+      }
+      if (cc.tb == 0 && (STEADY || it + 1 < nblk)) load_rows(cc);
+    };
+    int it0 = 0;
+    if (2 * DXT <= nblk) {
+      static_for<DXT>([&](auto jc) { block(jc, IntC<2>(), decltype(jc)::value); });
+      it0 = DXT;
+    }
+    for (; it0 + 2 * DXT <= nblk; it0 += DXT)
+      static_for<DXT>([&](auto jc) { block(jc, IntC<1>(), it0 + decltype(jc)::value); });
+    for (; it0 < nblk; it0 += DXT)
+      static_for<DXT>([&](auto jc) {
+        if (it0 + decltype(jc)::value < nblk) block(jc, IntC<0>(), it0 + decltype(jc)::value);
+      });
+  }
+  acc += (double)le * 0.6931471805599453 + log(lm);
+  if (TD) acc += (1.0 + 0.5 * (double)a.nu) * ((double)te * 0.6931471805599453 + log(tm));
+  acc = wave_allreduce_sum<double>(acc);
+  if (lane == 0) lpart[(size_t)b * lstride + g] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // (a2) activation half (reduce over f).  Lanes own 64 frames; a workgroup = ACT_NH waves walking interleaved
 //      bins of the same frame block, each wave handling all N sources; the streams are combined through LDS.
