@@ -15,6 +15,6 @@ for d in ("$ROOT/gpurun_out/${TAG}_a","$ROOT/gpurun_out/${TAG}_b"):
         for r in csv.DictReader(open(f)):
             agg[r['Kernel_Name'][:60]][r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items():
-        if 'stream_kernel' in k and 'finalize' not in k:
+        if 'stream' in k and 'finalize' not in k:
             print(k, {c: round(sum(x)/len(x)) for c,x in v.items()})
 PY
