@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--steps", type=int, default=500)
+    p.add_argument("--warmup", type=int, default=50)
     p.add_argument("--dtype", default="float64", choices=["float64", "float32"],
                    help="storage/compute type of the kernels; float64 = the reference's complex128 path")
     p.add_argument("--utterances-per-gpu", type=int, default=1)
