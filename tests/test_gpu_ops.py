@@ -4,6 +4,8 @@ Tolerances (relative Frobenius error unless stated):
   float64 storage: 1e-11 for single reductions/contractions (summation order differs), 1e-9 after an IP sweep.
   float32 storage: 2e-5 for single reductions, 2e-3 after an IP sweep (cond(WU) amplifies rounding).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -397,3 +399,73 @@ def test_tilrma_stages(eng, M, K, nu):
     W1, _ = orc.tilrma_spatial_update(X, W, T1, V1, nu)
     assert int(st.item()) == 0
     assert rel_err(host(Wd)[0], W1) < tol(eng, 1e-9, 2e-3)
+
+
+@pytest.fixture
+def few_workgroups():
+    """Force the flat partitions down to a handful of workgroups (ASSX_G), so that a small input gives every workgroup
+    a long range: several trips of the steady-state loop, the first-trip and drain code, ranges that start and end in
+    the middle of a bin and flush several partial records -- the paths a full-size utterance exercises."""
+    def _set(g):
+        os.environ["ASSX_G"] = str(g)
+    yield _set
+    os.environ.pop("ASSX_G", None)
+
+
+@pytest.mark.parametrize("G", [5, 16])
+@pytest.mark.parametrize("M,K,T", [(4, 4, 1030), (3, 2, 1500), (2, 3, 1024), (4, 6, 700)])
+def test_streaming_kernels_long_ranges(eng, few_workgroups, G, M, K, T):
+    few_workgroups(G)
+    F = 19
+    X, W = mixture(M, F, T, 100 + M), rand_filters(M, F, 101)
+    rng = np.random.default_rng(102 + K)
+    Tb, V = rng.random((M, F, K)) + 0.05, rng.random((M, K, T)) + 0.05
+    Xd, Wd = dev_c(eng, X[None]), dev_c(eng, W[None])
+    # loss
+    got = float(eng.ilrma_loss(Xd, Wd, dev_r(eng, Tb[None]), dev_r(eng, V[None])).item())
+    ref = orc.ilrma_loss(X, W, Tb, V, 2)
+    np.testing.assert_allclose(got, ref, rtol=tol(eng, 1e-12, 1e-5))
+    # source model
+    Td, Vd = dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    eng.ilrma_source_update(Xd, Wd, Td, Vd)
+    T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(X, W)) ** 2, Tb, V, 2)
+    assert rel_err(host(Td)[0], T1) < tol(eng, 1e-11, 5e-5)
+    assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
+    # spatial model
+    Ud = eng.empty((1, M, F, M, M), complex_=True)
+    st = eng.new_status(1)
+    Wd2 = dev_c(eng, W[None])
+    eng.ilrma_spatial_update(Xd, Wd2, dev_r(eng, T1[None]), dev_r(eng, V1[None]), status=st, U_out=Ud)
+    Wref, Uref, mask = orc.ilrma_spatial_update_ip(X, W.copy(), T1, V1, 2)
+    assert mask.all() and int(st.item()) == 0
+    assert rel_err(host(Ud)[0], Uref) < tol(eng, 1e-12, 2e-5)
+    assert rel_err(host(Wd2)[0], Wref) < tol(eng, 1e-9, 2e-3)
+    # AuxIVA-style weights given per (n, t) and plain covariance take the same kernel with other weight kinds
+    r = rng.random((M, T)) + 0.1
+    U2 = eng.cov_accumulate(Xd, dev_r(eng, r[None]))
+    assert rel_err(host(U2)[0], orc.weighted_covariance(X, r)) < tol(eng, 1e-12, 2e-5)
+
+
+@pytest.mark.parametrize("G", [3, 16])
+def test_streaming_kernels_long_ranges_two_utterances(eng, few_workgroups, G):
+    """Ranges that cross an utterance boundary (descriptor rebasing) with a ragged frame count."""
+    few_workgroups(G)
+    M, K, F, T = 4, 4, 11, 700
+    rng = np.random.default_rng(120)
+    Xs = [mixture(M, F, T, 121 + b) for b in range(2)]
+    Ws = [rand_filters(M, F, 123 + b) for b in range(2)]
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Xd, Wd = dev_c(eng, np.stack(Xs)), dev_c(eng, np.stack(Ws))
+    Td, Vd = dev_r(eng, Tb), dev_r(eng, V)
+    loss = host(eng.ilrma_loss(Xd, Wd, Td, Vd))
+    eng.ilrma_source_update(Xd, Wd, Td, Vd)
+    st = eng.new_status(2)
+    Wd2 = Wd.clone()
+    eng.ilrma_spatial_update(Xd, Wd2, Td, Vd, status=st)
+    for b in range(2):
+        np.testing.assert_allclose(loss[b], orc.ilrma_loss(Xs[b], Ws[b], Tb[b], V[b], 2), rtol=tol(eng, 1e-12, 1e-5))
+        T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], Ws[b])) ** 2, Tb[b], V[b], 2)
+        assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
+        Wref, _, _ = orc.ilrma_spatial_update_ip(Xs[b], Ws[b].copy(), T1, V1, 2)
+        assert rel_err(host(Wd2)[b], Wref) < tol(eng, 1e-9, 2e-3)
