@@ -1045,8 +1045,10 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
   ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");                              \
   ASSX_REQUIRE(ctx, (B) >= 1 && (M) >= 1 && (F) >= 1 && (T) >= 1, ASSX_E_ARG,                 \
                "invalid sizes B=%d M=%d F=%d T=%d", (B), (M), (F), (T));                       \
-  ASSX_REQUIRE(ctx, (long long)(M) * (F) * (T) < (1LL << 31) && (long long)(B) * (F) * (((T) + 31) / 32 + 1) < (1LL << 31), \
-               ASSX_E_UNSUPPORTED, "utterance too large for 32-bit in-kernel offsets (M*F*T and B*F*T/32 must be < 2^31)")
+  ASSX_REQUIRE(ctx, (long long)(M) * (F) * (T) < (1LL << 28) && (long long)(B) * (F) * (((T) + 31) / 32 + 1) < (1LL << 31), \
+               ASSX_E_UNSUPPORTED,                                                                                       \
+               "utterance too large: buffer offsets are 32-bit, one utterance must stay below 4 GiB in complex128 "     \
+               "(M*F*T < 2^28) and B*F*T/32 below 2^31")
 
 inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 

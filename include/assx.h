@@ -18,7 +18,8 @@
  *         U  (B, N, F, M, M) complex   weighted spatial covariance  ilrma.py:511
  *         Y  (B, N, F, T) complex      separated estimate           ilrma.py:153-165
  *     complex = interleaved (re, im) of the real type selected by `dtype`.
- *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 4.
+ *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 4; one utterance must stay
+ *     below 4 GiB in complex128 (M*F*T < 2^28: in-kernel buffer offsets are 32-bit), any number of utterances.
  *   - dtype: ASSX_F32 (float / complex64) or ASSX_F64 (double / complex128 = the reference's).
  *   - `ws` is caller-owned device scratch of at least assx_workspace_bytes() bytes.
  *   - `status` is a device int32[B]; kernels OR flags into it (ASSX_STATUS_*), never clear it.

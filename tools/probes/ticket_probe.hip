@@ -2,13 +2,16 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#ifndef STAGGER
+#define STAGGER 1
+#endif
 template <int MODE>
 __global__ void __launch_bounds__(64) k(double* rec, int* ticket, double* out, int per, int* err) {
   const int g = blockIdx.x, lane = threadIdx.x;
   const int grp = g / per;
   // a little work so that workgroups finish at different times
   double s = 0;
-  for (int i = 0; i < (g % 7) * 200; ++i) s += sin((double)(i + lane));
+  for (int i = 0; i < STAGGER * (g % 7) * 200 + 50; ++i) s += sin((double)(i + lane));
   if (lane < 32) {
     if (MODE == 0) rec[(size_t)g * 32 + lane] = (double)(g * 100 + lane) + (s * 0.0);
     else __hip_atomic_store(&rec[(size_t)g * 32 + lane], (double)(g * 100 + lane) + (s * 0.0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
