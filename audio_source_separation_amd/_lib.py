@@ -36,7 +36,7 @@ SIGNATURES = {
     "assx_demix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_cov_accumulate": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),
-    "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, ctypes.c_uint, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_source_update": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, ctypes.c_uint, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_expand_partitioned": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_source_update_partitioned": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_normalize_power_bins_partitioned": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -45,6 +45,9 @@ class DeviceArray:
         return ent.host
 
     def __set__(self, obj, value):
+        resolve = getattr(obj, "_resolve_deferred_loss", None)
+        if resolve is not None:
+            resolve()  # a loss still to be folded into the next pass refers to the state being replaced
         if isinstance(value, torch.Tensor):
             self._store(obj)[self.name] = _Entry(host=None, dev=None)
             self._store(obj)[self.name].host = to_numpy(value, np.complex128 if self.complex_ else np.float64)

@@ -68,6 +68,7 @@ class ILRMAbase(DeviceState):
         self.device = device
         self._engine = None
         self._estimation = None
+        self._deferred_loss = None  # device scalar(s) appended to `loss` whose value the next basis pass will write
 
     # ------------------------------------------------------------------ device plumbing
     def _require_supported(self):
@@ -296,6 +297,8 @@ class GaussILRMA(ILRMAbase):
 
             self._run_callbacks()
 
+        self._resolve_deferred_loss()  # the loss of the last iteration has no next pass to ride on
+
         # final projection back (ilrma.py:258-273); scale and y = W x in two small passes over X
         eng = self._engine
         scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
@@ -312,6 +315,7 @@ class GaussILRMA(ILRMAbase):
         return output
 
     def _reset(self, **kwargs):
+        self._resolve_deferred_loss()
         super()._reset(**kwargs)
         if self.partitioning:
             assert self.domain == 2, "Not support domain = {}".format(self.domain)
@@ -376,8 +380,9 @@ class GaussILRMA(ILRMAbase):
                                                          eps=self.eps)
             self._touch("Z", "T", "V")
             return
+        loss_prev, self._deferred_loss = self._deferred_loss, None
         self._engine.ilrma_source_update(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
-                                         sources=sources)
+                                         sources=sources, loss_prev=loss_prev)
         self._touch("T", "V")
 
     def _power_bins(self):
@@ -419,8 +424,25 @@ class GaussILRMA(ILRMAbase):
         self._touch("W")
         self._estimation = None
 
+    def _resolve_deferred_loss(self):
+        """Compute a loss value that was left for the next basis pass, now, with the stand-alone kernel."""
+        buf, self._deferred_loss = self._deferred_loss, None
+        if buf is not None:
+            self._engine.ilrma_loss(self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps, out=buf)
+
     def _record_loss(self):
-        """Append the current loss without a host sync (the value stays in HBM until `loss` is read)."""
+        """Append the current loss without a host sync (the value stays in HBM until `loss` is read).
+
+        Without a partitioning function and callbacks the value is not even computed here: the basis pass of the next
+        iteration forms the same y = W x and T V and accumulates the loss on the way (`loss_prev` of
+        assx_ilrma_source_update); whoever reads `loss`, replaces a model array or ends the call first triggers the
+        stand-alone kernel instead."""
+        if isinstance(self.loss, LazyLossList) and not self.partitioning and self.callbacks is None:
+            self._resolve_deferred_loss()
+            self._deferred_loss = self._engine.empty((self._X.shape[0],), dtype=torch.float64)
+            self.loss.before_flush = self._resolve_deferred_loss
+            self.loss.append_device(self._deferred_loss, self._batched)
+            return
         Tb, V = self._model()
         loss = self._engine.ilrma_loss(self._X, self._Wd, Tb, V, domain=self.domain, eps=self.eps)
         if isinstance(self.loss, LazyLossList):

@@ -1158,7 +1158,8 @@ int run_ip2(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, 
 template <typename R, int MM>
 int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain,
                       double eps, void* ws, int B, int F, int T, int K, hipStream_t st, FlatPart* fp_out,
-                      double nu = -1.0 /* >= 0: t-ILRMA harmonic statistic (domain 2) */) {
+                      double nu = -1.0 /* >= 0: t-ILRMA harmonic statistic (domain 2) */,
+                      double* lpart = nullptr /* fused loss partials (see basis_loss_fusable) */, int lstride = 0) {
   NmfArgs<R> a;
   a.nu = (R)nu;
   a.d = Dims{B, F, T, K};
@@ -1175,7 +1176,7 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
   constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, MM * KU>::TILE_BYTES;
 #define BASIS_VD(D2V, MW, TDV) \
   hipLaunchKernelGGL((basis_stream_vd_kernel<R, MM, D2V, 2, MW, TDV>), gb, bb, vlds, st, (const Cx<R>*)X, \
-                     (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
+                     (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a, (double*)nullptr, 0)
   if (nu >= 0.0) {
     if (k4 && vdma) BASIS_VD(true, 2, true);
     else if (k4) hipLaunchKernelGGL((basis_stream_kernel<R, MM, true, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
@@ -1183,7 +1184,10 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
     else hipLaunchKernelGGL((basis_stream_kernel<R, MM, false, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
   } else if (k4 && vdma) {
-    if (d2) BASIS_VD(true, 2, false);
+    if (d2 && lpart)
+      hipLaunchKernelGGL((basis_stream_vd_kernel<R, MM, true, 2, 2, false, true>), gb, bb, vlds, st, (const Cx<R>*)X,
+                         (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a, lpart, lstride);
+    else if (d2) BASIS_VD(true, 2, false);
     else BASIS_VD(false, 1, false);
   } else if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
   else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
@@ -1317,9 +1321,14 @@ int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, 
   });
 }
 
+// forward declaration (defined with the loss entry points)
+static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const void* W, const void* Tb,
+                           const void* V, double domain, double nu, double eps, double* loss, void* ws, int B, int M,
+                           int F, int T, int K, int dtype, void* stream);
+
 int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double domain, double eps,
-                             unsigned source_mask, void* ws, int B, int M, int F, int T, int K, int dtype,
-                             void* stream) {
+                             unsigned source_mask, double* loss_prev, void* ws, int B, int M, int F, int T, int K,
+                             int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_source_update: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
@@ -1330,8 +1339,39 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     constexpr int MM = decltype(mt)::value;
     const PowSpec p2 = make_pow(domain / (domain + 2.0));
     FlatPart fp;
-    int rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp);
+    int rc;
+    // loss of the model at entry: fused into the basis pass where that pass forms the same quantities (domain 2,
+    // K <= 4, LDS-ring kernel), otherwise a pass of its own before anything is updated
+    double* lpart = nullptr;
+    int lstride = 0;
+    if (loss_prev) {
+      const bool fusable = domain == 2.0 && K <= KU && env_int("ASSX_BASIS_VDMA", 1) && env_int("ASSX_FUSE_LOSS", 1);
+      if (!fusable) {
+        rc = ilrma_loss_impl(ctx, "assx_ilrma_source_update", X, W, Tb, V, domain, -1.0, eps, loss_prev, ws, B, MM, F, T,
+                             K, dtype, stream);
+        if (rc) return rc;
+      } else {
+        const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+        const FlatPart fb = flat_basis(B, F, T);
+        const int ncov = (int)(((long long)F * tblocks(T) + fb.L - 1) / fb.L) + 1;  // workgroups touching one utterance
+        lstride = ncov + F;  // [per-workgroup data terms | F log-det terms]
+        ASSX_REQUIRE(ctx, (size_t)B * lstride * sizeof(double) <= L.small - L.lpart, ASSX_E_UNSUPPORTED,
+                     "workspace too small for the fused loss partials");
+        lpart = (double*)((char*)ws + L.lpart);
+        hipError_t e = hipMemsetAsync(lpart, 0, (size_t)B * lstride * sizeof(double), st);
+        if (e != hipSuccess) return fail(ctx, (int)e, "hipMemsetAsync(loss partials): %s", hipGetErrorString(e));
+        hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st,
+                           (const Cx<R>*)W, lpart, B, F, T, lstride, ncov);
+        ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
+      }
+    }
+    rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp, -1.0, lpart, lstride);
     if (rc) return rc;
+    if (lpart) {
+      hipLaunchKernelGGL((sum_reduce_kernel<double, double>), dim3(B), dim3(REDUCE_THREADS), 0, st,
+                         (const double*)lpart, loss_prev, (size_t)lstride, 1.0);
+      ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+    }
     hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
                        st, (const R*)ws, (R*)Tb, B, MM, F, K, fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");

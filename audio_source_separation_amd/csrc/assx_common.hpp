@@ -132,6 +132,11 @@ __device__ __forceinline__ Vec2<float> buf_ldv<float>(BufRsrc r, unsigned voff, 
 // so the new block cannot be given other registers (which would come back as copies at the loop back-edge, behind a
 // vmcnt(0) drain).  The load is invisible to the compiler's vmcnt model: the consumer must call wait_slot<N>() with
 // N = the number of VMEM instructions issued after this refill that may still be in flight.
+// It is invisible to the hazard recogniser too: a scalar operand (descriptor, soffset) that the compiler has just
+// produced with a VALU instruction -- v_readlane of a spilled SGPR is the usual one -- needs 5 wait states before a
+// VMEM instruction may read it, and nothing inserts them inside an asm statement.  Without the `s_nop 4` the load
+// uses the register's previous contents whenever register pressure puts such a reload right in front of it
+// (found as a page fault: the soffset was the low word of an unrelated pointer).
 __device__ __forceinline__ buf_u4 make_rsrc_words(const void* base, size_t bytes) {
   const unsigned long long a = (unsigned long long)base;
   buf_u4 r;
@@ -142,17 +147,17 @@ __device__ __forceinline__ buf_u4 make_rsrc_words(const void* base, size_t bytes
   return r;
 }
 __device__ __forceinline__ void buf_ldv_tied(Vec2<double>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void buf_ldv_tied(Vec2<float>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("buffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 // one dword per lane, global -> LDS (lane L lands at lds_addr + 4 L), invisible to the compiler's vmcnt model like
 // buf_ldv_tied.  M0 carries the LDS address; nothing else in these kernels uses M0.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void buf_dword_to_lds(unsigned lds_addr, buf_u4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds"
                :
                : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                : "memory", "m0");

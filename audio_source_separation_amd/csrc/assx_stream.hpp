@@ -748,10 +748,16 @@ __global__ void __launch_bounds__(64, MINW)
 // K <= KU form of basis_stream_kernel with the activation tile through the LDS-direct ring (VTileDma) and the X
 // slots refilled in place (buf_ldv_tied): same partition, same records, same arithmetic.  All VMEM waits are
 // explicit; per block the issue order is [tile it+2] ... [X it+DXT], which fixes the vmcnt distances used below.
-template <typename R, int M, bool D2, int DXT, int MINW, bool TD>
+// LOSS (domain 2, Gaussian model): the pass also accumulates the data term of the negative log-likelihood of the
+// model it reads -- sum_{n,t} P/R + log R with the very y = W x and R = max(T V, eps) it forms anyway (ilrma.py:672-675)
+// -- so recording the loss of iteration i costs ~16 instructions per block of iteration i+1's basis pass instead of
+// a pass over X of its own.  One partial per (utterance, covering workgroup): lpart[b][g - first workgroup of b].
+template <typename R, int M, bool D2, int DXT, int MINW, bool TD, bool LOSS = false>
 __global__ void __launch_bounds__(64, MINW)
     basis_stream_vd_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb,
-                           const R* __restrict__ V, R* __restrict__ part, NmfArgs<R> a) {
+                           const R* __restrict__ V, R* __restrict__ part, NmfArgs<R> a, double* __restrict__ lpart,
+                           int lstride) {
+  static_assert(!LOSS || (D2 && !TD), "the fused loss is the domain-2 Gaussian one");
   constexpr int N = M;
   constexpr int NACC = N * KU * 2;
   constexpr int NV = next_pow2_c(NACC);
@@ -778,6 +784,8 @@ __global__ void __launch_bounds__(64, MINW)
   R acc[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc[i] = 0;
+  double lacc = 0.0, lm = 1.0;  // LOSS: sum P/R, and sum log R carried as mantissa product + exponent
+  int le = 0;
 
   auto issue_x_tied = [&](const Cursor& c, Vec2<R>(&x)[M]) {
     const int t = c.tb * WAVE + lane;
@@ -868,6 +876,7 @@ __global__ void __launch_bounds__(64, MINW)
 #pragma unroll
     for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
     const R live = (t < T) ? (R)1 : (R)0;
+    double lterm = 0.0, lprod = 1.0;
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       Cx<R> y = cmake<R>(0, 0);
@@ -887,6 +896,10 @@ __global__ void __launch_bounds__(64, MINW)
       if (TD) P = t_harmonic<R>(P, tv, a.nu);
       R inv = fast_rcp(tv);                                 // TV_inverse
       R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);   // division = P / TV**((d+2)/d)
+      if (LOSS) {
+        lterm += (double)(P * inv);
+        lprod *= (double)tv;
+      }
       inv *= live;  // frames past the end of the utterance contribute nothing (one multiply, not four selects)
       D *= live;
 #pragma unroll
@@ -894,6 +907,15 @@ __global__ void __launch_bounds__(64, MINW)
         acc[(n * KU + kk) * 2 + 0] = fma(D, v[kk], acc[(n * KU + kk) * 2 + 0]);
         acc[(n * KU + kk) * 2 + 1] = fma(inv, v[kk], acc[(n * KU + kk) * 2 + 1]);
       }
+    }
+    if (LOSS) {
+      if (t < T) {
+        lacc += lterm;
+        int e;
+        lm = frexp(lm * lprod, &e);
+        le += e;
+      }
+      asm volatile("" : "+v"(lacc), "+v"(lm));
     }
     value_fence(acc);  // every read of the slot is above this line
     if (STEADY || it + DXT < nblk) {
@@ -910,6 +932,15 @@ __global__ void __launch_bounds__(64, MINW)
         part[(((size_t)g * a.fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2 + (i & 1)] = tot;
 #pragma unroll
       for (int q = 0; q < NV; ++q) acc[q] = 0;
+      if (LOSS && (cc.b != cur.b || !more)) {  // leaving utterance cur.b: publish this workgroup's share of its loss
+        double tot = lacc + (double)le * 0.6931471805599453 + log(lm);
+        tot = wave_allreduce_sum<double>(tot);
+        const long long first_item = (long long)cur.b * F * TBk;
+        if (lane == 0) lpart[(size_t)cur.b * lstride + (g - (int)(first_item / a.fp.L))] = tot;
+        lacc = 0.0;
+        lm = 1.0;
+        le = 0;
+      }
       if (more) load_rows(cc);
     }
   };

@@ -76,14 +76,16 @@ class Engine:
         return W
 
     # ------------------------------------------------------------------ ILRMA
-    def ilrma_source_update(self, X, W, Tb, V, domain=2, eps=1e-12, sources=None):
-        """sources: None = all, or an iterable of source indices (pairwise update)."""
+    def ilrma_source_update(self, X, W, Tb, V, domain=2, eps=1e-12, sources=None, loss_prev=None):
+        """sources: None = all, or an iterable of source indices (pairwise update).
+        loss_prev: optional (B,) float64 tensor receiving the loss of the model at entry (fused into the basis pass)."""
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         mask = (1 << M) - 1 if sources is None else sum(1 << int(n) for n in set(sources))
         self._check(L.assx_ilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
-                                               mask, ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
+                                               mask, ptr(loss_prev), ptr(ws), B, M, F, T, K, self.prec.code,
+                                               self._st()),
                     "assx_ilrma_source_update")
 
     # ---- partitioning function (shared bases + latent variables), domain 2

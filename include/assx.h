@@ -109,9 +109,12 @@ int assx_ip2_update(assx_ctx* ctx, const void* U, void* W, double threshold, int
 /* GaussILRMA.update_source_model_basic, non-partitioned (src/bss/ilrma.py:356-366, 409-430):
  * P = |W x|^2 recomputed on the fly; IS-NMF (mm) basis update, then activation update with
  * the new basis.  Tb, V updated in place.  source_mask: bit n set = source n is updated (all ones = every source;
- * two bits = update_source_model_pairwise, src/bss/ilrma.py:432-481). */
+ * two bits = update_source_model_pairwise, src/bss/ilrma.py:432-481).
+ * loss_prev: optional (B,) float64 receiving compute_negative_loglikelihood (src/bss/ilrma.py:648-677) of the model
+ * AT ENTRY, i.e. the loss the reference records at the end of the previous iteration.  For domain 2 and K <= 4 it
+ * is accumulated inside the basis pass (which forms the same y = W x and T V) instead of costing a pass over X. */
 int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V,
-                             double domain, double eps, unsigned source_mask, void* ws,
+                             double domain, double eps, unsigned source_mask, double* loss_prev, void* ws,
                              int B, int M, int F, int T, int K, int dtype, void* stream);
 
 /* ---- (f1) partitioning function: shared bases Tb (B,F,K), activations V (B,K,T), latent Z (B,N,K) ----------

@@ -469,3 +469,26 @@ def test_streaming_kernels_long_ranges_two_utterances(eng, few_workgroups, G):
         assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
         Wref, _, _ = orc.ilrma_spatial_update_ip(Xs[b], Ws[b].copy(), T1, V1, 2)
         assert rel_err(host(Wd2)[b], Wref) < tol(eng, 1e-9, 2e-3)
+
+
+@pytest.mark.parametrize("G", [0, 5])
+@pytest.mark.parametrize("M,K,domain,T", [(4, 4, 2, 1030), (2, 3, 2, 700), (3, 6, 2, 300), (4, 2, 1, 300)])
+def test_source_update_loss_of_entry_state(eng, few_workgroups, G, M, K, domain, T):
+    """`loss_prev` of assx_ilrma_source_update = compute_negative_loglikelihood of the model at entry (ilrma.py:648-677):
+    fused into the basis pass for domain 2 / K <= 4, a pass of its own otherwise; two utterances, ragged T."""
+    if G:
+        few_workgroups(G)
+    F = 13
+    rng = np.random.default_rng(140 + M + K)
+    Xs = [mixture(M, F, T, 141 + b) for b in range(2)]
+    Ws = [rand_filters(M, F, 143 + b) for b in range(2)]
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Xd, Wd, Td, Vd = dev_c(eng, np.stack(Xs)), dev_c(eng, np.stack(Ws)), dev_r(eng, Tb), dev_r(eng, V)
+    lp = eng.empty((2,), dtype=torch.float64)
+    eng.ilrma_source_update(Xd, Wd, Td, Vd, domain=domain, loss_prev=lp)
+    for b in range(2):
+        np.testing.assert_allclose(host(lp)[b], orc.ilrma_loss(Xs[b], Ws[b], Tb[b], V[b], domain),
+                                   rtol=tol(eng, 1e-12, 1e-5))
+        T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], Ws[b])) ** 2, Tb[b], V[b], domain)
+        assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
