@@ -77,6 +77,17 @@ __device__ __forceinline__ void advance(Cursor& c, int TBk, int F) {
   }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8), each XCD with its own 4 MiB L2.  The flat partitions
+// hand out contiguous ranges of (utterance, bin, block) items, so giving XCD x the x-th contiguous eighth of the
+// ranges keeps what is re-read from L2 -- the activation tiles, the per-bin rows -- local: with 8 utterances in
+// flight every XCD then sees one utterance's V (0.5 MB) instead of all eight (4.2 MB, more than its L2).
+constexpr int N_XCD = 8;
+__device__ __forceinline__ int xcd_local_range(int bid, int G) {
+  const int x = bid % N_XCD, j = bid / N_XCD;
+  const int q = G / N_XCD, r = G % N_XCD;
+  return x * q + (x < r ? x : r) + j;
+}
+
 constexpr int DX = 4;  // X prefetch depth in 64-frame blocks: keeps >= 4 KB of X in flight per wave (Little's law:
                        // ~50 KB per CU are needed to cover HBM latency at 6 TB/s)
 constexpr int DW = 2;  // prefetch depth of the weight inputs (L2-resident)
@@ -250,7 +261,7 @@ __global__ void __launch_bounds__(64, MINW)
   const int s0 = (lane / FB) * SPL;            // first source of this lane group
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   if (q0 >= q1) return;
@@ -595,7 +606,7 @@ __global__ void __launch_bounds__(64, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   if (q0 >= q1) return;
@@ -767,7 +778,7 @@ __global__ void __launch_bounds__(64, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   if (q0 >= q1) return;
@@ -998,7 +1009,7 @@ __global__ void __launch_bounds__(64, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x, b = blockIdx.y;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x), b = blockIdx.y;
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   double acc = 0.0;
@@ -1151,7 +1162,7 @@ __global__ void __launch_bounds__(64, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x, b = blockIdx.y;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x), b = blockIdx.y;
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   double acc = 0.0;
@@ -1318,7 +1329,7 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K;
   const int TBk = (T + WAVE - 1) / WAVE;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   if (q0 >= q1) return;
@@ -1454,7 +1465,7 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K;
   const int TBk = (T + WAVE - 1) / WAVE;
   const size_t FT = (size_t)F * T;
-  const int g = blockIdx.x;
+  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
   const long long q0 = (long long)g * a.fp.L;
   const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
   if (q0 >= q1) return;
