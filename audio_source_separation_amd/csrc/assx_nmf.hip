@@ -10,6 +10,7 @@
 //                      activ. num|den = Tb^T [A|Bm]  (reduce over f)
 //   (3) finalize     : sum the split-K slabs, floor the denominator, multiply-update in place.
 // The GEMM is an LDS-tiled 64x64x16 register-blocked kernel in the storage precision.
+#include <cstdlib>
 #include "assx_common.hpp"
 #include "assx_nmf_mfma.hpp"
 
@@ -249,10 +250,16 @@ struct NmfWs {
 
 constexpr int NMF_MFMA_MAX_K = 64;
 
+inline int nmf_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
 // split counts of the MFMA path (deterministic: no device query)
 inline void mfma_basis_split(int B, int F, int T, int* TS, int* tchunk) {
   const int fg = (F + 63) / 64;
-  int ts = (512 + fg * B - 1) / (fg * B);  // one resident round at 2 waves/SIMD; fewer slabs for the finalize
+  const int wgs = nmf_env_int("ASSX_NMF_BASIS_WGS", 512);
+  int ts = (wgs + fg * B - 1) / (fg * B);  // one resident round; fewer slabs for the finalize
   const int max_ts = (T + 63) / 64;
   if (ts > max_ts) ts = max_ts;
   if (ts < 1) ts = 1;
@@ -262,7 +269,8 @@ inline void mfma_basis_split(int B, int F, int T, int* TS, int* tchunk) {
 }
 inline void mfma_act_split(int B, int F, int T, int* FS, int* fchunk) {
   const int tg = (T + 15) / 16;
-  int fs = (1024 + tg * B - 1) / (tg * B);
+  const int wgs = nmf_env_int("ASSX_NMF_ACT_WGS", 1024);
+  int fs = (wgs + tg * B - 1) / (tg * B);
   const int max_fs = (F + 63) / 64;
   if (fs > max_fs) fs = max_fs;
   if (fs < 1) fs = 1;
@@ -314,14 +322,27 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double eps, const vo
   int TS, tchunk, FS, fchunk;
   mfma_basis_split(B, F, T, &TS, &tchunk);
   mfma_act_split(B, F, T, &FS, &fchunk);
-  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X,
-                     (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts);
+  const bool d2 = domain == 2.0;  // every exponent is 0, 1 or 2: pow()-free instantiations
+#define NMF_BASIS(D2K)                                                                                         \
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X, \
+                     (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts)
+#define NMF_ACT(D2K)                                                                                           \
+  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3((T + 15) / 16, FS, B), dim3(256), 0, st, (const R*)X,   \
+                     (const R*)Tb, (const R*)V, part, B, F, T, K, fchunk, (R)eps, ts)
+  if (d2 && kind == ASSX_NMF_EUC) NMF_BASIS(ASSX_NMF_EUC);
+  else if (d2 && kind == ASSX_NMF_KL) NMF_BASIS(ASSX_NMF_KL);
+  else if (d2) NMF_BASIS(ASSX_NMF_IS_MM);
+  else NMF_BASIS(-1);
   ASSX_LAUNCH_CHECK(ctx, "nmf_basis_mfma_kernel");
   hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 256)), dim3(256), 0, st, (const R*)part,
                      (R*)Tb, B, (size_t)F * K, TS, (R)eps, pe);
   ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
-  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT>), dim3((T + 15) / 16, FS, B), dim3(256), 0, st, (const R*)X,
-                     (const R*)Tb, (const R*)V, part, B, F, T, K, fchunk, (R)eps, ts);
+  if (d2 && kind == ASSX_NMF_EUC) NMF_ACT(ASSX_NMF_EUC);
+  else if (d2 && kind == ASSX_NMF_KL) NMF_ACT(ASSX_NMF_KL);
+  else if (d2) NMF_ACT(ASSX_NMF_IS_MM);
+  else NMF_ACT(-1);
+#undef NMF_BASIS
+#undef NMF_ACT
   ASSX_LAUNCH_CHECK(ctx, "nmf_act_mfma_kernel");
   hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 256)), dim3(256), 0, st, (const R*)part,
                      (R*)V, B, (size_t)K * T, FS, (R)eps, pe);

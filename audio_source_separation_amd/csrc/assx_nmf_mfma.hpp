@@ -49,9 +49,27 @@ __device__ __forceinline__ R pow0(R x, PowSpec p) {  // x**0 == 1 exactly as num
 }
 
 // numerator / denominator weights of one element (only TV is floored here: nmf.py:312-316)
-template <typename R>
+// D2K: domain == 2 specialisation for the kind given (ASSX_NMF_EUC / _KL / _IS_MM (= both IS rules); -1 = generic, exponents at run time).
+// With domain 2 every exponent is 0, 1 or 2; keeping pow() out of the kernel takes it from 220 to ~130 VGPRs,
+// i.e. from 2 to 3-4 waves per SIMD to overlap one wave's elementwise / LDS phase with another's MFMA chain.
+template <typename R, int D2K = -1>
 __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R& a, R& bm) {
   tv = floor_eps<R>(tv, eps);
+  if (D2K == ASSX_NMF_EUC) {  // X * TV^0 ; TV^1
+    a = x;
+    bm = tv;
+    return;
+  }
+  if (D2K == ASSX_NMF_KL) {  // X / TV ; TV^0
+    a = x / tv;
+    bm = (R)1;
+    return;
+  }
+  if (D2K == ASSX_NMF_IS_MM) {  // X / TV^2 ; 1 / TV
+    bm = (R)1 / tv;
+    a = x * bm * bm;
+    return;
+  }
   if (s.kind == ASSX_NMF_EUC) {  // X * TV^((2-d)/d) ; TV^((4-d)/d)
     a = x * pow0<R>(tv, s.pa);
     bm = pow0<R>(tv, s.pb);
@@ -69,7 +87,7 @@ __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R
 //   grid (ceil(F/64), TS, B), 4 waves, wave w owns bins f0 = (4*blockIdx.x + w)*16 .. +15.
 //   part[ts][b*2 + s][f*K + k]
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT>
+template <typename R, int KT, int D2K = -1>
 __global__ void __launch_bounds__(256)
     nmf_basis_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
                           R* __restrict__ part, int B, int F, int T, int K, int tchunk, R eps, TermSpec s) {
@@ -146,7 +164,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int t = t0 + MM::crow(r, lane);
-      nmf_terms<R>(s, xc[r], tv[r], eps, a[r], bm[r]);
+      nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
       if (!(fvalid && t < te)) {
         a[r] = 0;
         bm[r] = 0;
@@ -186,7 +204,7 @@ __global__ void __launch_bounds__(256)
 //   grid (ceil(T/16), FS, B); the 4 waves stride over the bin range in sub-tiles of 16 and are combined through LDS.
 //   part[fs][b*2 + s][k*T + t]
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT>
+template <typename R, int KT, int D2K = -1>
 __global__ void __launch_bounds__(256)
     nmf_act_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
                         int B, int F, int T, int K, int fchunk, R eps, TermSpec s) {
@@ -261,7 +279,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int fr = f0 + MM::crow(r, lane);
-      nmf_terms<R>(s, xc[r], tv[r], eps, a[r], bm[r]);
+      nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
       if (!(tvalid && fr < fe)) {
         a[r] = 0;
         bm[r] = 0;
