@@ -61,12 +61,12 @@ __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R
     return;
   }
   if (D2K == ASSX_NMF_KL) {  // X / TV ; TV^0
-    a = x / tv;
+    a = x * fast_rcp(tv);
     bm = (R)1;
     return;
   }
-  if (D2K == ASSX_NMF_IS_MM) {  // X / TV^2 ; 1 / TV
-    bm = (R)1 / tv;
+  if (D2K == ASSX_NMF_IS_MM) {  // X / TV^2 ; 1 / TV   (v_rcp + Newton: 5 instructions instead of the ~25 of an IEEE divide)
+    bm = fast_rcp(tv);
     a = x * bm * bm;
     return;
   }

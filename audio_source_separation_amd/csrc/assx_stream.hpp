@@ -47,21 +47,6 @@ inline FlatPart make_flat(long long NB, int len, long long G_target) {
   return p;
 }
 
-// 1/x: v_rcp + Newton steps instead of the 11-instruction IEEE division expansion (|rel err| < 2^-52)
-__device__ __forceinline__ double fast_rcp(double x) {
-  double r = __builtin_amdgcn_rcp(x);
-  double e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  e = fma(-x, r, 1.0);
-  r = fma(r, e, r);
-  return r;
-}
-__device__ __forceinline__ float fast_rcp(float x) {
-  float r = __builtin_amdgcn_rcpf(x);
-  float e = fmaf(-x, r, 1.0f);
-  return fmaf(r, e, r);
-}
-
 // (utterance, bin, frame-block) cursor advanced incrementally: a 64-bit division per block would cost more
 // scalar instructions than the block's arithmetic.
 struct Cursor {
