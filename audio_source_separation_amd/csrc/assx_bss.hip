@@ -1384,7 +1384,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
     rc = run_act_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp);  // uses the new basis
     if (rc) return rc;
-    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3((unsigned)((size_t)B * MM * K * tblocks(T))), dim3(256), 0, st,
                        (const R*)ws, (R*)V, B, MM, F, K, T, fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
     return 0;
@@ -1707,7 +1707,7 @@ int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void*
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
     rc = run_act_partial<R, MM>(ctx, X, W, Tb, V, 2.0, eps, ws, B, F, T, K, st, &fp, nu);
     if (rc) return rc;
-    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * K * T, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3((unsigned)((size_t)B * MM * K * tblocks(T))), dim3(256), 0, st,
                        (const R*)ws, (R*)V, B, MM, F, K, T, fp, (R)eps, p2, ~0u);
     ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
     return 0;

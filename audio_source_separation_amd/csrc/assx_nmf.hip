@@ -173,17 +173,31 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g) {
 template <typename R>
 __global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__ part, R* __restrict__ out, int B,
                                                           size_t count, int splits, R eps, PowSpec p) {
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)B * count) return;
-  const size_t b = idx / count, i = idx % count;
+  // 64 outputs per workgroup, 4 strands per output (independent loads; the single-thread walk over ~30 slabs was a
+  // chain of L2 latencies), combined in a fixed order
+  __shared__ R sn[4][64], sd[4][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + o;
+  const bool ok = idx < (size_t)B * count;
+  const size_t b = ok ? idx / count : 0, i = ok ? idx % count : 0;
   R num = 0, den = 0;
-  for (int s = 0; s < splits; ++s) {
-    const R* q = part + ((size_t)s * B * 2 + b * 2) * count + i;
-    num += q[0];
-    den += q[count];
+  if (ok) {
+#pragma unroll 4
+    for (int s = q; s < splits; s += 4) {
+      const R* pq = part + ((size_t)s * B * 2 + b * 2) * count + i;
+      num += pq[0];
+      den += pq[count];
+    }
   }
-  den = floor_eps<R>(den, eps);
-  out[idx] = out[idx] * powspec<R>(num / den, p);
+  sn[q][o] = num;
+  sd[q][o] = den;
+  __syncthreads();
+  if (q == 0 && ok) {
+    num = (sn[0][o] + sn[1][o]) + (sn[2][o] + sn[3][o]);
+    den = (sd[0][o] + sd[1][o]) + (sd[2][o] + sd[3][o]);
+    den = floor_eps<R>(den, eps);
+    out[idx] = out[idx] * powspec<R>(num / den, p);
+  }
 }
 
 // loss partials: lpart[b][f*nblk_t + blk]
@@ -334,7 +348,7 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double eps, const vo
   else if (d2) NMF_BASIS(ASSX_NMF_IS_MM);
   else NMF_BASIS(-1);
   ASSX_LAUNCH_CHECK(ctx, "nmf_basis_mfma_kernel");
-  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 256)), dim3(256), 0, st, (const R*)part,
+  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 64)), dim3(256), 0, st, (const R*)part,
                      (R*)Tb, B, (size_t)F * K, TS, (R)eps, pe);
   ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
   if (d2 && kind == ASSX_NMF_EUC) NMF_ACT(ASSX_NMF_EUC);
@@ -344,7 +358,7 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double eps, const vo
 #undef NMF_BASIS
 #undef NMF_ACT
   ASSX_LAUNCH_CHECK(ctx, "nmf_act_mfma_kernel");
-  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 256)), dim3(256), 0, st, (const R*)part,
+  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 64)), dim3(256), 0, st, (const R*)part,
                      (R*)V, B, (size_t)K * T, FS, (R)eps, pe);
   ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
   return 0;
@@ -398,7 +412,7 @@ int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double eps, const vo
     dim3 grid((K + BN - 1) / BN, (F + BM - 1) / BM, g.Z * g.splits);
     hipLaunchKernelGGL((gemm_tile_kernel<R, true, true>), grid, dim3(256), 0, st, g);
     ASSX_LAUNCH_CHECK(ctx, "gemm_tile_kernel(basis)");
-    hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 64)), dim3(256), 0, st,
                        (const R*)part, (R*)Tb, B, (size_t)F * K, g.splits, (R)eps, pe);
     ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
   }
@@ -430,7 +444,7 @@ int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double eps, const vo
     dim3 grid((T + BN - 1) / BN, (K + BM - 1) / BM, g.Z * g.splits);
     hipLaunchKernelGGL((gemm_tile_kernel<R, false, false>), grid, dim3(256), 0, st, g);
     ASSX_LAUNCH_CHECK(ctx, "gemm_tile_kernel(activation)");
-    hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 64)), dim3(256), 0, st,
                        (const R*)part, (R*)V, B, (size_t)K * T, g.splits, (R)eps, pe);
     ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
   }
