@@ -88,3 +88,43 @@ def test_constructor_contract_matches_reference():
     assert not hasattr(m, "demix_filter") and not hasattr(m, "basis") and not hasattr(m, "activation")
     m.demix_filter = np.zeros((3, 2, 2), dtype=np.complex128)
     assert hasattr(m, "demix_filter") and m.demix_filter.shape == (3, 2, 2)
+
+
+def test_lazy_loss_list_defers_and_resolves():
+    """`model.loss` semantics without a GPU: parked entries are materialised on first read, after the model had the
+    chance to compute a value it deferred (before_flush); copies / pickles carry plain values."""
+    import copy
+    import pickle
+    from audio_source_separation_amd._loss import LazyLossList
+
+    class FakeTensor:
+        def __init__(self, v):
+            self.v = np.asarray(v, dtype=np.float64)
+
+        def detach(self):
+            return self
+
+        def cpu(self):
+            return self
+
+        def numpy(self):
+            return self.v
+
+    ll = LazyLossList()
+    ll.append(3.0)
+    box = FakeTensor([0.0])
+    calls = []
+
+    def resolve():
+        calls.append(1)
+        box.v = np.asarray([7.5])
+
+    ll.before_flush = resolve
+    ll.append_device(box, batched=False)
+    assert len(ll) == 2 and not calls            # len() and append never trigger the computation
+    assert ll[-1] == 7.5 and calls == [1]        # first read does, once
+    assert list(ll) == [3.0, 7.5] and calls == [1]
+    assert copy.deepcopy(ll) == ll and pickle.loads(pickle.dumps(ll))[1] == 7.5
+    assert np.asarray(ll).tolist() == [3.0, 7.5]
+    ll.append_device(FakeTensor([1.0, 2.0]), batched=True)       # utterance axis: one value per utterance
+    assert np.array_equal(np.asarray(ll[2]), [1.0, 2.0])

@@ -492,3 +492,14 @@ def test_source_update_loss_of_entry_state(eng, few_workgroups, G, M, K, domain,
         T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], Ws[b])) ** 2, Tb[b], V[b], domain)
         assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
         assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
+
+
+def test_oversize_utterance_is_rejected(eng):
+    """Buffer offsets are 32-bit: an utterance of 2^28 or more complex samples is refused, not mis-addressed."""
+    from audio_source_separation_amd import _lib as L
+    from audio_source_separation_amd._device import ptr
+    t = eng.empty((16,))
+    rc = L.lib.assx_ilrma_loss(eng.ctx, ptr(t), ptr(t), ptr(t), ptr(t), 2.0, 1e-12, ptr(t), ptr(t), 1, 4, 1 << 13, 1 << 13, 4,
+                               eng.prec.code, eng._st())
+    assert rc == -2  # ASSX_E_UNSUPPORTED
+    assert b"4 GiB" in L.lib.assx_last_error(eng.ctx)
