@@ -788,6 +788,27 @@ __global__ void __launch_bounds__(64) logdet_kernel(const Cx<R>* __restrict__ W,
   lpart[(size_t)b * lstride + offset + f] = neg2T_logabsdet<M, R>(W, (size_t)idx, T);
 }
 
+// Completes the loss folded into the basis pass: loss[b] = sum of the data-term partials of the workgroups that
+// touched utterance b (found from the partition arithmetic: nothing to zero beforehand) plus the F log-det terms
+// logdet_kernel left at lpart[b][ncov ..).  One workgroup per utterance, fixed summation order.
+__global__ void __launch_bounds__(REDUCE_THREADS) ilrma_loss_finish_kernel(const double* __restrict__ lpart,
+                                                                          double* __restrict__ loss, int F, int ncov,
+                                                                          int lstride, long long items_per_utt, int L) {
+  __shared__ double sm[REDUCE_THREADS];
+  const int b = blockIdx.x;
+  const int g_lo = (int)(((long long)b * items_per_utt) / L), g_hi = (int)((((long long)b + 1) * items_per_utt - 1) / L);
+  double s = 0.0;
+  for (int i = threadIdx.x; i <= g_hi - g_lo; i += REDUCE_THREADS) s += lpart[(size_t)b * lstride + i];
+  for (int f = threadIdx.x; f < F; f += REDUCE_THREADS) s += lpart[(size_t)b * lstride + ncov + f];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = REDUCE_THREADS / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[b] = sm[0];
+}
+
 // ------------------------------------------------------------------------------------------
 // (a8) projection back statistics: per (b,f): G = sum_t y y^H (packed Hermitian, N*N reals) and
 //      c[j] = sum_t x_ref conj(y_j) (2N reals).  DEMIX: y = W x on the fly, x_ref = X[ref];
@@ -1365,8 +1386,6 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
         ASSX_REQUIRE(ctx, (size_t)B * lstride * sizeof(double) <= L.small - L.lpart, ASSX_E_UNSUPPORTED,
                      "workspace too small for the fused loss partials");
         lpart = (double*)((char*)ws + L.lpart);
-        hipError_t e = hipMemsetAsync(lpart, 0, (size_t)B * lstride * sizeof(double), st);
-        if (e != hipSuccess) return fail(ctx, (int)e, "hipMemsetAsync(loss partials): %s", hipGetErrorString(e));
         hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st,
                            (const Cx<R>*)W, lpart, B, F, T, lstride, ncov);
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
@@ -1375,9 +1394,9 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp, -1.0, lpart, lstride);
     if (rc) return rc;
     if (lpart) {
-      hipLaunchKernelGGL((sum_reduce_kernel<double, double>), dim3(B), dim3(REDUCE_THREADS), 0, st,
-                         (const double*)lpart, loss_prev, (size_t)lstride, 1.0);
-      ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+      hipLaunchKernelGGL(ilrma_loss_finish_kernel, dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lpart, loss_prev,
+                         F, lstride - F, lstride, (long long)F * tblocks(T), fp.L);
+      ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_finish_kernel");
     }
     hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
                        st, (const R*)ws, (R*)Tb, B, MM, F, K, fp, (R)eps, p2, source_mask);
