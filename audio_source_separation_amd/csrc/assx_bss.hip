@@ -75,6 +75,124 @@ __global__ void __launch_bounds__(256) demix_kernel(const Cx<R>* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------
+// n_basis > 4 (the reference's default is 10): the source model no longer fits the per-lane registers of the
+// streaming kernels, so the two halves of the iteration go through a materialised (B,N,F,T) real array instead:
+//   * P = |W x|^2, on which the source-model update IS the batched IS-NMF MM update (ilrma.py:409-430 ==
+//     nmf.py:302-327 with target P) -- run on the f64/f32 matrix cores by assx_nmf_update, batch B*N;
+//   * R = (T V)^(2/domain), which the covariance kernel then reads as per-bin-per-frame weights (WK_NFT).
+// Both maps are one read of their input and one coalesced write.
+// ------------------------------------------------------------------------------------------
+template <typename R, int M>
+__global__ void __launch_bounds__(256) demix_power_map_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                             R* __restrict__ P, Dims d) {
+  const int f = blockIdx.y, b = blockIdx.z;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.T) return;
+  const size_t FT = (size_t)d.F * d.T;
+  Cx<R> w[M][M];
+  load_filter<R, M>(W, (size_t)b * d.F + f, w);
+  const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * d.T + t;
+  Cx<R> x[M], y[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
+  demix<R, M>(w, x, y);
+  R* pb = P + (size_t)b * M * FT + (size_t)f * d.T + t;
+#pragma unroll
+  for (int n = 0; n < M; ++n) pb[n * FT] = cabs2(y[n]);
+}
+
+// A thread owns one frame of WIDE_FB consecutive bins: the K activations of that frame are loaded once and serve
+// all of them (one bin per thread is bound by the K L2 reads per output element, 90 us at K = 10 instead of the
+// 30 us the 134 MB write costs); the basis rows are wave-uniform.
+constexpr int WIDE_FB = 8;
+
+template <typename R, bool D2>
+__global__ void __launch_bounds__(256) source_variance_map_kernel(const R* __restrict__ Tb, const R* __restrict__ V,
+                                                                 R* __restrict__ Rv, int F, int T, int K, PowSpec p2d) {
+  const int f0 = blockIdx.y * WIDE_FB, bn = blockIdx.z;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const R* vb = V + (size_t)bn * K * T + t;
+  const R* tb = Tb + (size_t)bn * F * K;
+  int row[WIDE_FB];
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j) row[j] = (f0 + j < F ? f0 + j : F - 1) * K;
+  R tv[WIDE_FB];
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j) tv[j] = 0;
+  for (int k = 0; k < K; ++k) {
+    const R v = vb[(size_t)k * T];
+#pragma unroll
+    for (int j = 0; j < WIDE_FB; ++j) tv[j] = fma(tb[row[j] + k], v, tv[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j)
+    if (f0 + j < F)  // floored by the reader (ilrma.py:499-509)
+      Rv[((size_t)bn * F + f0 + j) * T + t] = D2 ? tv[j] : powspec<R>(tv[j], p2d);
+}
+
+// loss data term sum_{n,f,t} P/R + log R (ilrma.py:672-675) for n_basis > 4, same bin batching; one wave per
+// workgroup, one partial per workgroup at lpart[b][blockIdx.y * gridDim.x + blockIdx.x]
+template <typename R, int M, bool D2>
+__global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                            const R* __restrict__ Tb, const R* __restrict__ V,
+                                                            double* __restrict__ lpart, int lstride, Dims d, R eps,
+                                                            PowSpec p2d) {
+  const int F = d.F, T = d.T, K = d.K;
+  const int f0 = blockIdx.y * WIDE_FB, b = blockIdx.z;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  const bool live = t < T;
+  const int tc = live ? t : T - 1;
+  int row[WIDE_FB];
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j) row[j] = (f0 + j < F ? f0 + j : F - 1) * K;
+  R r[M][WIDE_FB];
+#pragma unroll
+  for (int n = 0; n < M; ++n) {
+    const R* vb = V + ((size_t)b * M + n) * K * T + tc;
+    const R* tb = Tb + ((size_t)b * M + n) * F * K;
+#pragma unroll
+    for (int j = 0; j < WIDE_FB; ++j) r[n][j] = 0;
+    for (int k = 0; k < K; ++k) {
+      const R v = vb[(size_t)k * T];
+#pragma unroll
+      for (int j = 0; j < WIDE_FB; ++j) r[n][j] = fma(tb[row[j] + k], v, r[n][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < WIDE_FB; ++j) r[n][j] = floor_eps<R>(D2 ? r[n][j] : powspec<R>(r[n][j], p2d), eps);
+  }
+  const size_t FT = (size_t)F * T;
+  double acc = 0.0, lm = 1.0;
+  int le = 0;
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j) {
+    if (f0 + j >= F) break;  // wave-uniform
+    Cx<R> w[M][M];
+    load_filter<R, M>(W, (size_t)b * F + f0 + j, w);
+    const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)(f0 + j) * T + tc;
+    Cx<R> x[M], y[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
+    demix<R, M>(w, x, y);
+    double term = 0.0, rprod = 1.0;
+#pragma unroll
+    for (int n = 0; n < M; ++n) {
+      term += (double)(cabs2(y[n]) * fast_rcp(r[n][j]));
+      rprod *= (double)r[n][j];
+    }
+    if (live) {
+      acc += term;
+      int e;
+      lm = frexp(lm * rprod, &e);
+      le += e;
+    }
+  }
+  acc += (double)le * 0.6931471805599453 + log(lm);
+  acc = wave_allreduce_sum<double>(acc);
+  if (threadIdx.x == 0) lpart[(size_t)b * lstride + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
 // (a5) IP sweep.  A group of GW = next_pow2(M*M) lanes owns one bin (b, f): lane (i, j) holds element (i, j) of
 //      W and of the working matrix, rows/columns travel by in-group shuffles.  Gauss-Seidel over the sources
 //      (sequential), Gauss-Jordan with partial pivoting inside, all in float64.  The 1025 bins of one utterance
@@ -980,6 +1098,8 @@ struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte al
   size_t u;        // dense U (B,N,F,M,M) complex
   size_t lpart;    // double partials for losses / power
   size_t small;    // (B,N) reals etc.
+  size_t map;      // n_basis > 4 only: (B,N,F,T) reals (demixed power / source variance)
+  size_t nmf;      // n_basis > 4 only: scratch of the batched IS-NMF update
   size_t total;
 };
 
@@ -1045,6 +1165,12 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   off += align_up(nl * 8, 256);
   L.small = off;
   off += align_up((size_t)B * (M + 8) * 8, 256);
+  L.map = L.nmf = off;
+  if (K > KU) {
+    off += align_up((size_t)B * M * F * T * r, 256);
+    L.nmf = off;
+    off += align_up(assx_nmf_workspace_bytes(B * M, F, T, K, dtype), 256);
+  }
   L.total = off;
   return L;
 }
@@ -1267,6 +1393,26 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
   return 0;
 }
 
+// n_basis > 4: covariance partials through the materialised source variance (see source_variance_map_kernel)
+template <typename R, int MM>
+int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int K, double domain, double eps,
+                       void* ws, int B, int F, int T, int dtype, hipStream_t st, FlatPart* fp_out) {
+  static const int wide = env_int("ASSX_WIDE_K", 1);
+  if (K <= KU || !wide) return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, fp_out);
+  const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+  R* rv = (R*)((char*)ws + L.map);
+  const PowSpec p2d = make_pow(2.0 / domain);
+  const dim3 grid(blocks_for(T, 256), blocks_for(F, WIDE_FB), B * MM);
+  if (p2d.mode == POW_ID)
+    hipLaunchKernelGGL((source_variance_map_kernel<R, true>), grid, dim3(256), 0, st, (const R*)Tb, (const R*)V, rv, F, T,
+                       K, p2d);
+  else
+    hipLaunchKernelGGL((source_variance_map_kernel<R, false>), grid, dim3(256), 0, st, (const R*)Tb, (const R*)V, rv, F,
+                       T, K, p2d);
+  ASSX_LAUNCH_CHECK(ctx, "source_variance_map_kernel");
+  return run_cov_partial<R, MM>(ctx, WK_NFT, X, rv, nullptr, nullptr, 1, 2.0, eps, ws, B, F, T, st, fp_out);
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -1391,6 +1537,18 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
       }
     }
+    static const int wide = env_int("ASSX_WIDE_K", 1);
+    if (K > KU && wide && (source_mask & ((1u << MM) - 1u)) == ((1u << MM) - 1u)) {
+      // n_basis > 4: P = |W x|^2 once, then the batched IS-NMF MM update on the matrix cores (same update rule,
+      // ilrma.py:409-430 == nmf.py:302-327 with target P)
+      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+      R* pw = (R*)((char*)ws + L.map);
+      hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                         (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
+      ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      return assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype,
+                             stream);
+    }
     rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp, -1.0, lpart, lstride);
     if (rc) return rc;
     if (lpart) {
@@ -1514,7 +1672,7 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     FlatPart fp;
-    int rc = run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, &fp);
+    int rc = run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, B, F, T, dtype, st, &fp);
     if (rc) return rc;
     if (U_out) {  // dense covariance on request only; the IP sweep reduces the partial records itself
       hipLaunchKernelGGL((cov_stream_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)),
@@ -1538,7 +1696,7 @@ int assx_ilrma_cov_partials(assx_ctx* ctx, const void* X, const void* Tb, const 
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     FlatPart fp;
-    return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, &fp);
+    return run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, B, F, T, dtype, st, &fp);
   });
 }
 
@@ -1661,6 +1819,27 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
     a.nu = (R)nu;
     const PowSpec p2d = make_pow(2.0 / domain);
     const bool d2 = p2d.mode == POW_ID, k4 = K <= KU;
+    static const int wide = env_int("ASSX_WIDE_K", 1);
+    if (!k4 && wide && nu < 0.0) {  // n_basis > 4: bin-batched evaluation (ilrma_loss_wide_kernel)
+      const dim3 gw(blocks_for(T, 64), blocks_for(F, WIDE_FB), B);
+      const int nw = (int)(gw.x * gw.y), lsw = nw + F;
+      if ((size_t)B * lsw * sizeof(double) <= L.small - L.lpart) {
+        if (d2)
+          hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, true>), gw, dim3(64), 0, st, (const Cx<R>*)X,
+                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d);
+        else
+          hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, false>), gw, dim3(64), 0, st, (const Cx<R>*)X,
+                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d);
+        ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_wide_kernel");
+        hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st,
+                           (const Cx<R>*)W, lpart, B, F, T, lsw, nw);
+        ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
+        hipLaunchKernelGGL((sum_reduce_kernel<double, double>), dim3(B), dim3(REDUCE_THREADS), 0, st,
+                           (const double*)lpart, loss, (size_t)lsw, 1.0);
+        ASSX_LAUNCH_CHECK(ctx, "sum_reduce_kernel");
+        return 0;
+      }
+    }
     const int lstride = a.fp.G + F;  // [G data-term partials | F log-det terms] per utterance
     const dim3 grid(a.fp.G, B), blk(64);
 #define LOSS_LAUNCH(K4V, D2V, DXV, DWV, MW, TDV)                                                                \

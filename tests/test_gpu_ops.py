@@ -494,6 +494,43 @@ def test_source_update_loss_of_entry_state(eng, few_workgroups, G, M, K, domain,
         assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("M,K,domain,F,T", [(4, 10, 2, 19, 150), (2, 5, 2, 8, 64), (3, 17, 1, 21, 333), (4, 70, 2, 9, 130),
+                                            (2, 6, 1.5, 17, 257)])
+def test_wide_basis_path(eng, M, K, domain, F, T):
+    """n_basis > 4 (the reference's default is 10): source model through the materialised demixed power + the batched
+    IS-NMF update on the matrix cores, covariance through the materialised source variance, bin-batched loss; two
+    utterances, ragged F (bins are taken 8 at a time) and ragged T."""
+    rng = np.random.default_rng(150 + M + K)
+    Xs = [mixture(M, F, T, 151 + b) for b in range(2)]
+    Ws = [rand_filters(M, F, 153 + b) for b in range(2)]
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Xd, Td, Vd = dev_c(eng, np.stack(Xs)), dev_r(eng, Tb), dev_r(eng, V)
+    # loss
+    Wd = dev_c(eng, np.stack(Ws))
+    l0 = host(eng.ilrma_loss(Xd, Wd, Td, Vd, domain=domain))
+    for b in range(2):
+        np.testing.assert_allclose(l0[b], orc.ilrma_loss(Xs[b], Ws[b], Tb[b], V[b], domain), rtol=tol(eng, 1e-12, 1e-5))
+    # spatial model
+    Ud = eng.empty((2, M, F, M, M), complex_=True)
+    st = eng.new_status(2)
+    eng.ilrma_spatial_update(Xd, Wd, Td, Vd, domain=domain, status=st, U_out=Ud)
+    W1 = host(Wd)
+    for b in range(2):
+        Wref, Uref, mask = orc.ilrma_spatial_update_ip(Xs[b], Ws[b].copy(), Tb[b], V[b], domain)
+        assert mask.all()
+        assert rel_err(host(Ud)[b], Uref) < tol(eng, 1e-12, 2e-5)
+        assert rel_err(W1[b], Wref) < tol(eng, 1e-9, 2e-3)
+    # source model (with the loss of the entry state), from the original filters
+    Wd = dev_c(eng, np.stack(Ws))
+    lp = eng.empty((2,), dtype=torch.float64)
+    eng.ilrma_source_update(Xd, Wd, Td, Vd, domain=domain, loss_prev=lp)
+    for b in range(2):
+        np.testing.assert_allclose(host(lp)[b], l0[b], rtol=tol(eng, 1e-13, 1e-6))
+        T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], Ws[b])) ** 2, Tb[b], V[b], domain)
+        assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
+
+
 def test_oversize_utterance_is_rejected(eng):
     """Buffer offsets are 32-bit: an utterance of 2^28 or more complex samples is refused, not mis-addressed."""
     from audio_source_separation_amd import _lib as L
