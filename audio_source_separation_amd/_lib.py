@@ -25,6 +25,7 @@ _vp = ctypes.c_void_p
 _i = ctypes.c_int
 _d = ctypes.c_double
 _sz = ctypes.c_size_t
+_ll = ctypes.c_longlong
 
 # name -> (restype, argtypes) ; must list EVERY symbol include/assx.h declares (tests check this)
 SIGNATURES = {
@@ -60,6 +61,11 @@ SIGNATURES = {
     "assx_nmf_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "assx_nmf_update": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_loss": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_stft_num_frames": (_ll, [_ll, _i, _i]),
+    "assx_istft_num_samples": (_ll, [_i, _i, _i]),
+    "assx_stft_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "assx_stft": (_i, [_vp, _vp, _vp, _d, _vp, _vp, _i, _ll, _i, _i, _i, _i, _vp]),
+    "assx_istft": (_i, [_vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 
 

@@ -190,6 +190,29 @@ class Engine:
                                       ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_loss")
         return loss
 
+    # ------------------------------------------------------------------ STFT / iSTFT (row f3)
+    def stft(self, x, window, fft_size, hop):
+        """x (C, L) real -> X (C, fft_size//2+1, n_frames) complex; scipy.signal.stft semantics (include/assx.h)."""
+        C, n = int(x.shape[0]), int(x.shape[1])
+        T = int(L.assx_stft_num_frames(n, fft_size, hop))
+        X = self.empty((C, fft_size // 2 + 1, max(T, 0)), complex_=True)
+        ws = self._ws.get(L.assx_stft_workspace_bytes(C, fft_size, max(T, 1), self.prec.code))
+        self._check(L.assx_stft(self.ctx, ptr(x), ptr(window), float(window.sum().item()), ptr(X), ptr(ws), C, n,
+                                fft_size, hop, T, self.prec.code, self._st()), "assx_stft")
+        return X
+
+    def istft(self, X, window, fft_size, hop):
+        """X (C, fft_size//2+1, n_frames) complex -> y (C, n_samples) real; scipy.signal.istft semantics."""
+        C, F, T = (int(v) for v in X.shape)
+        if F != fft_size // 2 + 1:
+            raise ValueError("istft: {} bins do not match fft_size={}".format(F, fft_size))
+        n = int(L.assx_istft_num_samples(fft_size, hop, T))
+        y = self.empty((C, max(n, 0)))
+        ws = self._ws.get(L.assx_stft_workspace_bytes(C, fft_size, T, self.prec.code))
+        self._check(L.assx_istft(self.ctx, ptr(X), ptr(window), float(window.sum().item()), ptr(y), ptr(ws), C,
+                                 fft_size, hop, T, self.prec.code, self._st()), "assx_istft")
+        return y
+
     # ------------------------------------------------------------------ t-ILRMA
     def tilrma_source_update(self, X, W, Tb, V, nu, eps=1e-12):
         B, M, F, T = self._dims(X)

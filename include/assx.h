@@ -232,6 +232,24 @@ int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const vo
 int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void* X, const void* Tb, const void* V,
                   double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
 
+/* ---- (f3) STFT / iSTFT either side of the loop ---------------------------------------------- */
+/* stft / istft of src/transform/stft.py:4-17, i.e. scipy.signal.stft / istft with nperseg = fft_size,
+ * noverlap = fft_size - hop, boundary='zeros', padded=True, detrend=False, scaling='spectrum', one-sided:
+ *   X[c,f,t] = rfft(window * x_padded[c, t*hop : t*hop + fft_size])[f] / window_sum
+ *   y        = weighted overlap-add of window * irfft(X[c,:,t]) * window_sum / sum_t window^2, boundary removed.
+ * x (C, n_samples) real; window (fft_size,) real on the device, window_sum = its sum; X (C, fft_size/2+1, n_frames)
+ * complex, frames fastest -- the layout the separation loop reads; y (C, assx_istft_num_samples(...)) real.
+ * n_frames must equal assx_stft_num_frames(n_samples, fft_size, hop) (the count scipy produces); n_samples >=
+ * fft_size (scipy shrinks the window for shorter signals: refused here).  Any fft_size whose frame fits LDS; powers
+ * of two up to 8192 take the in-LDS FFT, the rest a direct DFT. */
+long long assx_stft_num_frames(long long n_samples, int fft_size, int hop);
+long long assx_istft_num_samples(int fft_size, int hop, int n_frames);
+size_t assx_stft_workspace_bytes(int C, int fft_size, int n_frames, int dtype);
+int assx_stft(assx_ctx* ctx, const void* x, const void* window, double window_sum, void* X, void* ws, int C,
+              long long n_samples, int fft_size, int hop, int n_frames, int dtype, void* stream);
+int assx_istft(assx_ctx* ctx, const void* X, const void* window, double window_sum, void* y, void* ws, int C,
+               int fft_size, int hop, int n_frames, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -424,6 +424,33 @@ def gen_tilrma():
              T_final=model.basis, V_final=model.activation, **snap.data)
 
 
+def stft_perturb(X):
+    """Deterministic modulation that takes a spectrogram off the set of consistent ones (also sets the imaginary
+    parts of the DC / Nyquist bins, which irfft must ignore)."""
+    return X * (1.0 + 0.1 * np.cos(np.arange(X.size, dtype=np.float64)).reshape(X.shape)) + 0.01j
+
+
+def gen_stft():
+    """stft / istft of src/transform/stft.py (scipy.signal.stft / istft) on seeded noise: power-of-two and
+    odd / non-power-of-two fft sizes, hops that do and do not divide the length, both windows."""
+    import warnings
+    from transform.stft import stft, istft
+    rng = np.random.default_rng(1000)
+    out = {}
+    cases = [(1000, 64, 16, "hann"), (777, 128, 64, "hann"), (500, 32, 8, "hamming"), (300, 30, 10, "hann"),
+             (401, 33, 11, "hann"), (4096, 256, 128, "hann"), (100, 64, 48, "hann"), (5000, 1024, 256, "hann")]
+    for i, (L, N, hop, wf) in enumerate(cases):
+        x = rng.standard_normal((2 if L < 2000 else 1, L))
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")   # NOLA warnings for hops that break the overlap-add constraint
+            X = stft(x, fft_size=N, hop_size=hop, window_fn=wf)
+            Z = stft_perturb(X)   # not a consistent spectrogram (rule shared with the tests, not stored)
+            y = istft(Z, fft_size=N, hop_size=hop, window_fn=wf)
+            y_cut = istft(X, fft_size=N, hop_size=hop, window_fn=wf, length=L)
+        out.update({"x%d" % i: x, "X%d" % i: X, "y%d" % i: y, "ycut%d" % i: y_cut})
+    save("stft", cases=np.array([(L, N, hop, wf == "hamming") for L, N, hop, wf in cases]), **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
         for name in sys.argv[1:]:
@@ -435,3 +462,7 @@ if __name__ == "__main__":
     gen_ilrma()
     gen_projection_back()
     gen_edge()
+    gen_ip2()
+    gen_part()
+    gen_tilrma()
+    gen_stft()

@@ -274,3 +274,28 @@ def test_tilrma(name):
             assert rel_err(got, g["%s_%d" % (key, k)]) < 1e-9, (key, k)
     np.testing.assert_allclose(res["loss"], g["loss"], rtol=1e-10)
     assert rel_err(res["Y"], g["Y_out"]) < 1e-9
+
+
+def stft_perturb(X):
+    """Same rule as tests/golden/make_golden.py:stft_perturb."""
+    return X * (1.0 + 0.1 * np.cos(np.arange(X.size, dtype=np.float64)).reshape(X.shape)) + 0.01j
+
+
+def stft_cases():
+    g = load_golden("stft")
+    for i, (L, N, hop, hamming) in enumerate(g["cases"]):
+        yield i, int(L), int(N), int(hop), ("hamming" if hamming else "hann"), g
+
+
+def test_stft_istft():
+    """The numpy.fft restatement against scipy.signal.stft / istft as the reference calls them (stft.py:4-17)."""
+    for i, L, N, hop, wf, g in stft_cases():
+        X = orc.stft(g["x%d" % i], N, hop, wf)
+        assert X.shape == g["X%d" % i].shape
+        assert rel_err(X, g["X%d" % i]) < 1e-14
+        y = orc.istft(stft_perturb(g["X%d" % i]), N, hop, wf)
+        assert y.shape == g["y%d" % i].shape
+        assert rel_err(y, g["y%d" % i]) < 1e-14
+        ycut = orc.istft(g["X%d" % i], N, hop, wf, length=L)
+        assert ycut.shape == g["ycut%d" % i].shape
+        assert rel_err(ycut, g["ycut%d" % i]) < 1e-13
