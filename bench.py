@@ -123,6 +123,12 @@ def main():
         r = c // 2
         # algorithmic bytes per launch (weights rebuilt in-kernel from Tb,V), per utterance x B
         bytes_per_launch = B * (M * F * T * c + (M * F * K + M * K * T) * r + M * F * M * M * c)
+        kernel_name = "cov_stream_kernel"
+        if K > 4:
+            # n_basis > 4: the source variance is materialised first (write N.F.T reals), then read back as (N,F,T)
+            # weights -- the "weights materialised" contract of SURVEY.md 8d plus the map's own write
+            bytes_per_launch += B * 2 * M * F * T * r
+            kernel_name = "source_variance_map_kernel + cov_stream_kernel (N,F,T weights)"
         for _ in range(5):
             eng.ilrma_cov_partials(model._X, model._Td, model._Vd)
         stream = torch.cuda.current_stream(dev)
@@ -142,7 +148,7 @@ def main():
                 traffic = int(round(tj["traffic_bytes"] * B))
         except Exception:
             pass
-        roofline = {"bound": "hbm", "kernel": "cov_stream_kernel", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "kernel_ms": round(ms, 5), "algorithmic_bytes": bytes_per_launch}
 
