@@ -18,6 +18,7 @@ F32, F64 = 0, 1
 W_NONE, W_NT, W_NFT = 0, 1, 2
 IVA_LAPLACE, IVA_GAUSS = 0, 1
 NMF_EUC, NMF_KL, NMF_IS_MM, NMF_IS_ME = 0, 1, 2, 3
+NMF_T, NMF_CAUCHY_NAIVE, NMF_CAUCHY_MM, NMF_CAUCHY_ME, NMF_CAUCHY_MM_FAST = 4, 5, 6, 7, 8
 STATUS_SINGULAR, STATUS_COND_REJECT = 1, 2
 SPATIAL_IP, SPATIAL_ISS, SPATIAL_IP2 = 0, 1, 2
 
@@ -61,6 +62,8 @@ SIGNATURES = {
     "assx_nmf_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "assx_nmf_update": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_loss": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_nmf_update_ex": (_i, [_vp, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_nmf_loss_ex": (_i, [_vp, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_stft_num_frames": (_ll, [_ll, _i, _i]),
     "assx_istft_num_samples": (_ll, [_i, _i, _i]),
     "assx_stft_workspace_bytes": (_sz, [_i, _i, _i, _i]),

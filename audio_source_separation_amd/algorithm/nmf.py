@@ -1,5 +1,5 @@
-"""NMF by multiplicative updates on MI355X -- drop-in for `algorithm.nmf.EUCNMF / KLNMF / ISNMF`
-of the reference (/root/reference/src/algorithm/nmf.py:10-56, 150-356).
+"""NMF by multiplicative updates on MI355X -- drop-in for `algorithm.nmf.EUCNMF / KLNMF / ISNMF / tNMF / CauchyNMF`
+of the reference (/root/reference/src/algorithm/nmf.py:10-56, 150-600).
 
 Same constructors, `nmf(target, iteration=100, **kwargs) -> (basis.copy(), activation.copy())`,
 `basis` / `activation` / `loss` attributes.  `update_once()` and the per-iteration loss run as HIP
@@ -83,12 +83,15 @@ class NMFbase(DeviceState):
             raise NotImplementedError("Implement 'update_once' function")
         return self._KIND
 
+    def _kind_param(self):
+        return 0.0
+
     def update(self, iteration=100):
         for idx in range(iteration):
             self.update_once()
 
             loss = self._engine.nmf_loss(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
-                                         domain=self.domain, eps=self.eps)
+                                         domain=self.domain, eps=self.eps, param=self._kind_param())
             if isinstance(self.loss, LazyLossList):
                 self.loss.append_device(loss, self._batched)  # no host sync inside the loop
             else:
@@ -96,7 +99,7 @@ class NMFbase(DeviceState):
 
     def update_once(self):
         self._engine.nmf_update(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
-                                domain=self.domain, eps=self.eps)
+                                domain=self.domain, eps=self.eps, param=self._kind_param())
         self._touch("T", "V")
 
 
@@ -188,3 +191,72 @@ class ISNMF(NMFbase):
     def update_once_me(self):
         assert self.domain == 2, "Only domain = 2 is supported."
         NMFbase.update_once(self)
+
+
+class tNMF(NMFbase):
+    """reference: nmf.py:358-429 (Student's t NMF, MM update; domain 2 only)"""
+    _KIND = _lib.NMF_T
+
+    def __init__(self, n_basis=2, nu=1e+3, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+        """
+        Args:
+            K: number of basis
+            algorithm: 'mm': MM algorithm based update
+        """
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+
+        assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
+
+        self.nu = nu
+        self.domain = domain
+        self.algorithm = algorithm
+
+    def _kind_param(self):
+        return float(self.nu)
+
+    def update_once(self):
+        if self.algorithm == 'mm':
+            self.update_once_mm()
+        else:
+            raise ValueError("Not support {} based update.".format(self.algorithm))
+
+    def update_once_mm(self):
+        assert self.domain == 2, "`domain` is expected 2."
+        NMFbase.update_once(self)
+
+
+class CauchyNMF(NMFbase):
+    """reference: nmf.py:431-600 ('naive-multipricative', 'mm', 'me', 'mm_fast'; domain 2 only)"""
+    _ALGORITHMS = {'naive-multipricative': _lib.NMF_CAUCHY_NAIVE, 'mm': _lib.NMF_CAUCHY_MM,
+                   'me': _lib.NMF_CAUCHY_ME, 'mm_fast': _lib.NMF_CAUCHY_MM_FAST}
+
+    def __init__(self, n_basis, domain=2, algorithm='naive-multipricative', eps=EPS, *, dtype='float64', device=None):
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+
+        assert domain == 2, "Only `domain` = 2 is supported."
+
+        self.domain = domain
+        self.algorithm = algorithm
+
+    def _kind_code(self):
+        if self.algorithm not in self._ALGORITHMS:
+            raise ValueError("Not support {} based update.".format(self.algorithm))
+        return self._ALGORITHMS[self.algorithm]
+
+    def update_once(self):
+        if self.algorithm == 'naive-multipricative':
+            self.update_once_naive()
+        elif self.algorithm == 'mm':
+            self.update_once_mm()
+        elif self.algorithm == 'me':
+            self.update_once_me()
+        elif self.algorithm == 'mm_fast':
+            self.update_once_mm_fast()
+        else:
+            raise ValueError("Not support {} based update.".format(self.algorithm))
+
+    def _update_once_checked(self):
+        assert self.domain == 2, "Only 'domain' = 2 is supported."
+        NMFbase.update_once(self)
+
+    update_once_naive = update_once_mm = update_once_me = update_once_mm_fast = _update_once_checked

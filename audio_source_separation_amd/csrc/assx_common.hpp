@@ -272,7 +272,8 @@ __device__ __forceinline__ Cx<double> csqrt_principal(Cx<double> z) {
 // ------------------------------------------------------------------------------------------
 // x**e with the fast paths numpy itself takes for e in {1, 2, 0.5}; generic pow otherwise.
 // ------------------------------------------------------------------------------------------
-enum PowMode { POW_GENERIC = 0, POW_ID = 1, POW_SQUARE = 2, POW_CUBE = 3, POW_SQRT = 4 };
+enum PowMode { POW_GENERIC = 0, POW_ID = 1, POW_SQUARE = 2, POW_CUBE = 3, POW_SQRT = 4,
+               POW_CAUCHY_ME = 5 /* not a power: marks the CauchyNMF 'me' combination rule for nmf_finalize_kernel */ };
 
 struct PowSpec {
   double e;

@@ -21,9 +21,10 @@ namespace {
 constexpr int BM = 64, BN = 64, BK = 16, TM = 4, TN = 4;
 
 // kind/domain -> elementwise weights (only TV and the denominators are floored: nmf.py:312-316)
-inline TermSpec make_terms(int kind, double d) {
+inline TermSpec make_terms(int kind, double d, double p0) {
   TermSpec s;
   s.kind = kind;
+  s.p0 = p0;
   switch (kind) {
     case ASSX_NMF_EUC:  // num: X * TV^((2-d)/d)   den: TV^((4-d)/d)
       s.pa = make_pow((2.0 - d) / d);
@@ -45,7 +46,15 @@ inline PowSpec update_exponent(int kind, double d) {
     case ASSX_NMF_EUC: return make_pow(d / (4.0 - d));
     case ASSX_NMF_KL: return make_pow(d / 2.0);
     case ASSX_NMF_IS_MM: return make_pow(d / (d + 2.0));
-    default: return make_pow(1.0);  // IS me: no outer power (nmf.py:345,354)
+    case ASSX_NMF_T:
+    case ASSX_NMF_CAUCHY_MM:
+    case ASSX_NMF_CAUCHY_MM_FAST: return make_pow(0.5);  // np.sqrt (nmf.py:420,429,514,530,583,597)
+    case ASSX_NMF_CAUCHY_ME: {
+      PowSpec p = make_pow(1.0);
+      p.mode = POW_CAUCHY_ME;  // T *= B / max(A + sqrt(A^2 + 2 B A), eps)  (nmf.py:550-552)
+      return p;
+    }
+    default: return make_pow(1.0);  // IS me, Cauchy naive: no outer power (nmf.py:345,354,487)
   }
 }
 
@@ -61,19 +70,9 @@ __global__ void __launch_bounds__(256) nmf_terms_kernel(const R* __restrict__ X,
   const R* vb = V + (size_t)b * K * T + t;
   R tv = 0;
   for (int k = 0; k < K; ++k) tv = fma(tb[k], vb[(size_t)k * T], tv);
-  tv = floor_eps<R>(tv, eps);
   const R x = X[((size_t)b * F + f) * T + t];
   R a, bm;
-  if (s.kind == ASSX_NMF_EUC) {
-    a = x * pow0<R>(tv, s.pa);
-    bm = pow0<R>(tv, s.pb);
-  } else if (s.kind == ASSX_NMF_KL) {
-    a = x / tv;
-    bm = pow0<R>(tv, s.pb);
-  } else {
-    a = x / pow0<R>(tv, s.pa);
-    bm = (R)1 / tv;
-  }
+  nmf_terms<R, -1>(s, x, tv, eps, a, bm);  // floors T V where the kind's reference code does
   const size_t FT = (size_t)F * T;
   R* o = AB + (size_t)b * 2 * FT + (size_t)f * T + t;
   o[0] = a;
@@ -195,8 +194,13 @@ __global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__
   if (q == 0 && ok) {
     num = (sn[0][o] + sn[1][o]) + (sn[2][o] + sn[3][o]);
     den = (sd[0][o] + sd[1][o]) + (sd[2][o] + sd[3][o]);
-    den = floor_eps<R>(den, eps);
-    out[idx] = out[idx] * powspec<R>(num / den, p);
+    if (p.mode == POW_CAUCHY_ME) {  // num = B, den = A
+      const R d2 = floor_eps<R>(den + sqrt(fma(den, den, (R)2 * num * den)), eps);
+      out[idx] = out[idx] * (num / d2);
+    } else {
+      den = floor_eps<R>(den, eps);
+      out[idx] = out[idx] * powspec<R>(num / den, p);
+    }
   }
 }
 
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__
 template <typename R>
 __global__ void __launch_bounds__(256) nmf_loss_kernel(const R* __restrict__ X, const R* __restrict__ Tb,
                                                       const R* __restrict__ V, double* __restrict__ lpart, int F, int T,
-                                                      int K, int kind, double eps, PowSpec p2d) {
+                                                      int K, int kind, double eps, PowSpec p2d, double p0) {
   __shared__ double sm[256];
   const int f = blockIdx.y, b = blockIdx.z;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,14 +219,7 @@ __global__ void __launch_bounds__(256) nmf_loss_kernel(const R* __restrict__ X, 
     R tv = 0;
     for (int k = 0; k < K; ++k) tv = fma(tb[k], vb[(size_t)k * T], tv);
     const double in = (double)powspec<R>(tv, p2d);      // (T V) ** (2 / domain), not floored
-    const double x = (double)X[((size_t)b * F + f) * T + t];
-    if (kind == ASSX_NMF_EUC) {
-      term = (x - in) * (x - in);
-    } else {
-      const double _in = in + eps, _tg = x + eps;       // divergence.py:26-27, 39-40
-      const double ratio = _tg / _in;
-      term = (kind == ASSX_NMF_KL) ? _tg * log(ratio) + _in - _tg : ratio - log(ratio) - 1.0;
-    }
+    term = nmf_criterion(kind, in, (double)X[((size_t)b * F + f) * T + t], eps, p0);
   }
   sm[threadIdx.x] = term;
   __syncthreads();
@@ -327,16 +324,16 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
 
 // matrix-core path (n_basis <= 64): two chained-MFMA kernels + the split finalize
 template <typename R, int KT>
-int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
+int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st) {
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   R* part = (R*)((char*)ws + L.part);
-  const TermSpec ts = make_terms(kind, domain);
+  const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   int TS, tchunk, FS, fchunk;
   mfma_basis_split(B, F, T, &TS, &tchunk);
   mfma_act_split(B, F, T, &FS, &fchunk);
-  const bool d2 = domain == 2.0;  // every exponent is 0, 1 or 2: pow()-free instantiations
+  const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
   hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X, \
                      (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts)
@@ -365,21 +362,21 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double eps, const vo
 }
 
 template <typename R>
-int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
+int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st) {
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
   if (K <= NMF_MFMA_MAX_K && !no_mfma) {
     switch ((K + 15) / 16) {
-      case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-      case 2: return nmf_update_mfma<R, 2>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-      case 3: return nmf_update_mfma<R, 3>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-      default: return nmf_update_mfma<R, 4>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      case 2: return nmf_update_mfma<R, 2>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      case 3: return nmf_update_mfma<R, 3>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      default: return nmf_update_mfma<R, 4>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
     }
   }
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   R* AB = (R*)((char*)ws + L.ab);
   R* part = (R*)((char*)ws + L.part);
-  const TermSpec ts = make_terms(kind, domain);
+  const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   const size_t FT = (size_t)F * T;
   dim3 tgrid(nblocks(T, 256), F, B);
@@ -460,26 +457,41 @@ size_t assx_nmf_workspace_bytes(int B, int F, int T, int K, int dtype) {
   return nmf_ws(B, F, T, K, dtype).total;
 }
 
-int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
-                    int B, int F, int T, int K, int dtype, void* stream) {
+int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb,
+                       void* V, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
   ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
   ASSX_REQUIRE(ctx, X && Tb && V && ws, ASSX_E_NULL, "assx_nmf_update: NULL array");
-  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_IS_ME, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_CAUCHY_MM_FAST, ASSX_E_ARG, "bad NMF kind %d", kind);
   ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
   ASSX_REQUIRE(ctx, kind != ASSX_NMF_IS_ME || domain == 2.0, ASSX_E_ARG, "Only domain = 2 is supported (IS me).");
+  ASSX_REQUIRE(ctx, kind < ASSX_NMF_T || domain == 2.0, ASSX_E_ARG, "Only domain = 2 is supported (tNMF, CauchyNMF).");
+  ASSX_REQUIRE(ctx, kind != ASSX_NMF_T || param > 0.0, ASSX_E_ARG, "tNMF: nu must be > 0, got %g", param);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == ASSX_F64) return nmf_update_impl<double>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-  if (dtype == ASSX_F32) return nmf_update_impl<float>(ctx, kind, domain, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+  if (dtype == ASSX_F64) return nmf_update_impl<double>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+  if (dtype == ASSX_F32) return nmf_update_impl<float>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
   return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+}
+
+int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,
+                    int B, int F, int T, int K, int dtype, void* stream) {
+  ASSX_REQUIRE(ctx, ctx == nullptr || (kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_IS_ME), ASSX_E_ARG, "bad NMF kind %d", kind);
+  return assx_nmf_update_ex(ctx, kind, domain, 0.0, eps, X, Tb, V, ws, B, F, T, K, dtype, stream);
 }
 
 int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void* X, const void* Tb, const void* V,
                   double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
+  ASSX_REQUIRE(ctx, ctx == nullptr || (kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_IS_ME), ASSX_E_ARG, "bad NMF kind %d", kind);
+  return assx_nmf_loss_ex(ctx, kind, domain, 0.0, eps, X, Tb, V, loss, ws, B, F, T, K, dtype, stream);
+}
+
+int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* Tb,
+                     const void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
   ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
   ASSX_REQUIRE(ctx, X && Tb && V && loss && ws, ASSX_E_NULL, "assx_nmf_loss: NULL array");
-  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_IS_ME, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_CAUCHY_MM_FAST, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, kind != ASSX_NMF_T || param > 0.0, ASSX_E_ARG, "tNMF: nu must be > 0, got %g", param);
   hipStream_t st = (hipStream_t)stream;
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   double* lpart = (double*)((char*)ws + L.lpart);
@@ -492,7 +504,7 @@ int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void
     const dim3 g2((T + 15) / 16, FS, B);
 #define NMF_LOSS_LAUNCH(RT, KTV)                                                                                 \
   hipLaunchKernelGGL((nmf_loss_mfma_kernel<RT, KTV>), g2, dim3(256), 0, st, (const RT*)X, (const RT*)Tb,          \
-                     (const RT*)V, lpart, F, T, K, fchunk, k2, eps, p2d)
+                     (const RT*)V, lpart, F, T, K, fchunk, k2, eps, p2d, param)
 #define NMF_LOSS_BY_K(RT)                     \
   switch ((K + 15) / 16) {                    \
     case 1: NMF_LOSS_LAUNCH(RT, 1); break;    \
@@ -518,10 +530,10 @@ int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void
   dim3 grid(nblocks(T, 256), F, B);
   if (dtype == ASSX_F64)
     hipLaunchKernelGGL((nmf_loss_kernel<double>), grid, dim3(256), 0, st, (const double*)X, (const double*)Tb,
-                       (const double*)V, lpart, F, T, K, k2, eps, p2d);
+                       (const double*)V, lpart, F, T, K, k2, eps, p2d, param);
   else if (dtype == ASSX_F32)
     hipLaunchKernelGGL((nmf_loss_kernel<float>), grid, dim3(256), 0, st, (const float*)X, (const float*)Tb,
-                       (const float*)V, lpart, F, T, K, k2, eps, p2d);
+                       (const float*)V, lpart, F, T, K, k2, eps, p2d, param);
   else
     return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
   ASSX_LAUNCH_CHECK(ctx, "nmf_loss_kernel");

@@ -41,6 +41,7 @@ struct Mfma16<float> {
 struct TermSpec {
   int kind;
   PowSpec pa, pb;  // exponents applied to TV for the numerator / denominator weights
+  double p0;       // the kind's own parameter (tNMF: nu)
 };
 
 template <typename R>
@@ -54,6 +55,30 @@ __device__ __forceinline__ R pow0(R x, PowSpec p) {  // x**0 == 1 exactly as num
 // i.e. from 2 to 3-4 waves per SIMD to overlap one wave's elementwise / LDS phase with another's MFMA chain.
 template <typename R, int D2K = -1>
 __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R& a, R& bm) {
+  if (D2K < 0 && s.kind >= ASSX_NMF_T) {  // tNMF / CauchyNMF (domain 2), floors exactly where the reference has them
+    if (s.kind == ASSX_NMF_CAUCHY_MM_FAST) {  // nmf.py:577-588: T V is NOT floored
+      const R c = fma(tv, tv, (R)2 * x);
+      a = x / floor_eps<R>(c * tv, eps);
+      bm = tv / floor_eps<R>(c, eps);
+      return;
+    }
+    if (s.kind == ASSX_NMF_CAUCHY_ME) {  // nmf.py:548-556: T V is NOT floored; "num" carries B, "den" carries A
+      a = (R)1 / tv;
+      bm = (R)0.75 * (tv / floor_eps<R>(fma(tv, tv, x), eps));
+      return;
+    }
+    tv = floor_eps<R>(tv, eps);
+    if (s.kind == ASSX_NMF_T) {  // nmf.py:410-417
+      const R nu = (R)s.p0, z = x > eps ? x : eps;
+      const R harmonic = (R)1 / ((R)2 / (((R)2 + nu) * tv) + nu / (((R)2 + nu) * z));
+      a = harmonic / (tv * tv);
+      bm = (R)1 / tv;
+    } else {  // CAUCHY_NAIVE / CAUCHY_MM, nmf.py:478-486
+      a = (R)1 / tv;
+      bm = (R)3 * (tv / floor_eps<R>(fma(tv, tv, (R)2 * x), eps));
+    }
+    return;
+  }
   tv = floor_eps<R>(tv, eps);
   if (D2K == ASSX_NMF_EUC) {  // X * TV^0 ; TV^1
     a = x;
@@ -331,7 +356,19 @@ __global__ void __launch_bounds__(256)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// loss: sum_{f,t} criterion((Tb V)^(2/domain), X)   (nmf.py:170-174, 229-233, 288-292; divergence.py:21-45)
+// one element of criterion(in = (Tb V)^(2/domain), x)  (nmf.py:170-174, 229-233, 288-292; divergence.py:21-45;
+// t_divergence nmf.py:369-373, cauchy_divergence nmf.py:435-443)
+__device__ __forceinline__ double nmf_criterion(int kind, double in, double x, double eps, double p0) {
+  if (kind == ASSX_NMF_EUC) return (x - in) * (x - in);
+  const double _in = in + eps, _tg = x + eps;  // divergence.py:26-27, 39-40
+  const double ratio = _tg / _in;
+  if (kind == ASSX_NMF_KL) return _tg * log(ratio) + _in - _tg;
+  if (kind == ASSX_NMF_T) return log(_in) + 0.5 * (2.0 + p0) * log(1.0 + (2.0 / p0) * ratio);
+  if (kind >= ASSX_NMF_CAUCHY_NAIVE) return log(ratio) + 1.5 * log((2.0 * _tg * _tg + _in * _in) / (3.0 * _tg * _tg));
+  return ratio - log(ratio) - 1.0;
+}
+
+// loss: sum_{f,t} criterion((Tb V)^(2/domain), X)
 //   Same tiling as the activation kernel (TV sub-tiles by MFMA, elementwise in the accumulator layout);
 //   one float64 partial per workgroup: lpart[b][blockIdx.y * gridDim.x + blockIdx.x]
 // ---------------------------------------------------------------------------------------------------------
@@ -339,7 +376,7 @@ template <typename R, int KT>
 __global__ void __launch_bounds__(256)
     nmf_loss_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
                          double* __restrict__ lpart, int F, int T, int K, int fchunk, int kind, double eps,
-                         PowSpec p2d) {
+                         PowSpec p2d, double p0) {
   using MM = Mfma16<R>;
   using acc_t = typename MM::acc_t;
   constexpr int KS = KT * 4;
@@ -380,14 +417,7 @@ __global__ void __launch_bounds__(256)
       const int fr = f0 + MM::crow(r, lane);
       if (tvalid && fr < fe) {
         const double in = (double)powspec<R>(tv[r], p2d);  // (T V) ** (2 / domain), not floored
-        const double x = (double)xc[r];
-        if (kind == ASSX_NMF_EUC) {
-          acc += (x - in) * (x - in);
-        } else {
-          const double _in = in + eps, _tg = x + eps;  // divergence.py:26-27, 39-40
-          const double ratio = _tg / _in;
-          acc += (kind == ASSX_NMF_KL) ? _tg * log(ratio) + _in - _tg : ratio - log(ratio) - 1.0;
-        }
+        acc += nmf_criterion(kind, in, (double)xc[r], eps, p0);
       }
     }
   }

@@ -280,18 +280,19 @@ class Engine:
     def _nmf_scratch(self, B, F, T, K):
         return self._ws.get(L.assx_nmf_workspace_bytes(B, F, T, K, self.prec.code))
 
-    def nmf_update(self, kind, X, Tb, V, domain=2, eps=1e-12):
+    def nmf_update(self, kind, X, Tb, V, domain=2, eps=1e-12, param=0.0):
         B, F, T = (int(s) for s in X.shape)
         K = int(Tb.shape[-1])
         ws = self._nmf_scratch(B, F, T, K)
-        self._check(L.assx_nmf_update(self.ctx, int(kind), float(domain), float(eps), ptr(X), ptr(Tb), ptr(V), ptr(ws),
-                                      B, F, T, K, self.prec.code, self._st()), "assx_nmf_update")
+        self._check(L.assx_nmf_update_ex(self.ctx, int(kind), float(domain), float(param), float(eps), ptr(X), ptr(Tb),
+                                         ptr(V), ptr(ws), B, F, T, K, self.prec.code, self._st()), "assx_nmf_update_ex")
 
-    def nmf_loss(self, kind, X, Tb, V, domain=2, eps=1e-12, out=None):
+    def nmf_loss(self, kind, X, Tb, V, domain=2, eps=1e-12, out=None, param=0.0):
         B, F, T = (int(s) for s in X.shape)
         K = int(Tb.shape[-1])
         loss = out if out is not None else self.empty((B,), dtype=torch.float64)
         ws = self._nmf_scratch(B, F, T, K)
-        self._check(L.assx_nmf_loss(self.ctx, int(kind), float(domain), float(eps), ptr(X), ptr(Tb), ptr(V), ptr(loss),
-                                    ptr(ws), B, F, T, K, self.prec.code, self._st()), "assx_nmf_loss")
+        self._check(L.assx_nmf_loss_ex(self.ctx, int(kind), float(domain), float(param), float(eps), ptr(X), ptr(Tb),
+                                       ptr(V), ptr(loss), ptr(ws), B, F, T, K, self.prec.code, self._st()),
+                    "assx_nmf_loss_ex")
         return loss

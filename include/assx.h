@@ -60,7 +60,13 @@ enum { ASSX_IVA_LAPLACE = 0, ASSX_IVA_GAUSS = 1 };
 enum { ASSX_SPATIAL_IP = 0, ASSX_SPATIAL_ISS = 1, ASSX_SPATIAL_IP2 = 2 };
 
 /* NMF divergence / algorithm */
-enum { ASSX_NMF_EUC = 0, ASSX_NMF_KL = 1, ASSX_NMF_IS_MM = 2, ASSX_NMF_IS_ME = 3 };
+enum { ASSX_NMF_EUC = 0, ASSX_NMF_KL = 1, ASSX_NMF_IS_MM = 2, ASSX_NMF_IS_ME = 3,
+       /* row f4, same skeleton (assx_nmf_update_ex / assx_nmf_loss_ex only; domain 2 only): */
+       ASSX_NMF_T = 4,              /* tNMF.update_once_mm, param = nu      (nmf.py:400-429) */
+       ASSX_NMF_CAUCHY_NAIVE = 5,   /* CauchyNMF.update_once_naive          (nmf.py:468-502) */
+       ASSX_NMF_CAUCHY_MM = 6,      /* CauchyNMF.update_once_mm             (nmf.py:504-534) */
+       ASSX_NMF_CAUCHY_ME = 7,      /* CauchyNMF.update_once_me             (nmf.py:536-565) */
+       ASSX_NMF_CAUCHY_MM_FAST = 8  /* CauchyNMF.update_once_mm_fast        (nmf.py:567-600) */ };
 
 typedef struct assx_ctx assx_ctx;
 
@@ -231,6 +237,13 @@ int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const vo
  * src/criterion/divergence.py:21-45).  kind IS_ME uses the IS criterion. loss: (B,) float64. */
 int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void* X, const void* Tb, const void* V,
                   double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
+/* The same two calls for every kind of the enum, with the kind's extra parameter (ASSX_NMF_T: nu > 0; others: unused).
+ * tNMF / CauchyNMF floor exactly where the reference does (mm_fast and me leave T V itself unfloored); their losses
+ * are t_divergence (nmf.py:369-373) and cauchy_divergence (nmf.py:435-443) of (T V + eps, X + eps). */
+int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb,
+                       void* V, void* ws, int B, int F, int T, int K, int dtype, void* stream);
+int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* Tb,
+                     const void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
 
 /* ---- (f3) STFT / iSTFT either side of the loop ---------------------------------------------- */
 /* stft / istft of src/transform/stft.py:4-17, i.e. scipy.signal.stft / istft with nperseg = fft_size,

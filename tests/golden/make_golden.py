@@ -424,6 +424,39 @@ def gen_tilrma():
              T_final=model.basis, V_final=model.activation, **snap.data)
 
 
+def gen_xnmf():
+    """tNMF / CauchyNMF (the other users of the NMF skeleton), nmf.py:358-600."""
+    from algorithm.nmf import tNMF, CauchyNMF
+    cases = [("t_nu1", tNMF, dict(nu=1.0), (33, 40, 3)), ("t_nu1000", tNMF, dict(), (65, 48, 4)),
+             ("t_k20", tNMF, dict(nu=4.0), (40, 96, 20)),
+             ("cauchy_naive", CauchyNMF, dict(algorithm="naive-multipricative"), (33, 40, 3)),
+             ("cauchy_mm", CauchyNMF, dict(algorithm="mm"), (65, 48, 4)),
+             ("cauchy_me", CauchyNMF, dict(algorithm="me"), (33, 40, 3)),
+             ("cauchy_mm_fast", CauchyNMF, dict(algorithm="mm_fast"), (65, 48, 4)),
+             ("cauchy_mm_k20", CauchyNMF, dict(algorithm="mm"), (40, 96, 20))]
+    for idx, (name, cls, kw, (F, T, K)) in enumerate(cases):
+        rng = np.random.default_rng(1100 + idx)
+        X = (rng.random((F, K)) @ rng.random((K, T))) * rng.exponential(size=(F, T))
+        X[rng.random((F, T)) < 0.01] = 0.0
+        out = dict(X=X, F=F, T=T, K=K, nu=float(kw.get("nu", 1e3)), algorithm=kw.get("algorithm", "mm"),
+                   kind=name.split("_")[0], seed=70 + idx)
+        iters = (1, 2, 5, 20)
+        for k in iters:
+            np.random.seed(70 + idx)
+            model = cls(n_basis=K, **kw)
+            if k == iters[0]:
+                state = np.random.get_state()
+                out["T0"] = np.random.rand(F, K)
+                out["V0"] = np.random.rand(K, T)
+                np.random.set_state(state)
+            Tk, Vk = model(X, iteration=k)
+            out["T_%d" % k] = Tk
+            out["V_%d" % k] = Vk
+            out["loss_%d" % k] = np.asarray(model.loss, dtype=np.float64)
+        out["iters"] = np.asarray(iters)
+        save("xnmf_" + name, **out)
+
+
 def stft_perturb(X):
     """Deterministic modulation that takes a spectrogram off the set of consistent ones (also sets the imaginary
     parts of the DC / Nyquist bins, which irfft must ignore)."""
@@ -466,3 +499,4 @@ if __name__ == "__main__":
     gen_part()
     gen_tilrma()
     gen_stft()
+    gen_xnmf()

@@ -244,6 +244,28 @@ def test_nmf_golden(name):
     assert T is not model.basis and np.array_equal(T, model.basis)  # copies are returned (nmf.py:31)
 
 
+XNMF_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "xnmf_*.npz")))
+
+
+@pytest.mark.parametrize("name", XNMF_FILES)
+def test_tnmf_cauchy_nmf_classes(name):
+    """tNMF / CauchyNMF classes (nmf.py:358-600): same constructors, same global-RNG init, same outputs and losses."""
+    from audio_source_separation_amd.algorithm.nmf import tNMF, CauchyNMF
+    g = load_golden(name)
+    k = int(g["iters"][-1])
+    np.random.seed(int(g["seed"]))
+    if str(g["kind"]) == "t":
+        model = tNMF(n_basis=int(g["K"]), nu=float(g["nu"]))
+    else:
+        model = CauchyNMF(n_basis=int(g["K"]), algorithm=str(g["algorithm"]))
+    T, V = model(g["X"], iteration=k)
+    assert rel_err(T, g["T_%d" % k]) < 1e-9 and rel_err(V, g["V_%d" % k]) < 1e-9
+    assert len(model.loss) == k
+    np.testing.assert_allclose(model.loss, g["loss_%d" % k], rtol=1e-10)
+    with pytest.raises(ValueError):
+        CauchyNMF(n_basis=2, algorithm="nope")(g["X"], iteration=1)
+
+
 def test_projection_back_function():
     from audio_source_separation_amd.algorithm.projection_back import projection_back
     g = load_golden("projection_back")

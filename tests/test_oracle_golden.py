@@ -299,3 +299,23 @@ def test_stft_istft():
         ycut = orc.istft(g["X%d" % i], N, hop, wf, length=L)
         assert ycut.shape == g["ycut%d" % i].shape
         assert rel_err(ycut, g["ycut%d" % i]) < 1e-13
+
+
+XNMF_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "xnmf_*.npz")))
+
+
+def xnmf_oracle(g, k):
+    if str(g["kind"]) == "t":
+        return orc.tnmf(g["X"], int(k), g["T0"], g["V0"], float(g["nu"]))
+    return orc.cauchy_nmf(g["X"], int(k), g["T0"], g["V0"], str(g["algorithm"]))
+
+
+@pytest.mark.parametrize("name", XNMF_FILES)
+def test_tnmf_cauchy_nmf(name):
+    """tNMF / CauchyNMF restatements against the reference's classes (nmf.py:358-600)."""
+    g = load_golden(name)
+    for k in g["iters"]:
+        T, V, loss = xnmf_oracle(g, k)
+        assert rel_err(T, g["T_%d" % k]) < 1e-11
+        assert rel_err(V, g["V_%d" % k]) < 1e-11
+        np.testing.assert_allclose(loss, g["loss_%d" % k], rtol=1e-11)
