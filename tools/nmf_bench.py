@@ -13,11 +13,19 @@ X = (torch.rand((1, F, T), dtype=torch.float64, device=eng.dev, generator=g) ** 
 Tb = torch.rand((1, F, K), dtype=torch.float64, device=eng.dev, generator=g).to(eng.prec.real)
 V = torch.rand((1, K, T), dtype=torch.float64, device=eng.dev, generator=g).to(eng.prec.real)
 for name, fn in (("nmf_update IS", lambda: eng.nmf_update(_lib.NMF_IS_MM, X, Tb, V)),
-                 ("nmf_loss IS", lambda: eng.nmf_loss(_lib.NMF_IS_MM, X, Tb, V))):
+                 ("nmf_loss IS", lambda: eng.nmf_loss(_lib.NMF_IS_MM, X, Tb, V)),
+                 ("nmf_update EUC", lambda: eng.nmf_update(_lib.NMF_EUC, X, Tb, V)),
+                 ("nmf_update KL", lambda: eng.nmf_update(_lib.NMF_KL, X, Tb, V)),
+                 ("nmf_update IS d=1", lambda: eng.nmf_update(_lib.NMF_IS_MM, X, Tb, V, domain=1)),
+                 ("nmf_update t", lambda: eng.nmf_update(_lib.NMF_T, X, Tb, V, param=4.0)),
+                 ("nmf_update Cauchy mm", lambda: eng.nmf_update(_lib.NMF_CAUCHY_MM, X, Tb, V)),
+                 ("nmf_update Cauchy me", lambda: eng.nmf_update(_lib.NMF_CAUCHY_ME, X, Tb, V)),
+                 ("nmf_update Cauchy mmf", lambda: eng.nmf_update(_lib.NMF_CAUCHY_MM_FAST, X, Tb, V)),
+                 ("nmf_loss t", lambda: eng.nmf_loss(_lib.NMF_T, X, Tb, V, param=4.0))):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): fn()
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    print("%-16s %8.1f us  %6.1f TFLOP/s (12FTK)" % (name, ms * 1e3, 12 * F * T * K / ms / 1e9))
+    print("%-22s %8.1f us  %6.1f TFLOP/s (12FTK)" % (name, ms * 1e3, 12 * F * T * K / ms / 1e9))
