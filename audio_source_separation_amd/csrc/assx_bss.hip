@@ -18,6 +18,7 @@
 #include "assx_small_linalg.hpp"
 #include "assx_stream.hpp"
 #include "assx_partition.hpp"
+#include "assx_cov_wide.hpp"
 
 using namespace assx;
 
@@ -1131,6 +1132,10 @@ inline FlatPart flat_act(int B, int F, int T) {    // act_stream_kernel: ACT_NH 
   return make_flat((long long)B * tblocks(T) * F, F, g_target(8 / ACT_NH));
 }
 
+inline FlatPart flat_cov_wide(int B, int F, int T) {  // cov_wide_kernel: COVW_BINS waves per workgroup, one workgroup per CU
+  return make_flat((long long)B * ((F + COVW_BINS - 1) / COVW_BINS) * tblocks(T), tblocks(T), g_target(1));
+}
+
 inline FlatPart flat_loss(int F, int T) {  // loss_stream_kernel: per-utterance partition (grid.y = B)
   return make_flat((long long)F * tblocks(T), tblocks(T), g_target(8));
 }
@@ -1149,6 +1154,11 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   size_t p_pow = (size_t)B * M * TS * F;
   size_t p_aux = (size_t)B * FS * M * T;
   size_t pmax = p_cov;
+  if (K > KU) {  // cov_wide_kernel records: [g][slot][COVW_BINS][N][M*M]
+    const FlatPart fw = flat_cov_wide(B, F, T);
+    const size_t p_wide = (size_t)fw.G * fw.S * COVW_BINS * (M * M * M);
+    if (p_wide > pmax) pmax = p_wide;
+  }
   if (p_basis > pmax) pmax = p_basis;
   if (p_act > pmax) pmax = p_act;
   if (p_pb > pmax) pmax = p_pb;
@@ -1393,15 +1403,45 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
   return 0;
 }
 
-// n_basis > 4: covariance partials through the materialised source variance (see source_variance_map_kernel)
+// n_basis > 4: covariance without the (N,F,T) detour where the activation tile fits LDS (cov_wide_kernel; dense U
+// lands at `U_dense` and *dense is set), otherwise through the materialised source variance
+// (source_variance_map_kernel + the (N,F,T)-weights form of the streaming kernel; partial records as usual)
 template <typename R, int MM>
 int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int K, double domain, double eps,
-                       void* ws, int B, int F, int T, int dtype, hipStream_t st, FlatPart* fp_out) {
+                       void* ws, void* U_dense, int B, int F, int T, int dtype, hipStream_t st, FlatPart* fp_out,
+                       bool* dense) {
   static const int wide = env_int("ASSX_WIDE_K", 1);
+  static const int fused = env_int("ASSX_COV_WIDE", 1);
+  *dense = false;
   if (K <= KU || !wide) return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, fp_out);
   const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
-  R* rv = (R*)((char*)ws + L.map);
   const PowSpec p2d = make_pow(2.0 / domain);
+  const size_t lds = CovWideGeom<R>::lds_bytes(MM * K);
+  if (fused && U_dense && lds <= 144 * 1024 && (size_t)B * MM * K * T * sizeof(R) < 0xffffffffull) {
+    const FlatPart fw = flat_cov_wide(B, F, T);
+    const Dims d{B, F, T, K};
+    if (p2d.mode == POW_ID) {
+      if (lds > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((cov_wide_kernel<R, MM, true>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st, (const Cx<R>*)X,
+                         (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);
+    } else {
+      if (lds > 64 * 1024)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL((cov_wide_kernel<R, MM, false>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st, (const Cx<R>*)X,
+                         (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);
+    }
+    ASSX_LAUNCH_CHECK(ctx, "cov_wide_kernel");
+    hipLaunchKernelGGL((cov_wide_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)), dim3(256),
+                       0, st, (const R*)ws, (Cx<R>*)U_dense, B, F, fw, (R)(1.0 / (double)T));
+    ASSX_LAUNCH_CHECK(ctx, "cov_wide_finalize_kernel");
+    *fp_out = fw;
+    *dense = true;
+    return 0;
+  }
+  R* rv = (R*)((char*)ws + L.map);
   const dim3 grid(blocks_for(T, 256), blocks_for(F, WIDE_FB), B * MM);
   if (p2d.mode == POW_ID)
     hipLaunchKernelGGL((source_variance_map_kernel<R, true>), grid, dim3(256), 0, st, (const R*)Tb, (const R*)V, rv, F, T,
@@ -1672,17 +1712,21 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     FlatPart fp;
-    int rc = run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, B, F, T, dtype, st, &fp);
+    bool dense = false;
+    void* Ud = U_out ? U_out : (void*)((char*)ws + ws_layout(B, MM, F, T, K, dtype).u);
+    int rc = run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, Ud, B, F, T, dtype, st, &fp, &dense);
     if (rc) return rc;
-    if (U_out) {  // dense covariance on request only; the IP sweep reduces the partial records itself
+    if (U_out && !dense) {  // dense covariance on request only; the IP sweep reduces the partial records itself
       hipLaunchKernelGGL((cov_stream_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)),
                          dim3(256), 0, st, (const R*)ws, (Cx<R>*)U_out, B, MM, F, fp, (R)(1.0 / (double)T));
       ASSX_LAUNCH_CHECK(ctx, "cov_stream_finalize_kernel");
     }
-    if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, B, F, st);
+    const void* Uin = dense ? Ud : nullptr;
+    const void* pin = dense ? nullptr : ws;
+    if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, B, F, st);
     if (spatial == ASSX_SPATIAL_IP2)
-      return run_ip2<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, threshold, status, B, F, pair_m, pair_n, st);
-    return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, threshold, status, B, F, st);
+      return run_ip2<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, threshold, status, B, F, pair_m, pair_n, st);
+    return run_ip<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, threshold, status, B, F, st);
   });
 }
 
@@ -1696,7 +1740,9 @@ int assx_ilrma_cov_partials(assx_ctx* ctx, const void* X, const void* Tb, const 
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     FlatPart fp;
-    return run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, B, F, T, dtype, st, &fp);
+    bool dense = false;
+    return run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, (char*)ws + ws_layout(B, MM, F, T, K, dtype).u, B, F, T,
+                                     dtype, st, &fp, &dense);
   });
 }
 

@@ -125,10 +125,16 @@ def main():
         bytes_per_launch = B * (M * F * T * c + (M * F * K + M * K * T) * r + M * F * M * M * c)
         kernel_name = "cov_stream_kernel"
         if K > 4:
-            # n_basis > 4: the source variance is materialised first (write N.F.T reals), then read back as (N,F,T)
-            # weights -- the "weights materialised" contract of SURVEY.md 8d plus the map's own write
-            bytes_per_launch += B * 2 * M * F * T * r
-            kernel_name = "source_variance_map_kernel + cov_stream_kernel (N,F,T weights)"
+            rpi = 2 if r == 8 else 4                      # rows per LDS-direct instruction (csrc/assx_cov_wide.hpp)
+            lds = 2 * ((M * K + rpi - 1) // rpi * rpi) * 64 * r + 8 * M * K * r
+            if lds <= 144 * 1024 and os.environ.get("ASSX_COV_WIDE", "1") != "0":
+                # activation tile shared by 8 bins through LDS: still the "weights rebuilt in-kernel" contract
+                kernel_name = "cov_wide_kernel (+ cov_wide_finalize_kernel)"
+            else:
+                # the source variance is materialised first (write N.F.T reals), then read back as (N,F,T) weights --
+                # the "weights materialised" contract of SURVEY.md 8d plus the map's own write
+                bytes_per_launch += B * 2 * M * F * T * r
+                kernel_name = "source_variance_map_kernel + cov_stream_kernel (N,F,T weights)"
         for _ in range(5):
             eng.ilrma_cov_partials(model._X, model._Td, model._Vd)
         stream = torch.cuda.current_stream(dev)
