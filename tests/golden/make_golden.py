@@ -424,6 +424,51 @@ def gen_tilrma():
              T_final=model.basis, V_final=model.activation, **snap.data)
 
 
+def gen_k10():
+    """The reference's DEFAULT n_basis = 10 (ilrma.py:183) through every spatial algorithm: the n_basis > 4 kernels."""
+    def init(M, F, T, K, seed):
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        T0 = np.random.rand(M, F, K)
+        V0 = np.random.rand(M, K, T)
+        np.random.set_state(state)
+        return X, T0, V0
+
+    def tag_of(M, K, normalize, domain):
+        return "m%d_k%d_%s_d%s" % (M, K, {"power": "pow", "projection-back": "pb", False: "none"}[normalize],
+                                   str(domain).replace(".", ""))
+    K = 10
+    for seed, (M, normalize, domain) in zip((1201, 1202), [(3, "power", 2), (4, "projection-back", 1)]):
+        F, T = 33, 64
+        X, T0, V0 = init(M, F, T, K, seed)
+        snap = Snapshot(SNAP_ITERS, with_nmf=True)
+        model = GaussILRMA(domain=domain, normalize=normalize, callbacks=snap)   # n_basis left at its default
+        assert model.n_basis == K
+        Y = model(X, iteration=max(SNAP_ITERS))
+        save("ilrma_" + tag_of(M, K, normalize, domain), X=X, M=M, F=F, T=T, K=K, domain=domain,
+             normalize=np.array(str(normalize)), seed=seed, T0=T0, V0=V0, iters=np.asarray(SNAP_ITERS),
+             loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter,
+             T_final=model.basis, V_final=model.activation, **snap.data)
+    M, normalize, domain, seed = 3, "power", 2, 1203
+    X, T0, V0 = init(M, 17, 48, K, seed)
+    snap = Snapshot((1, 2, 5), with_nmf=True)
+    model = GaussILRMA(domain=domain, normalize=normalize, algorithm_spatial="ISS", callbacks=snap)
+    Y = model(X, iteration=5)
+    save("iss_ilrma_" + tag_of(M, K, normalize, domain), X=X, M=M, K=K, domain=domain, normalize=np.array(str(normalize)),
+         seed=seed, T0=T0, V0=V0, iters=np.asarray((1, 2, 5)), loss=np.asarray(model.loss), Y_out=Y,
+         W_final=model.demix_filter, T_final=model.basis, V_final=model.activation, **snap.data)
+    M, normalize, domain, seed, alg = 4, "power", 2, 1204, "IP2"
+    X, T0, V0 = init(M, 17, 48, K, seed)
+    snap = Snapshot((1, 2, 6), with_nmf=True)
+    model = GaussILRMA(domain=domain, normalize=normalize, algorithm_spatial=alg, callbacks=snap)
+    Y = model(X, iteration=6)
+    save("ip2_ilrma_" + tag_of(M, K, normalize, domain), X=X, M=M, K=K, domain=domain, normalize=np.array(str(normalize)),
+         seed=seed, T0=T0, V0=V0, alg=np.array(alg), iters=np.asarray((1, 2, 6)), loss=np.asarray(model.loss), Y_out=Y,
+         W_final=model.demix_filter, T_final=model.basis, V_final=model.activation,
+         update_pair=np.asarray(model.update_pair), **snap.data)
+
+
 def gen_xnmf():
     """tNMF / CauchyNMF (the other users of the NMF skeleton), nmf.py:358-600."""
     from algorithm.nmf import tNMF, CauchyNMF
@@ -500,3 +545,4 @@ if __name__ == "__main__":
     gen_tilrma()
     gen_stft()
     gen_xnmf()
+    gen_k10()

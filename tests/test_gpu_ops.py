@@ -522,12 +522,16 @@ def test_source_update_loss_of_entry_state(eng, few_workgroups, G, M, K, domain,
         assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("G", [0, 2, 5])
 @pytest.mark.parametrize("M,K,domain,F,T", [(4, 10, 2, 19, 150), (2, 5, 2, 8, 64), (3, 17, 1, 21, 333), (4, 70, 2, 9, 130),
                                             (2, 6, 1.5, 17, 257)])
-def test_wide_basis_path(eng, M, K, domain, F, T):
+def test_wide_basis_path(eng, few_workgroups, G, M, K, domain, F, T):
     """n_basis > 4 (the reference's default is 10): source model through the materialised demixed power + the batched
     IS-NMF update on the matrix cores, covariance through the materialised source variance, bin-batched loss; two
-    utterances, ragged F (bins are taken 8 at a time) and ragged T."""
+    utterances, ragged F (bins are taken 8 at a time) and ragged T.  G > 0 squeezes the flat partitions into a few
+    workgroups, so that a range crosses bin groups and utterances (record flush, basis-row reload, slot arithmetic)."""
+    if G:
+        few_workgroups(G)
     rng = np.random.default_rng(150 + M + K)
     Xs = [mixture(M, F, T, 151 + b) for b in range(2)]
     Ws = [rand_filters(M, F, 153 + b) for b in range(2)]
