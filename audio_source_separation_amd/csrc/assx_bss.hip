@@ -134,11 +134,11 @@ __global__ void __launch_bounds__(256) source_variance_map_kernel(const R* __res
 
 // loss data term sum_{n,f,t} P/R + log R (ilrma.py:672-675) for n_basis > 4, same bin batching; one wave per
 // workgroup, one partial per workgroup at lpart[b][blockIdx.y * gridDim.x + blockIdx.x]
-template <typename R, int M, bool D2>
+template <typename R, int M, bool D2, bool TD = false>
 __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
                                                             const R* __restrict__ Tb, const R* __restrict__ V,
                                                             double* __restrict__ lpart, int lstride, Dims d, R eps,
-                                                            PowSpec p2d) {
+                                                            PowSpec p2d, R nu = 0) {
   const int F = d.F, T = d.T, K = d.K;
   const int f0 = blockIdx.y * WIDE_FB, b = blockIdx.z;
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -163,8 +163,8 @@ __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __rest
     for (int j = 0; j < WIDE_FB; ++j) r[n][j] = floor_eps<R>(D2 ? r[n][j] : powspec<R>(r[n][j], p2d), eps);
   }
   const size_t FT = (size_t)F * T;
-  double acc = 0.0, lm = 1.0;
-  int le = 0;
+  double acc = 0.0, lm = 1.0, tm = 1.0;  // TD: t-ILRMA terms (ilrma.py:1001-1018), see loss_stream_kernel
+  int le = 0, te = 0;
 #pragma unroll
   for (int j = 0; j < WIDE_FB; ++j) {
     if (f0 + j >= F) break;  // wave-uniform
@@ -175,10 +175,11 @@ __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __rest
 #pragma unroll
     for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
     demix<R, M>(w, x, y);
-    double term = 0.0, rprod = 1.0;
+    double term = 0.0, rprod = 1.0, tprod = 1.0;
 #pragma unroll
     for (int n = 0; n < M; ++n) {
-      term += (double)(cabs2(y[n]) * fast_rcp(r[n][j]));
+      if (TD) tprod *= fma((double)((R)2 * fast_rcp(nu)), (double)(cabs2(y[n]) * fast_rcp(r[n][j])), 1.0);
+      else term += (double)(cabs2(y[n]) * fast_rcp(r[n][j]));
       rprod *= (double)r[n][j];
     }
     if (live) {
@@ -186,9 +187,14 @@ __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __rest
       int e;
       lm = frexp(lm * rprod, &e);
       le += e;
+      if (TD) {
+        tm = frexp(tm * tprod, &e);
+        te += e;
+      }
     }
   }
   acc += (double)le * 0.6931471805599453 + log(lm);
+  if (TD) acc += (1.0 + 0.5 * (double)nu) * ((double)te * 0.6931471805599453 + log(tm));
   acc = wave_allreduce_sum<double>(acc);
   if (threadIdx.x == 0) lpart[(size_t)b * lstride + (size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
 }
@@ -1094,6 +1100,52 @@ __global__ void __launch_bounds__(256) tilrma_xi_kernel(const Cx<R>* __restrict_
   }
 }
 
+// n_basis > 4 form of tilrma_xi_kernel: a thread owns one frame of WIDE_FB consecutive bins (the K activations it loads
+// serve all of them, see source_variance_map_kernel)
+template <typename R, int M>
+__global__ void __launch_bounds__(64) tilrma_xi_wide_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                           const R* __restrict__ Tb, const R* __restrict__ V,
+                                                           R* __restrict__ Xi, Dims d, R nu, R eps) {
+  constexpr int N = M;
+  const int F = d.F, T = d.T, K = d.K;
+  const int f0 = blockIdx.y * WIDE_FB, b = blockIdx.z;
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= T) return;
+  int row[WIDE_FB];
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j) row[j] = (f0 + j < F ? f0 + j : F - 1) * K;
+  R r[N][WIDE_FB];
+#pragma unroll
+  for (int n = 0; n < N; ++n) {
+    const R* vb = V + ((size_t)b * N + n) * K * T + t;
+    const R* tb = Tb + ((size_t)b * N + n) * F * K;
+#pragma unroll
+    for (int j = 0; j < WIDE_FB; ++j) r[n][j] = 0;
+    for (int k = 0; k < K; ++k) {
+      const R v = vb[(size_t)k * T];
+#pragma unroll
+      for (int j = 0; j < WIDE_FB; ++j) r[n][j] = fma(tb[row[j] + k], v, r[n][j]);
+    }
+  }
+  const size_t FT = (size_t)F * T;
+  const R inv = fast_rcp(nu + (R)2);
+#pragma unroll
+  for (int j = 0; j < WIDE_FB; ++j) {
+    if (f0 + j >= F) break;
+    Cx<R> w[M][M];
+    load_filter<R, M>(W, (size_t)b * F + f0 + j, w);
+    const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)(f0 + j) * T + t;
+    Cx<R> x[M], y[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
+    demix<R, M>(w, x, y);
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+      Xi[((size_t)b * N + n) * FT + (size_t)(f0 + j) * T + t] =
+          fma(nu, floor_eps<R>(r[n][j], eps), (R)2 * cabs2(y[n])) * inv;
+  }
+}
+
 struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte aligned
   size_t part;     // reduction partials (largest user: activation update)
   size_t u;        // dense U (B,N,F,M,M) complex
@@ -1866,11 +1918,14 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
     const PowSpec p2d = make_pow(2.0 / domain);
     const bool d2 = p2d.mode == POW_ID, k4 = K <= KU;
     static const int wide = env_int("ASSX_WIDE_K", 1);
-    if (!k4 && wide && nu < 0.0) {  // n_basis > 4: bin-batched evaluation (ilrma_loss_wide_kernel)
+    if (!k4 && wide) {  // n_basis > 4: bin-batched evaluation (ilrma_loss_wide_kernel)
       const dim3 gw(blocks_for(T, 64), blocks_for(F, WIDE_FB), B);
       const int nw = (int)(gw.x * gw.y), lsw = nw + F;
       if ((size_t)B * lsw * sizeof(double) <= L.small - L.lpart) {
-        if (d2)
+        if (nu >= 0.0)
+          hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, true, true>), gw, dim3(64), 0, st, (const Cx<R>*)X,
+                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d, (R)nu);
+        else if (d2)
           hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, true>), gw, dim3(64), 0, st, (const Cx<R>*)X,
                              (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d);
         else
@@ -1944,6 +1999,16 @@ int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void*
     constexpr int MM = decltype(mt)::value;
     const PowSpec p2 = make_pow(0.5);
     FlatPart fp;
+    static const int wide = env_int("ASSX_WIDE_K", 1);
+    if (K > KU && wide) {  // n_basis > 4: P = |W x|^2 once, then the batched tNMF-type update on the matrix cores
+      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+      R* pw = (R*)((char*)ws + L.map);
+      hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                         (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
+      ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      return assx_nmf_update_ex(ctx, ASSX_NMF_T_RAW, 2.0, nu, eps, pw, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype,
+                                stream);
+    }
     int rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, 2.0, eps, ws, B, F, T, K, st, &fp, nu);
     if (rc) return rc;
     hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
@@ -1971,8 +2036,14 @@ int assx_tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    hipLaunchKernelGGL((tilrma_xi_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
-                       (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)Xi, Dims{B, F, T, K}, (R)nu, (R)eps);
+    static const int wide = env_int("ASSX_WIDE_K", 1);
+    if (K > KU && wide)
+      hipLaunchKernelGGL((tilrma_xi_wide_kernel<R, MM>), dim3(blocks_for(T, 64), blocks_for(F, WIDE_FB), B), dim3(64), 0,
+                         st, (const Cx<R>*)X, (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)Xi, Dims{B, F, T, K},
+                         (R)nu, (R)eps);
+    else
+      hipLaunchKernelGGL((tilrma_xi_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
+                         (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)Xi, Dims{B, F, T, K}, (R)nu, (R)eps);
     ASSX_LAUNCH_CHECK(ctx, "tilrma_xi_kernel");
     FlatPart fp;
     // Xi is used as is (the reference does not floor it): eps = 0 in the covariance pass

@@ -47,6 +47,7 @@ inline PowSpec update_exponent(int kind, double d) {
     case ASSX_NMF_KL: return make_pow(d / 2.0);
     case ASSX_NMF_IS_MM: return make_pow(d / (d + 2.0));
     case ASSX_NMF_T:
+    case ASSX_NMF_T_RAW:
     case ASSX_NMF_CAUCHY_MM:
     case ASSX_NMF_CAUCHY_MM_FAST: return make_pow(0.5);  // np.sqrt (nmf.py:420,429,514,530,583,597)
     case ASSX_NMF_CAUCHY_ME: {
@@ -462,7 +463,8 @@ int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, dou
   ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
   ASSX_REQUIRE(ctx, X && Tb && V && ws, ASSX_E_NULL, "assx_nmf_update: NULL array");
-  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_CAUCHY_MM_FAST, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_T_RAW, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, kind != ASSX_NMF_T_RAW || param >= 0.0, ASSX_E_ARG, "nu must be >= 0, got %g", param);
   ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
   ASSX_REQUIRE(ctx, kind != ASSX_NMF_IS_ME || domain == 2.0, ASSX_E_ARG, "Only domain = 2 is supported (IS me).");
   ASSX_REQUIRE(ctx, kind < ASSX_NMF_T || domain == 2.0, ASSX_E_ARG, "Only domain = 2 is supported (tNMF, CauchyNMF).");

@@ -68,8 +68,8 @@ __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R
       return;
     }
     tv = floor_eps<R>(tv, eps);
-    if (s.kind == ASSX_NMF_T) {  // nmf.py:410-417
-      const R nu = (R)s.p0, z = x > eps ? x : eps;
+    if (s.kind == ASSX_NMF_T || s.kind == ASSX_NMF_T_RAW) {  // nmf.py:410-417; T_RAW: ilrma.py:903-906 (P as is)
+      const R nu = (R)s.p0, z = (s.kind == ASSX_NMF_T && x < eps) ? eps : x;
       const R harmonic = (R)1 / ((R)2 / (((R)2 + nu) * tv) + nu / (((R)2 + nu) * z));
       a = harmonic / (tv * tv);
       bm = (R)1 / tv;

@@ -66,7 +66,9 @@ enum { ASSX_NMF_EUC = 0, ASSX_NMF_KL = 1, ASSX_NMF_IS_MM = 2, ASSX_NMF_IS_ME = 3
        ASSX_NMF_CAUCHY_NAIVE = 5,   /* CauchyNMF.update_once_naive          (nmf.py:468-502) */
        ASSX_NMF_CAUCHY_MM = 6,      /* CauchyNMF.update_once_mm             (nmf.py:504-534) */
        ASSX_NMF_CAUCHY_ME = 7,      /* CauchyNMF.update_once_me             (nmf.py:536-565) */
-       ASSX_NMF_CAUCHY_MM_FAST = 8  /* CauchyNMF.update_once_mm_fast        (nmf.py:567-600) */ };
+       ASSX_NMF_CAUCHY_MM_FAST = 8, /* CauchyNMF.update_once_mm_fast        (nmf.py:567-600) */
+       ASSX_NMF_T_RAW = 9           /* tILRMA source model on a demixed power: ASSX_NMF_T with the target NOT floored,
+                                       param = nu >= 0 (ilrma.py:899-922); update only */ };
 
 typedef struct assx_ctx assx_ctx;
 

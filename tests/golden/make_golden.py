@@ -469,6 +469,25 @@ def gen_k10():
          update_pair=np.asarray(model.update_pair), **snap.data)
 
 
+def gen_tilrma_k10():
+    """tILRMA at its default n_basis = 10 (ilrma.py:713)."""
+    seed, M, K, nu, normalize, F, T = 1301, 3, 10, 5, "power", 17, 72
+    X = convolutive_mixture(M, F, T, seed=seed)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    T0 = np.random.rand(M, F, K)
+    V0 = np.random.rand(M, K, T)
+    np.random.set_state(state)
+    snap_iters = (1, 2, 5)
+    snap = Snapshot(snap_iters, with_nmf=True)
+    model = tILRMA(nu=nu, normalize=normalize, callbacks=snap)
+    assert model.n_basis == K
+    Y = model(X, iteration=5)
+    save("tilrma_m3_k10_nu5_pow", X=X, M=M, K=K, nu=float(nu), normalize=np.array(str(normalize)), seed=seed, T0=T0, V0=V0,
+         iters=np.asarray(snap_iters), loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter,
+         T_final=model.basis, V_final=model.activation, **snap.data)
+
+
 def gen_xnmf():
     """tNMF / CauchyNMF (the other users of the NMF skeleton), nmf.py:358-600."""
     from algorithm.nmf import tNMF, CauchyNMF
@@ -546,3 +565,4 @@ if __name__ == "__main__":
     gen_stft()
     gen_xnmf()
     gen_k10()
+    gen_tilrma_k10()

@@ -406,7 +406,7 @@ def test_partitioned_expand_and_normalize(eng):
     assert rel_err(host(Wd), W / aux[:, None, :, None]) < tol(eng, 1e-13, 1e-5)
 
 
-@pytest.mark.parametrize("M,K,nu", [(2, 2, 1.0), (3, 4, 5.0), (4, 4, 100.0), (4, 7, 2.5)])
+@pytest.mark.parametrize("M,K,nu", [(2, 2, 1.0), (3, 4, 5.0), (4, 4, 100.0), (4, 7, 2.5), (3, 10, 5.0), (4, 18, 1.0)])
 def test_tilrma_stages(eng, M, K, nu):
     """t-ILRMA source model, spatial model and loss, one stage at a time, vs the oracle (ilrma.py:880-1018)."""
     F, T = 19, 150
