@@ -77,7 +77,8 @@ int assx_ctx_create(int device, assx_ctx** ctx);
 int assx_ctx_destroy(assx_ctx* ctx);
 const char* assx_last_error(const assx_ctx* ctx);
 const char* assx_version(void);
-/* scratch bytes sufficient for any call below at these sizes */
+/* scratch bytes sufficient for any call below at these sizes (n_basis > 4 adds one (B,N,F,T) real array and the
+ * scratch of the batched NMF update: the source model then runs on the matrix cores) */
 size_t assx_workspace_bytes(int B, int M, int F, int T, int K, int dtype);
 
 /* ---- (a3) demixing  y = W x ----------------------------------------------------------- */
@@ -160,7 +161,9 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n
                               int B, int M, int F, int T, int K, int dtype, void* stream);
 
 /* Stage 1 of assx_ilrma_spatial_update alone: ONE launch of the covariance-accumulate kernel (packed
- * Hermitian partial sums into ws).  Exposed so a harness can time exactly that kernel with HIP events. */
+ * Hermitian partial sums into ws).  Exposed so a harness can time exactly that kernel with HIP events.
+ * n_basis > 4: the launch is cov_wide_kernel + its small finalize (dense U inside ws), or, when the activation
+ * tile does not fit LDS, the source-variance map + the (N,F,T)-weights form of the streaming kernel. */
 int assx_ilrma_cov_partials(assx_ctx* ctx, const void* X, const void* Tb, const void* V, double domain, double eps,
                             void* ws, int B, int M, int F, int T, int K, int dtype, void* stream);
 
