@@ -138,7 +138,8 @@ template <typename R, int M, bool D2, bool TD = false>
 __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
                                                             const R* __restrict__ Tb, const R* __restrict__ V,
                                                             double* __restrict__ lpart, int lstride, Dims d, R eps,
-                                                            PowSpec p2d, R nu = 0) {
+                                                            PowSpec p2d, R nu = 0,
+                                                            R* __restrict__ P_out = nullptr /* (B,N,F,T) |W x|^2 */) {
   const int F = d.F, T = d.T, K = d.K;
   const int f0 = blockIdx.y * WIDE_FB, b = blockIdx.z;
   const int t = blockIdx.x * 64 + threadIdx.x;
@@ -175,6 +176,10 @@ __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __rest
 #pragma unroll
     for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
     demix<R, M>(w, x, y);
+    if (P_out && live) {  // the source-model pass that follows needs exactly this map (demix_power_map_kernel)
+#pragma unroll
+      for (int n = 0; n < M; ++n) P_out[((size_t)b * M + n) * FT + (size_t)(f0 + j) * T + t] = cabs2(y[n]);
+    }
     double term = 0.0, rprod = 1.0, tprod = 1.0;
 #pragma unroll
     for (int n = 0; n < M; ++n) {
@@ -1590,7 +1595,8 @@ int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, 
 // forward declaration (defined with the loss entry points)
 static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const void* W, const void* Tb,
                            const void* V, double domain, double nu, double eps, double* loss, void* ws, int B, int M,
-                           int F, int T, int K, int dtype, void* stream);
+                           int F, int T, int K, int dtype, void* stream, void* P_out = nullptr,
+                           bool* wrote_P = nullptr);
 
 int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double domain, double eps,
                              unsigned source_mask, double* loss_prev, void* ws, int B, int M, int F, int T, int K,
@@ -1610,11 +1616,16 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     // K <= 4, LDS-ring kernel), otherwise a pass of its own before anything is updated
     double* lpart = nullptr;
     int lstride = 0;
+    static const int wide_k = env_int("ASSX_WIDE_K", 1);
+    const bool full_mask = (source_mask & ((1u << MM) - 1u)) == ((1u << MM) - 1u);
+    bool have_map = false;
     if (loss_prev) {
       const bool fusable = domain == 2.0 && K <= KU && env_int("ASSX_BASIS_VDMA", 1) && env_int("ASSX_FUSE_LOSS", 1);
       if (!fusable) {
+        // n_basis > 4: the loss pass forms |W x|^2 anyway and leaves it behind as the map the source model needs
+        void* pmap = (K > KU && wide_k && full_mask) ? (void*)((char*)ws + ws_layout(B, MM, F, T, K, dtype).map) : nullptr;
         rc = ilrma_loss_impl(ctx, "assx_ilrma_source_update", X, W, Tb, V, domain, -1.0, eps, loss_prev, ws, B, MM, F, T,
-                             K, dtype, stream);
+                             K, dtype, stream, pmap, &have_map);
         if (rc) return rc;
       } else {
         const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
@@ -1629,15 +1640,16 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
       }
     }
-    static const int wide = env_int("ASSX_WIDE_K", 1);
-    if (K > KU && wide && (source_mask & ((1u << MM) - 1u)) == ((1u << MM) - 1u)) {
+    if (K > KU && wide_k && full_mask) {
       // n_basis > 4: P = |W x|^2 once, then the batched IS-NMF MM update on the matrix cores (same update rule,
       // ilrma.py:409-430 == nmf.py:302-327 with target P)
       const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
       R* pw = (R*)((char*)ws + L.map);
-      hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
-                         (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
-      ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      if (!have_map) {
+        hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                           (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
+        ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      }
       return assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype,
                              stream);
     }
@@ -1899,7 +1911,7 @@ int assx_ilrma_normalize_pb(assx_ctx* ctx, void* W, void* Tb, const void* scale,
 
 static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const void* W, const void* Tb,
                            const void* V, double domain, double nu, double eps, double* loss, void* ws, int B, int M,
-                           int F, int T, int K, int dtype, void* stream) {
+                           int F, int T, int K, int dtype, void* stream, void* P_out, bool* wrote_P) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Tb && V && loss && ws, ASSX_E_NULL, "%s: NULL array", who);
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
@@ -1924,14 +1936,15 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
       if ((size_t)B * lsw * sizeof(double) <= L.small - L.lpart) {
         if (nu >= 0.0)
           hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, true, true>), gw, dim3(64), 0, st, (const Cx<R>*)X,
-                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d, (R)nu);
+                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d, (R)nu, (R*)P_out);
         else if (d2)
           hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, true>), gw, dim3(64), 0, st, (const Cx<R>*)X,
-                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d);
+                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d, (R)0, (R*)P_out);
         else
           hipLaunchKernelGGL((ilrma_loss_wide_kernel<R, MM, false>), gw, dim3(64), 0, st, (const Cx<R>*)X,
-                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d);
+                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lsw, a.d, a.eps, p2d, (R)0, (R*)P_out);
         ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_wide_kernel");
+        if (wrote_P) *wrote_P = P_out != nullptr;
         hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st,
                            (const Cx<R>*)W, lpart, B, F, T, lsw, nw);
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
