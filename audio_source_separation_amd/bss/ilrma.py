@@ -460,6 +460,58 @@ class GaussILRMA(ILRMAbase):
         return np.float64(loss.item())
 
 
+class ConsistentGaussILRMA(GaussILRMA):
+    """
+    Reference: "Consistent independent low-rank matrix analysis for determined blind source separation"
+    See https://asp-eurasipjournals.springeropen.com/articles/10.1186/s13634-020-00704-4
+    (reference implementation: ilrma.py:1089-1233)
+
+    The reference supports IP only, and with IP its `update_once` recomputes the estimate from the demixing filters
+    (ilrma.py:356-366), so the istft -> stft projection of `estimation` it performs first (ilrma.py:1206-1207) never
+    reaches the model: what remains is Gauss-ILRMA with the projection-back rescaling of W and T after every
+    iteration (ilrma.py:1219-1229).  That is what runs here; the projection itself is not recomputed.
+    """
+
+    def __init__(self, n_basis=10, partitioning=False, algorithm_spatial='IP', reference_id=0, fft_size=None,
+                 hop_size=None, callbacks=None, recordable_loss=True, eps=EPS, threshold=THRESHOLD, *,
+                 dtype='float64', device=None):
+        super().__init__(n_basis=n_basis, partitioning=partitioning, normalize=False,
+                         algorithm_spatial=algorithm_spatial, reference_id=reference_id, callbacks=callbacks,
+                         recordable_loss=recordable_loss, eps=eps, threshold=threshold, dtype=dtype, device=device)
+
+        if fft_size is None:
+            raise ValueError("Specify `fft_size`.")
+
+        if hop_size is None:
+            hop_size = fft_size // 2
+
+        self.fft_size, self.hop_size = fft_size, hop_size
+
+        assert self.algorithm_spatial == 'IP', "Supports only IP-based spatial update."
+
+    def __repr__(self):
+        s = "Consistent-GaussILRMA("
+        s += "n_basis={n_basis}"
+        s += ", domain={domain}"
+        s += ", partitioning={partitioning}"
+        s += ", normalize={normalize}"
+        s += ", algorithm_spatial={algorithm_spatial}"
+        s += ")"
+
+        return s.format(**self.__dict__)
+
+    def update_once(self):
+        if self.n_bins != self.fft_size // 2 + 1:
+            raise ValueError("n_bins = {} does not match fft_size = {}.".format(self.n_bins, self.fft_size))
+        if self.partitioning:
+            raise NotImplementedError("Not support 'projection-back' based normalization for partitioninig function. Choose 'power' based normalization.")
+        self.normalize = 'projection-back'  # ilrma.py:1219-1229 == the 'projection-back' block of GaussILRMA.update_once
+        try:
+            GaussILRMA.update_once(self)
+        finally:
+            self.normalize = False
+
+
 class tILRMA(ILRMAbase):
     """
     Reference: "Independent low-rank matrix analysis based on complex student's t-distribution for blind audio source separation"

@@ -488,6 +488,25 @@ def gen_tilrma_k10():
          T_final=model.basis, V_final=model.activation, **snap.data)
 
 
+def gen_consistent():
+    """ConsistentGaussILRMA (ilrma.py:1089-1233), IP only."""
+    from bss.ilrma import ConsistentGaussILRMA
+    seed, M, K, fft_size = 1401, 3, 4, 32
+    F, T = fft_size // 2 + 1, 40
+    X = convolutive_mixture(M, F, T, seed=seed)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    T0 = np.random.rand(M, F, K)
+    V0 = np.random.rand(M, K, T)
+    np.random.set_state(state)
+    snap = Snapshot((1, 2, 5), with_nmf=True)
+    model = ConsistentGaussILRMA(n_basis=K, fft_size=fft_size, hop_size=fft_size // 2, callbacks=snap)
+    Y = model(X, iteration=5)
+    save("consistent_ilrma_m3_k4", X=X, M=M, K=K, fft_size=fft_size, seed=seed, T0=T0, V0=V0,
+         iters=np.asarray((1, 2, 5)), loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter,
+         T_final=model.basis, V_final=model.activation, repr=np.array(repr(model)), **snap.data)
+
+
 def gen_xnmf():
     """tNMF / CauchyNMF (the other users of the NMF skeleton), nmf.py:358-600."""
     from algorithm.nmf import tNMF, CauchyNMF
@@ -566,3 +585,4 @@ if __name__ == "__main__":
     gen_xnmf()
     gen_k10()
     gen_tilrma_k10()
+    gen_consistent()

@@ -319,3 +319,17 @@ def test_tnmf_cauchy_nmf(name):
         assert rel_err(T, g["T_%d" % k]) < 1e-11
         assert rel_err(V, g["V_%d" % k]) < 1e-11
         np.testing.assert_allclose(loss, g["loss_%d" % k], rtol=1e-11)
+
+
+def test_consistent_gauss_ilrma():
+    """ConsistentGaussILRMA (ilrma.py:1089-1233, IP only) == Gauss-ILRMA with the projection-back rescaling after
+    every iteration: with IP the reference recomputes the estimate from W, so its istft -> stft projection of
+    `estimation` never reaches the model.  Pinned on the reference's own output."""
+    g = load_golden("consistent_ilrma_m3_k4")
+    iters = [int(k) for k in g["iters"]]
+    out = orc.gauss_ilrma(g["X"], max(iters), g["T0"], g["V0"], normalize="projection-back", snapshots=iters)
+    for k in iters:
+        W, T, V = out["snapshots"][k]
+        assert rel_err(W, g["W_%d" % k]) < 1e-9 and rel_err(T, g["T_%d" % k]) < 1e-9 and rel_err(V, g["V_%d" % k]) < 1e-9
+    np.testing.assert_allclose(out["loss"], g["loss"], rtol=1e-10)
+    assert rel_err(out["Y"], g["Y_out"]) < 1e-9
