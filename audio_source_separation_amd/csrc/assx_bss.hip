@@ -19,6 +19,7 @@
 #include "assx_stream.hpp"
 #include "assx_partition.hpp"
 #include "assx_cov_wide.hpp"
+#include "assx_nmf_internal.hpp"
 
 using namespace assx;
 
@@ -1215,6 +1216,8 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
     const FlatPart fw = flat_cov_wide(B, F, T);
     const size_t p_wide = (size_t)fw.G * fw.S * COVW_BINS * (M * M * M);
     if (p_wide > pmax) pmax = p_wide;
+    const size_t p_adapt = (size_t)B * tblocks(T) * M * 2 * Kc * WAVE;  // part_adapt_act_kernel records
+    if (p_adapt > pmax) pmax = p_adapt;
   }
   if (p_basis > pmax) pmax = p_basis;
   if (p_act > pmax) pmax = p_act;
@@ -1712,6 +1715,52 @@ int assx_ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const voi
     };
     FlatPart fp;
     int rc;
+    static const int wide = env_int("ASSX_WIDE_K", 1);
+    if (K > KU && K <= 64 && wide) {
+      // n_basis > 4: the three sets of per-source sums come from the NMF matrix-core kernels on P = |W x|^2 (formed
+      // once: W does not move here) with the effective model, batch B*N; adapters lay them out as the records the
+      // combination kernels read
+      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+      R* pw = (R*)((char*)ws + L.map);
+      void* nws = (char*)ws + L.nmf;
+      hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                         (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
+      ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      const int TBk = tblocks(T);
+      const FlatPart fpb{(long long)B * F * TBk, TBk, TBk, B * F, 1};   // one record per bin
+      const FlatPart fpa{(long long)B * TBk * F, F, F, B * TBk, 1};     // one record per frame block
+      auto sums = [&](int half) -> int {
+        const void* np = nullptr;
+        int slabs = 0;
+        int r2 = nmf_half_partials(ctx, ASSX_NMF_IS_MM, 2.0, 0.0, eps, half, pw, Teff, Veff, nws, B * MM, F, T, K, dtype,
+                                   st, &np, &slabs);
+        if (r2) return r2;
+        if (half == NMF_HALF_BASIS)
+          hipLaunchKernelGGL((part_adapt_basis_kernel<R>), dim3(blocks_for((size_t)B * F * MM * 2 * K, 256)), dim3(256), 0,
+                             st, (const R*)np, (R*)ws, B, MM, F, K, slabs);
+        else
+          hipLaunchKernelGGL((part_adapt_act_kernel<R>), dim3(blocks_for((size_t)B * TBk * MM * 2 * K * WAVE, 256)),
+                             dim3(256), 0, st, (const R*)np, (R*)ws, B, MM, K, T, slabs);
+        ASSX_LAUNCH_CHECK(ctx, "part_adapt_kernel");
+        return 0;
+      };
+      if ((rc = expand(true))) return rc;
+      if ((rc = sums(NMF_HALF_BASIS))) return rc;
+      hipLaunchKernelGGL((part_latent_kernel<R, MM>), dim3(K, B), dim3(256), 0, st, (const R*)ws, (const R*)Tb, (R*)Z, F,
+                         K, fpb, (R)eps);
+      ASSX_LAUNCH_CHECK(ctx, "part_latent_kernel");
+      if ((rc = expand(false))) return rc;
+      if ((rc = sums(NMF_HALF_BASIS))) return rc;
+      hipLaunchKernelGGL((part_basis_kernel<R>), dim3(blocks_for((size_t)B * F * K, 256)), dim3(256), 0, st,
+                         (const R*)ws, (const R*)Z, (R*)Tb, B, MM, F, K, fpb, (R)eps);
+      ASSX_LAUNCH_CHECK(ctx, "part_basis_kernel");
+      if ((rc = expand(false))) return rc;
+      if ((rc = sums(NMF_HALF_ACT))) return rc;
+      hipLaunchKernelGGL((part_act_kernel<R>), dim3(blocks_for((size_t)B * K * T, 256)), dim3(256), 0, st, (const R*)ws,
+                         (R*)V, B, MM, F, K, T, fpa, (R)eps);
+      ASSX_LAUNCH_CHECK(ctx, "part_act_kernel");
+      return expand(true);
+    }
     // ---- latent variables (ilrma.py:368-387)
     if ((rc = expand(true))) return rc;
     if ((rc = run_basis_partial<R, MM>(ctx, X, W, Teff, Veff, 2.0, eps, ws, B, F, T, K, st, &fp))) return rc;

@@ -14,6 +14,8 @@
 #include "assx_common.hpp"
 #include "assx_nmf_mfma.hpp"
 
+#include "assx_nmf_internal.hpp"
+
 using namespace assx;
 
 namespace {
@@ -450,6 +452,53 @@ int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double
 }
 
 }  // namespace
+
+namespace assx {
+
+template <typename R, int KT>
+static int nmf_half_launch(assx_ctx* ctx, const TermSpec& ts, int half, const void* X, const void* Tb, const void* V,
+                           R* part, int B, int F, int T, int K, double eps, hipStream_t st, int* slabs) {
+  int TS, tchunk, FS, fchunk;
+  mfma_basis_split(B, F, T, &TS, &tchunk);
+  mfma_act_split(B, F, T, &FS, &fchunk);
+  if (half == NMF_HALF_BASIS) {
+    hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, -1>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X,
+                       (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts);
+    *slabs = TS;
+  } else {
+    hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, -1>), dim3((T + 15) / 16, FS, B), dim3(256), 0, st, (const R*)X,
+                       (const R*)Tb, (const R*)V, part, B, F, T, K, fchunk, (R)eps, ts);
+    *slabs = FS;
+  }
+  ASSX_LAUNCH_CHECK(ctx, "nmf half kernel");
+  return 0;
+}
+
+int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, double eps, int half, const void* X,
+                      const void* Tb, const void* V, void* ws, int B, int F, int T, int K, int dtype, hipStream_t st,
+                      const void** part, int* slabs) {
+  if (K > NMF_MFMA_MAX_K) return fail(ctx, ASSX_E_UNSUPPORTED, "nmf_half_partials: n_basis %d > %d", K, NMF_MFMA_MAX_K);
+  const NmfWs L = nmf_ws(B, F, T, K, dtype);
+  const TermSpec ts = make_terms(kind, domain, param);
+  void* p = (char*)ws + L.part;
+  *part = p;
+#define HALF_BY_K(RT)                                                                                              \
+  switch ((K + 15) / 16) {                                                                                         \
+    case 1: return nmf_half_launch<RT, 1>(ctx, ts, half, X, Tb, V, (RT*)p, B, F, T, K, eps, st, slabs);            \
+    case 2: return nmf_half_launch<RT, 2>(ctx, ts, half, X, Tb, V, (RT*)p, B, F, T, K, eps, st, slabs);            \
+    case 3: return nmf_half_launch<RT, 3>(ctx, ts, half, X, Tb, V, (RT*)p, B, F, T, K, eps, st, slabs);            \
+    default: return nmf_half_launch<RT, 4>(ctx, ts, half, X, Tb, V, (RT*)p, B, F, T, K, eps, st, slabs);           \
+  }
+  if (dtype == ASSX_F64) {
+    HALF_BY_K(double)
+  } else if (dtype == ASSX_F32) {
+    HALF_BY_K(float)
+  }
+#undef HALF_BY_K
+  return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+}
+
+}  // namespace assx
 
 extern "C" {
 

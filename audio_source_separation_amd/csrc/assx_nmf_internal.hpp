@@ -1,0 +1,20 @@
+// Library-internal door into the NMF matrix-core kernels (not part of the C-ABI): one half of an update, stopped
+// before the combination step, for callers that combine the per-element sums differently (the partitioning-function
+// source model of ILRMA, ilrma.py:368-408).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/assx.h"
+
+namespace assx {
+
+constexpr int NMF_HALF_BASIS = 0, NMF_HALF_ACT = 1;
+
+// Launches the basis (reduce over t) or activation (reduce over f) kernel of `kind` on X (B,F,T), Tb (B,F,K),
+// V (B,K,T) and leaves the split partial sums in `ws` (assx_nmf_workspace_bytes):
+//   basis:      part[slab][b*2 + s][f*K + k]        activation: part[slab][b*2 + s][k*T + t]     (s = 0 num, 1 den)
+// Returns 0 and sets *part / *slabs; ASSX_E_UNSUPPORTED when K exceeds the matrix-core path (n_basis <= 64).
+int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, double eps, int half, const void* X,
+                      const void* Tb, const void* V, void* ws, int B, int F, int T, int K, int dtype, hipStream_t st,
+                      const void** part, int* slabs);
+
+}  // namespace assx

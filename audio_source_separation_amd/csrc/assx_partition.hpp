@@ -140,6 +140,46 @@ __global__ void __launch_bounds__(256) part_act_kernel(const R* __restrict__ par
   V[idx] = V[idx] * sqrt(num / den);
 }
 
+// n_basis > 4: the per-source sums come from the NMF matrix-core kernels run on the demixed power with the effective
+// model (batch = B*N, see nmf_half_partials); these two kernels add up the slabs and lay the result out as the
+// records the kernels above read, with the trivial partition "one workgroup per bin / per frame block, one slot".
+template <typename R>
+__global__ void __launch_bounds__(256) part_adapt_basis_kernel(const R* __restrict__ nmf_part, R* __restrict__ out,
+                                                              int B, int N, int F, int K, int slabs) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // ((b*F + f)*N + n)*2K + 2k + s
+  if (idx >= (size_t)B * F * N * 2 * K) return;
+  const int s = idx & 1, k = (idx >> 1) % K;
+  const int n = (idx / (2 * K)) % N;
+  const int f = (idx / ((size_t)2 * K * N)) % F;
+  const int b = idx / ((size_t)2 * K * N * F);
+  const size_t FK = (size_t)F * K, slab = (size_t)B * N * 2 * FK;
+  const R* p = nmf_part + ((size_t)(b * N + n) * 2 + s) * FK + (size_t)f * K + k;
+  R acc = 0;
+  for (int i = 0; i < slabs; ++i) acc += p[(size_t)i * slab];
+  out[idx] = acc;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) part_adapt_act_kernel(const R* __restrict__ nmf_part, R* __restrict__ out, int B,
+                                                            int N, int K, int T, int slabs) {
+  const int TBk = (T + WAVE - 1) / WAVE;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (((b*TBk + tb)*N + n)*2K + 2k + s)*64 + lane
+  if (idx >= (size_t)B * TBk * N * 2 * K * WAVE) return;
+  const int lane = idx % WAVE;
+  const int s = (idx / WAVE) & 1, k = (idx / (2 * WAVE)) % K;
+  const int n = (idx / ((size_t)2 * K * WAVE)) % N;
+  const int tb = (idx / ((size_t)2 * K * WAVE * N)) % TBk;
+  const int b = idx / ((size_t)2 * K * WAVE * N * TBk);
+  const int t = tb * WAVE + lane;
+  R acc = 0;
+  if (t < T) {
+    const size_t KT = (size_t)K * T, slab = (size_t)B * N * 2 * KT;
+    const R* p = nmf_part + ((size_t)(b * N + n) * 2 + s) * KT + (size_t)k * T + t;
+    for (int i = 0; i < slabs; ++i) acc += p[(size_t)i * slab];
+  }
+  out[idx] = acc;
+}
+
 // 'power' normalisation with a partitioning function (ilrma.py:313-320): W[n] /= a[n];  Z' = Z / a^2;
 // T *= sum_n Z'[n,k];  Z = Z' / sum_n Z'.  Every workgroup derives a[] and the column sums for its utterance
 // (tiny, fixed order), rescales its slice of W / T; workgroup 0 of the utterance also stores the new Z into Zout

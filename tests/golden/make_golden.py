@@ -369,9 +369,8 @@ def gen_ip2():
 # ----------------------------------------------------------------------------
 # G6c: partitioning function (shared bases + latent Z)   (ilrma.py:79-95, 368-408, 313-320)
 # ----------------------------------------------------------------------------
-def gen_part():
-    seed = 800
-    for M, K, normalize, alg in [(2, 3, "power", "IP"), (3, 4, "power", "IP"), (4, 4, False, "IP"), (3, 3, "power", "ISS")]:
+def gen_part(cases=((2, 3, "power", "IP"), (3, 4, "power", "IP"), (4, 4, False, "IP"), (3, 3, "power", "ISS")), seed=800):
+    for M, K, normalize, alg in cases:
         seed += 1
         F, T = 17, 48
         X = convolutive_mixture(M, F, T, seed=seed)
@@ -507,6 +506,11 @@ def gen_consistent():
          T_final=model.basis, V_final=model.activation, repr=np.array(repr(model)), **snap.data)
 
 
+def gen_part_k10():
+    """partitioning=True at the default n_basis = 10 (IP and ISS)."""
+    gen_part(cases=((3, 10, "power", "IP"), (4, 10, "power", "ISS")), seed=1500)
+
+
 def gen_xnmf():
     """tNMF / CauchyNMF (the other users of the NMF skeleton), nmf.py:358-600."""
     from algorithm.nmf import tNMF, CauchyNMF
@@ -586,3 +590,4 @@ if __name__ == "__main__":
     gen_k10()
     gen_tilrma_k10()
     gen_consistent()
+    gen_part_k10()

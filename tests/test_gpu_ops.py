@@ -362,7 +362,7 @@ def test_ip2_update(eng, M, F, T):
         assert rel_err(got, Wref) < tol(eng, 1e-9, 5e-3)
 
 
-@pytest.mark.parametrize("M,K", [(2, 3), (3, 4), (4, 4), (4, 7)])
+@pytest.mark.parametrize("M,K", [(2, 3), (3, 4), (4, 4), (4, 7), (3, 10), (2, 5), (4, 20)])
 def test_partitioned_source_update(eng, M, K):
     """Z, T, V updates of the partitioning branch (ilrma.py:368-408) vs the oracle; B = 2 utterances."""
     F, T = 21, 150
