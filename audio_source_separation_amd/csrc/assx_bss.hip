@@ -103,6 +103,23 @@ __global__ void __launch_bounds__(256) demix_power_map_kernel(const Cx<R>* __res
   for (int n = 0; n < M; ++n) pb[n * FT] = cabs2(y[n]);
 }
 
+// copy back the source models of the sources selected by `mask` (pairwise updates, ilrma.py:432-481)
+template <typename R>
+__global__ void __launch_bounds__(256) masked_model_copy_kernel(const R* __restrict__ Tsrc, const R* __restrict__ Vsrc,
+                                                               R* __restrict__ Tdst, R* __restrict__ Vdst, int B, int N,
+                                                               size_t FK, size_t KT, unsigned mask) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nT = (size_t)B * N * FK, nV = (size_t)B * N * KT;
+  if (idx < nT) {
+    const int n = (idx / FK) % N;
+    if ((mask >> n) & 1u) Tdst[idx] = Tsrc[idx];
+  } else if (idx < nT + nV) {
+    const size_t j = idx - nT;
+    const int n = (j / KT) % N;
+    if ((mask >> n) & 1u) Vdst[j] = Vsrc[j];
+  }
+}
+
 // A thread owns one frame of WIDE_FB consecutive bins: the K activations of that frame are loaded once and serve
 // all of them (one bin per thread is bound by the K L2 reads per output element, 90 us at K = 10 instead of the
 // 30 us the 134 MB write costs); the basis rows are wave-uniform.
@@ -1159,6 +1176,7 @@ struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte al
   size_t small;    // (B,N) reals etc.
   size_t map;      // n_basis > 4 only: (B,N,F,T) reals (demixed power / source variance)
   size_t nmf;      // n_basis > 4 only: scratch of the batched IS-NMF update
+  size_t tmp;      // n_basis > 4 only: copies of (Tb, V) for a source-masked update
   size_t total;
 };
 
@@ -1235,11 +1253,13 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   off += align_up(nl * 8, 256);
   L.small = off;
   off += align_up((size_t)B * (M + 8) * 8, 256);
-  L.map = L.nmf = off;
+  L.map = L.nmf = L.tmp = off;
   if (K > KU) {
     off += align_up((size_t)B * M * F * T * r, 256);
     L.nmf = off;
     off += align_up(assx_nmf_workspace_bytes(B * M, F, T, K, dtype), 256);
+    L.tmp = off;
+    off += align_up(((size_t)B * M * F * K + (size_t)B * M * K * T) * r, 256);
   }
   L.total = off;
   return L;
@@ -1626,7 +1646,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
       const bool fusable = domain == 2.0 && K <= KU && env_int("ASSX_BASIS_VDMA", 1) && env_int("ASSX_FUSE_LOSS", 1);
       if (!fusable) {
         // n_basis > 4: the loss pass forms |W x|^2 anyway and leaves it behind as the map the source model needs
-        void* pmap = (K > KU && wide_k && full_mask) ? (void*)((char*)ws + ws_layout(B, MM, F, T, K, dtype).map) : nullptr;
+        void* pmap = (K > KU && wide_k) ? (void*)((char*)ws + ws_layout(B, MM, F, T, K, dtype).map) : nullptr;
         rc = ilrma_loss_impl(ctx, "assx_ilrma_source_update", X, W, Tb, V, domain, -1.0, eps, loss_prev, ws, B, MM, F, T,
                              K, dtype, stream, pmap, &have_map);
         if (rc) return rc;
@@ -1655,6 +1675,29 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
       }
       return assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype,
                              stream);
+    }
+    if (K > KU && wide_k && !full_mask && (source_mask & ((1u << MM) - 1u)) != 0u) {
+      // pairwise update at n_basis > 4: every source's update is independent, so all of them are run on copies of
+      // the model (matrix cores, one pass) and only the selected sources are copied back
+      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+      R* pw = (R*)((char*)ws + L.map);
+      const size_t nT = (size_t)B * MM * F * K, nV = (size_t)B * MM * K * T;
+      R* Tt = (R*)((char*)ws + L.tmp);
+      R* Vt = Tt + nT;
+      if (!have_map) {
+        hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                           (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
+        ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      }
+      hipError_t e = hipMemcpyAsync(Tt, Tb, nT * sizeof(R), hipMemcpyDeviceToDevice, st);
+      if (e == hipSuccess) e = hipMemcpyAsync(Vt, V, nV * sizeof(R), hipMemcpyDeviceToDevice, st);
+      if (e != hipSuccess) return fail(ctx, (int)e, "hipMemcpyAsync(model copy): %s", hipGetErrorString(e));
+      rc = assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tt, Vt, (char*)ws + L.nmf, B * MM, F, T, K, dtype, stream);
+      if (rc) return rc;
+      hipLaunchKernelGGL((masked_model_copy_kernel<R>), dim3(blocks_for(nT + nV, 256)), dim3(256), 0, st, (const R*)Tt,
+                         (const R*)Vt, (R*)Tb, (R*)V, B, MM, (size_t)F * K, (size_t)K * T, source_mask);
+      ASSX_LAUNCH_CHECK(ctx, "masked_model_copy_kernel");
+      return 0;
     }
     rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp, -1.0, lpart, lstride);
     if (rc) return rc;

@@ -563,6 +563,31 @@ def test_wide_basis_path(eng, few_workgroups, G, M, K, domain, F, T):
         assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("M,K,pair", [(4, 3, (1, 2)), (4, 10, (3, 0)), (3, 6, (0, 2)), (2, 12, (1,))])
+def test_source_update_of_selected_sources(eng, M, K, pair):
+    """Pairwise update (ilrma.py:432-481): only the selected sources' models move, and they move exactly as in the
+    full update; with n_basis > 4 the update runs on copies of the whole model and the selection is copied back.
+    The loss of the entry state rides along."""
+    F, T = 19, 150
+    rng = np.random.default_rng(170 + M + K)
+    Xs = [mixture(M, F, T, 171 + b) for b in range(2)]
+    Ws = [rand_filters(M, F, 173 + b) for b in range(2)]
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Xd, Wd, Td, Vd = dev_c(eng, np.stack(Xs)), dev_c(eng, np.stack(Ws)), dev_r(eng, Tb), dev_r(eng, V)
+    lp = eng.empty((2,), dtype=torch.float64)
+    eng.ilrma_source_update(Xd, Wd, Td, Vd, sources=pair, loss_prev=lp)
+    for b in range(2):
+        np.testing.assert_allclose(host(lp)[b], orc.ilrma_loss(Xs[b], Ws[b], Tb[b], V[b], 2), rtol=tol(eng, 1e-12, 1e-5))
+        T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], Ws[b])) ** 2, Tb[b], V[b], 2)
+        for n in range(M):
+            if n in pair:
+                assert rel_err(host(Td)[b, n], T1[n]) < tol(eng, 1e-11, 5e-5)
+                assert rel_err(host(Vd)[b, n], V1[n]) < tol(eng, 1e-11, 5e-5)
+            else:  # untouched, bit for bit
+                assert np.array_equal(host(Td)[b, n], host(dev_r(eng, Tb))[b, n])
+                assert np.array_equal(host(Vd)[b, n], host(dev_r(eng, V))[b, n])
+
+
 def test_oversize_utterance_is_rejected(eng):
     """Buffer offsets are 32-bit: an utterance of 2^28 or more complex samples is refused, not mis-addressed."""
     from audio_source_separation_amd import _lib as L
