@@ -128,3 +128,32 @@ def test_lazy_loss_list_defers_and_resolves():
     assert np.asarray(ll).tolist() == [3.0, 7.5]
     ll.append_device(FakeTensor([1.0, 2.0]), batched=True)       # utterance axis: one value per utterance
     assert np.array_equal(np.asarray(ll[2]), [1.0, 2.0])
+
+
+def test_stft_geometry_matches_scipy_semantics():
+    """assx_stft_num_frames / assx_istft_num_samples (host arithmetic, no GPU) against the oracle's restatement of
+    scipy.signal.stft / istft (boundary + padding rules) over many lengths, frame sizes and hops."""
+    from audio_source_separation_amd import _lib
+    from oracle import oracle_np as orc
+    lib = _lib.lib
+    for N in (2, 8, 30, 33, 64):
+        for hop in sorted({1, max(1, N // 4), max(1, N // 2), N - 1 if N > 1 else 1, N}):
+            for L in (N, N + 1, 2 * N + 3, 5 * N, 257):
+                if L < N:
+                    continue
+                X = orc.stft(np.zeros((1, L)), N, hop)
+                assert lib.assx_stft_num_frames(L, N, hop) == X.shape[-1], (L, N, hop)
+                y = orc.istft(X, N, hop)
+                assert lib.assx_istft_num_samples(N, hop, X.shape[-1]) == y.shape[-1], (L, N, hop)
+    assert lib.assx_stft_num_frames(-1, 8, 2) == -1 and lib.assx_stft_num_frames(10, 8, 0) == -1
+    n64 = lib.assx_stft_workspace_bytes(4, 2048, 4096, _lib.F64)
+    assert n64 > 4 * 4096 * (1025 * 16 + 2048 * 8) and lib.assx_stft_workspace_bytes(0, 8, 1, _lib.F64) == 0
+
+
+def test_workspace_grows_for_wide_basis():
+    """n_basis > 4 adds the (B,N,F,T) map and the NMF scratch to assx_workspace_bytes (include/assx.h)."""
+    from audio_source_separation_amd import _lib
+    lib = _lib.lib
+    small = lib.assx_workspace_bytes(1, 4, 1025, 4096, 4, _lib.F64)
+    wide = lib.assx_workspace_bytes(1, 4, 1025, 4096, 10, _lib.F64)
+    assert wide - small >= 4 * 1025 * 4096 * 8 + lib.assx_nmf_workspace_bytes(4, 1025, 4096, 10, _lib.F64) - 4096
