@@ -1501,15 +1501,19 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
     const FlatPart fw = flat_cov_wide(B, F, T);
     const Dims d{B, F, T, K};
     if (p2d.mode == POW_ID) {
-      if (lds > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(cov_wide_kernel)");
+      }
       hipLaunchKernelGGL((cov_wide_kernel<R, MM, true>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st, (const Cx<R>*)X,
                          (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);
     } else {
-      if (lds > 64 * 1024)
-        hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(cov_wide_kernel)");
+      }
       hipLaunchKernelGGL((cov_wide_kernel<R, MM, false>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st, (const Cx<R>*)X,
                          (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);
     }
