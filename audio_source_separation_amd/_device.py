@@ -3,6 +3,7 @@
 All arithmetic of the hot path happens in libassx.so (hand-written HIP); nothing here computes.
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -43,8 +44,9 @@ def require_gpu(device=None):
 
 
 def context(dev):
-    """One assx context per device (include/assx.h: contexts are per (device, host thread))."""
-    key = dev.index
+    """One assx context per (device, host thread), as include/assx.h specifies: a context is not thread-safe (it holds
+    the last error message), so two threads driving the same GPU get two contexts."""
+    key = (dev.index, threading.get_ident())
     if key not in _CTX:
         h = ctypes.c_void_p()
         rc = _lib.lib.assx_ctx_create(int(dev.index), ctypes.byref(h))

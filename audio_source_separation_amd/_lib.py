@@ -59,6 +59,7 @@ SIGNATURES = {
     "assx_auxiva_spatial_update": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back_scale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_compute_demix_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "assx_nmf_update": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_loss": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -40,9 +40,13 @@ class LazyLossList(list):
         method.__name__ = name
         return method
 
+    # readers AND every mutator that moves, drops or overwrites entries: pending device scalars are keyed by absolute
+    # index, so they are materialised first and the list then behaves exactly like the reference's plain list
+    # (`loss.clear()`, `del loss[:k]`, `insert`, `extend`, slicing assignment ... between calls are all legal there)
     for _n in ("__getitem__", "__iter__", "__repr__", "__str__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__",
                "__ge__", "__contains__", "__reversed__", "__add__", "__mul__", "__rmul__", "copy", "count", "index",
-               "pop", "sort", "reverse"):
+               "pop", "sort", "reverse", "clear", "insert", "remove", "extend", "__iadd__", "__imul__",
+               "__setitem__", "__delitem__"):
         locals()[_n] = _wrap(_n)
     del _n, _wrap
 

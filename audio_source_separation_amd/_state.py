@@ -4,7 +4,8 @@ The reference keeps `demix_filter`, `basis`, `activation`, `estimation` as NumPy
 callbacks read after every iteration (egs/bss-example/ilrma/test_gauss-ilrma.ipynb cells 69-78)
 and that `_reset` warm-starts from via `hasattr` (src/bss/ilrma.py:67-72, 88-104).  Here the
 authoritative copy is a device tensor; the NumPy view is downloaded lazily and cached until a
-kernel touches the tensor again, so a loop without callbacks never leaves the GPU.
+kernel touches the tensor again, so a loop without callbacks never leaves the GPU.  Downloaded views are READ-ONLY
+(in-place edits would not reach the device): assign a new array to modify state.
 """
 import numpy as np
 
@@ -41,7 +42,12 @@ class DeviceArray:
             raise AttributeError("'%s' object has no attribute '%s'" % (type(obj).__name__, self.attr))
         if ent.host is None:
             a = to_numpy(ent.dev, np.complex128 if self.complex_ else np.float64)
-            ent.host = a if obj._batched else a[0]
+            a = a if obj._batched else a[0]
+            # the device tensor stays authoritative: an in-place edit of this snapshot (`model.demix_filter[...] *= s`)
+            # would be silently dropped at the next kernel, whereas it takes effect in the reference.  Make it fail
+            # loudly instead; ASSIGNING an array (`model.demix_filter = new`) is the supported way to modify state.
+            a.setflags(write=False)
+            ent.host = a
         return ent.host
 
     def __set__(self, obj, value):

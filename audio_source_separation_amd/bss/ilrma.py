@@ -215,6 +215,27 @@ class ILRMAbase(DeviceState):
         Y = to_numpy(Y, np.complex128)
         return Y if batched else Y[0]
 
+    def compute_demix_filter(self, estimation, input):
+        """W = Y X^H (X X^H)^{-1} per bin (ilrma.py:167-173): the least-squares demixing filter that maps `input`
+        onto `estimation`.  (n_sources, n_bins, n_frames) x (n_channels, n_bins, n_frames) -> (n_bins, n_sources,
+        n_channels); NumPy in -> NumPy out, device tensors in -> device tensor out; a leading utterance axis is kept."""
+        eng = self._ensure_engine()
+        Y = to_device(estimation, eng.prec.cplx, eng.dev)
+        X = to_device(input, eng.prec.cplx, eng.dev)
+        if Y.shape != X.shape:
+            raise ValueError("estimation {} and input {} must have the same shape (n_sources == n_channels)".format(tuple(Y.shape), tuple(X.shape)))
+        batched = X.dim() == 4
+        if not batched:
+            X, Y = X.unsqueeze(0), Y.unsqueeze(0)
+        status = eng.new_status(X.shape[0])
+        W = eng.compute_demix_filter(Y.contiguous(), X.contiguous(), status=status)
+        if int(status.max().item()) & _lib.STATUS_SINGULAR:
+            raise np.linalg.LinAlgError("Singular matrix")
+        if isinstance(input, torch.Tensor) and isinstance(estimation, torch.Tensor):
+            return W if batched else W[0]
+        W = to_numpy(W, np.complex128)
+        return W if batched else W[0]
+
     def compute_negative_loglikelihood(self):
         raise NotImplementedError("Implement 'compute_negative_loglikelihood' function.")
 
@@ -360,7 +381,8 @@ class GaussILRMA(ILRMAbase):
                 if self.partitioning:
                     raise NotImplementedError("Not support 'projection-back' based normalization for partitioninig function. Choose 'power' based normalization.")
                 scale = eng.projection_back_scale(self._X, self._Wd, self.reference_id, self._status)
-                eng.ilrma_normalize_pb(self._Wd, self._Td, scale, domain=domain)
+                eng.ilrma_normalize_pb(self._Wd, self._Td, scale,
+                                       domain=getattr(self, "_pb_basis_exponent", None) or domain)
             else:
                 raise ValueError("Not support normalization based on {}. Choose 'power' or 'projection-back'".format(self.normalize))
             self._touch("W", "T")
@@ -505,11 +527,13 @@ class ConsistentGaussILRMA(GaussILRMA):
             raise ValueError("n_bins = {} does not match fft_size = {}.".format(self.n_bins, self.fft_size))
         if self.partitioning:
             raise NotImplementedError("Not support 'projection-back' based normalization for partitioninig function. Choose 'power' based normalization.")
-        self.normalize = 'projection-back'  # ilrma.py:1219-1229 == the 'projection-back' block of GaussILRMA.update_once
+        # ilrma.py:1219-1229 == the 'projection-back' block of GaussILRMA.update_once, except that the reference
+        # rescales the basis by |scale|**2 whatever `domain` a caller set through kwargs (ilrma.py:1229)
+        self.normalize, self._pb_basis_exponent = 'projection-back', 2
         try:
             GaussILRMA.update_once(self)
         finally:
-            self.normalize = False
+            self.normalize, self._pb_basis_exponent = False, None
 
 
 class tILRMA(ILRMAbase):

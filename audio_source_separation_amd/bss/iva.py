@@ -128,6 +128,27 @@ class IVAbase(DeviceState):
         Y = to_numpy(Y, np.complex128)
         return Y if batched else Y[0]
 
+    def compute_demix_filter(self, estimation, input):
+        """W = Y X^H (X X^H)^{-1} per bin (iva.py:119-125): the least-squares demixing filter that maps `input`
+        onto `estimation`.  (n_sources, n_bins, n_frames) x (n_channels, n_bins, n_frames) -> (n_bins, n_sources,
+        n_channels); NumPy in -> NumPy out, device tensors in -> device tensor out; a leading utterance axis is kept."""
+        eng = self._ensure_engine()
+        Y = to_device(estimation, eng.prec.cplx, eng.dev)
+        X = to_device(input, eng.prec.cplx, eng.dev)
+        if Y.shape != X.shape:
+            raise ValueError("estimation {} and input {} must have the same shape (n_sources == n_channels)".format(tuple(Y.shape), tuple(X.shape)))
+        batched = X.dim() == 4
+        if not batched:
+            X, Y = X.unsqueeze(0), Y.unsqueeze(0)
+        status = eng.new_status(X.shape[0])
+        W = eng.compute_demix_filter(Y.contiguous(), X.contiguous(), status=status)
+        if int(status.max().item()) & _lib.STATUS_SINGULAR:
+            raise np.linalg.LinAlgError("Singular matrix")
+        if isinstance(input, torch.Tensor) and isinstance(estimation, torch.Tensor):
+            return W if batched else W[0]
+        W = to_numpy(W, np.complex128)
+        return W if batched else W[0]
+
     def compute_negative_loglikelihood(self):
         raise NotImplementedError("Implement 'compute_negative_loglikelihood' function.")
 

@@ -10,8 +10,8 @@ int assx_ctx_create(int device, assx_ctx** out) {
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess) return (int)e;
   if (device < 0 || device >= count) return ASSX_E_ARG;
-  e = hipSetDevice(device);
-  if (e != hipSuccess) return (int)e;
+  // the current device of the calling thread is left alone (it belongs to the host framework); entry points check
+  // that it equals `device` when they are called (assx_common.hpp: check_ctx_device)
   assx_ctx* c = (assx_ctx*)calloc(1, sizeof(assx_ctx));
   if (!c) return ASSX_E_ARG;
   c->device = device;

@@ -1286,7 +1286,7 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
 }
 
 #define CHECK_COMMON(ctx, B, M, F, T)                                                        \
-  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");                              \
+  ASSX_REQUIRE_CTX(ctx);                              \
   ASSX_REQUIRE(ctx, (B) >= 1 && (M) >= 1 && (F) >= 1 && (T) >= 1, ASSX_E_ARG,                 \
                "invalid sizes B=%d M=%d F=%d T=%d", (B), (M), (F), (T));                       \
   ASSX_REQUIRE(ctx, (long long)(M) * (F) * (T) < (1LL << 28) && (long long)(B) * (F) * (((T) + 31) / 32 + 1) < (1LL << 31), \

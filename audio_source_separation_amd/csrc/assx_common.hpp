@@ -48,6 +48,27 @@ inline int hip_fail(assx_ctx* ctx, hipError_t e, const char* where) {
     if (e__ != hipSuccess) return ::assx::hip_fail((ctx), e__, (where)); \
   } while (0)
 
+// Every entry point: the context exists and ITS device is the calling thread's current device.  The library never
+// changes the current device itself (a host framework such as torch owns it); a mismatch would launch on -- or
+// query attributes of -- the wrong GPU, so it is refused loudly instead.
+inline int check_ctx_device(assx_ctx* ctx) {
+  int cur = -1;
+  hipError_t e = hipGetDevice(&cur);
+  if (e != hipSuccess) return hip_fail(ctx, e, "hipGetDevice");
+  if (cur != ctx->device)
+    return fail(ctx, ASSX_E_ARG,
+                "the calling thread's current device is %d but this context was created for device %d: make it "
+                "current (hipSetDevice) before calling", cur, ctx->device);
+  return 0;
+}
+
+#define ASSX_REQUIRE_CTX(ctx)                                       \
+  do {                                                              \
+    if ((ctx) == nullptr) return ASSX_E_NULL;                       \
+    int rc__ = ::assx::check_ctx_device(ctx);                       \
+    if (rc__ != 0) return rc__;                                     \
+  } while (0)
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ------------------------------------------------------------------------------------------

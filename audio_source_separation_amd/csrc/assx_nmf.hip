@@ -509,7 +509,7 @@ size_t assx_nmf_workspace_bytes(int B, int F, int T, int K, int dtype) {
 
 int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb,
                        void* V, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
-  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
+  ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
   ASSX_REQUIRE(ctx, X && Tb && V && ws, ASSX_E_NULL, "assx_nmf_update: NULL array");
   ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_T_RAW, ASSX_E_ARG, "bad NMF kind %d", kind);
@@ -538,7 +538,7 @@ int assx_nmf_loss(assx_ctx* ctx, int kind, double domain, double eps, const void
 
 int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* Tb,
                      const void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
-  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
+  ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
   ASSX_REQUIRE(ctx, X && Tb && V && loss && ws, ASSX_E_NULL, "assx_nmf_loss: NULL array");
   ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_CAUCHY_MM_FAST, ASSX_E_ARG, "bad NMF kind %d", kind);

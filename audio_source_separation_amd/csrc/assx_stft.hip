@@ -315,7 +315,7 @@ size_t assx_stft_workspace_bytes(int C, int fft_size, int n_frames, int dtype) {
 
 int assx_stft(assx_ctx* ctx, const void* x, const void* window, double window_sum, void* X, void* ws, int C,
               long long n_samples, int fft_size, int hop, int n_frames, int dtype, void* stream) {
-  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
+  ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, x && window && X && ws, ASSX_E_NULL, "assx_stft: NULL array");
   ASSX_REQUIRE(ctx, C >= 1 && n_samples >= 1 && fft_size >= 2 && hop >= 1, ASSX_E_ARG,
                "assx_stft: invalid sizes C=%d n_samples=%lld fft_size=%d hop=%d", C, n_samples, fft_size, hop);
@@ -337,7 +337,7 @@ int assx_stft(assx_ctx* ctx, const void* x, const void* window, double window_su
 
 int assx_istft(assx_ctx* ctx, const void* X, const void* window, double window_sum, void* y, void* ws, int C,
                int fft_size, int hop, int n_frames, int dtype, void* stream) {
-  ASSX_REQUIRE(ctx, ctx != nullptr, ASSX_E_NULL, "ctx is NULL");
+  ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, X && window && y && ws, ASSX_E_NULL, "assx_istft: NULL array");
   ASSX_REQUIRE(ctx, C >= 1 && n_frames >= 1 && fft_size >= 2 && hop >= 1, ASSX_E_ARG,
                "assx_istft: invalid sizes C=%d n_frames=%d fft_size=%d hop=%d", C, n_frames, fft_size, hop);

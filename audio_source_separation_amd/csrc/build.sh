@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"
 pids=()
-for src in assx_api assx_bss assx_nmf assx_stft; do
+for src in assx_api assx_bss assx_nmf assx_stft assx_generic; do
   stale=0
   [ -f "$src.o" ] || stale=1
   for dep in "$src.hip" *.hpp ../../include/assx.h build.sh; do
@@ -17,5 +17,5 @@ for src in assx_api assx_bss assx_nmf assx_stft; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so assx_api.o assx_bss.o assx_nmf.o assx_stft.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so assx_api.o assx_bss.o assx_nmf.o assx_stft.o assx_generic.o
 echo "built $(pwd)/libassx.so"

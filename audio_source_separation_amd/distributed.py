@@ -2,12 +2,20 @@
 over xGMI on ROCm; "gloo" on CPU for tests).
 
 The hot path shards by utterance and needs NO data-path collective: every rank runs the complete NMF / AuxIVA /
-ILRMA loop on its own block of utterances.  RCCL is used only at the edges:
+ILRMA loop on its own block of utterances (ref src/bss/ilrma.py:203-273 -- each `__call__`
+owns all of its state).  RCCL is used only at the edges:
   * scatter_utterances : root -> ranks, the mixtures X (skipped when every rank loads / generates its own),
   * gather_utterances  : ranks -> root, the separated outputs Y,
   * max_over_ranks     : the MAX of a per-rank timing (bench.py contract).
-Root <-> 7 peers is 7 concurrent point-to-point xGMI links, so scatter/gather are issued as one
-`dist.scatter` / `dist.gather` (grouped send/recv inside RCCL), never as a ring.
+The edges are point-to-point: root <-> 7 peers is 7 concurrent xGMI links, so both are ONE grouped batch of
+send/recv operations on VIEWS of the root's array (`dist.batch_isend_irecv` = ncclGroupStart/End around
+ncclSend/ncclRecv): no ring, no padded staging copies, ragged shards need no padding.
+
+Communication deliberately lives on the host side (torch's RCCL binding), not in the C-ABI: include/assx.h is the
+device boundary of ONE rank, and every entry point there is communication-free.
+
+`all_gather_ordered_sum` is the deterministic reduction the F-sharded single-utterance mode
+builds on.
 """
 import os
 
@@ -42,6 +50,9 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
         if backend == "nccl":
+            if local_rank >= torch.cuda.device_count():
+                raise RuntimeError("LOCAL_RANK=%d but only %d GPU(s) are visible: one process per GPU is required"
+                                   % (local_rank, torch.cuda.device_count()))
             torch.cuda.set_device(local_rank)
             kwargs["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
@@ -56,57 +67,63 @@ def _as_real(t):
     return torch.view_as_real(t) if t.is_complex() else t
 
 
+def _run_p2p(ops):
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
 def scatter_utterances(x_all, n_items, item_shape, dtype, device, src=0):
-    """Root holds x_all (n_items, *item_shape); every rank returns its own block (n_local, *item_shape)."""
+    """Root holds x_all (n_items, *item_shape) on `device`; every rank returns its own block (n_local, *item_shape).
+    One grouped batch of sends of contiguous row-blocks (views of x_all); the root's own block is a view, not a copy."""
     rank, world = _world()
     lo, hi = shard_range(n_items, world, rank)
     if world == 1:
-        return x_all[lo:hi].to(device)
-    out = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=device)
-    # equal-size requirement of dist.scatter: pad every block to the largest shard
-    sizes = shard_sizes(n_items, world)
-    pad = max(sizes)
-    buf = torch.zeros((pad,) + tuple(item_shape), dtype=dtype, device=device)
-    chunks = None
+        return x_all[lo:hi].to(device=device, dtype=dtype)
     if rank == src:
-        chunks = []
+        x_all = x_all.to(device=device, dtype=dtype).contiguous()
+        ops = []
         for r in range(world):
             a, b = shard_range(n_items, world, r)
-            c = torch.zeros((pad,) + tuple(item_shape), dtype=dtype, device=device)
-            c[: b - a] = x_all[a:b].to(device)
-            chunks.append(_as_real(c).contiguous())
-    dist.scatter(_as_real(buf), scatter_list=chunks, src=src)
-    out.copy_(buf[: hi - lo])
+            if r != src and b > a:
+                ops.append(dist.P2POp(dist.isend, _as_real(x_all[a:b]), r))
+        _run_p2p(ops)
+        return x_all[lo:hi]
+    out = torch.empty((hi - lo,) + tuple(item_shape), dtype=dtype, device=device)
+    if hi > lo:
+        _run_p2p([dist.P2POp(dist.irecv, _as_real(out), src)])
     return out
 
 
 def gather_utterances(y_local, n_items, dst=0):
-    """Inverse of scatter_utterances: root returns (n_items, ...) in the original utterance order, others None."""
+    """Inverse of scatter_utterances: root returns (n_items, ...) in the original utterance order, others None.
+    Peers send their block once; the root receives every block straight into its slice of the result."""
     rank, world = _world()
     if world == 1:
         return y_local
-    sizes = shard_sizes(n_items, world)
-    pad = max(sizes)
-    item_shape = tuple(y_local.shape[1:])
-    buf = torch.zeros((pad,) + item_shape, dtype=y_local.dtype, device=y_local.device)
-    buf[: y_local.shape[0]] = y_local
-    recv = None
-    if rank == dst:
-        recv = [torch.empty_like(_as_real(buf)) for _ in range(world)]
-    dist.gather(_as_real(buf).contiguous(), gather_list=recv, dst=dst)
+    lo, hi = shard_range(n_items, world, rank)
+    y_local = y_local.contiguous()
     if rank != dst:
+        if hi > lo:
+            _run_p2p([dist.P2POp(dist.isend, _as_real(y_local), dst)])
         return None
-    parts = []
+    out = torch.empty((n_items,) + tuple(y_local.shape[1:]), dtype=y_local.dtype, device=y_local.device)
+    out[lo:hi] = y_local
+    ops = []
     for r in range(world):
-        t = recv[r]
-        t = torch.view_as_complex(t) if y_local.is_complex() else t
-        parts.append(t[: sizes[r]])
-    return torch.cat(parts, dim=0)
+        a, b = shard_range(n_items, world, r)
+        if r != dst and b > a:
+            ops.append(dist.P2POp(dist.irecv, _as_real(out[a:b]), r))
+    _run_p2p(ops)
+    return out
 
 
 def barrier(device=None):
     if dist.is_initialized():
-        dist.barrier()
+        if device is not None and torch.device(device).type == "cuda":
+            dist.barrier(device_ids=[torch.device(device).index])
+        else:
+            dist.barrier()
     if device is not None and torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
 
@@ -125,3 +142,49 @@ def run_sharded(process_fn, x_all, n_items, item_shape, dtype, device, gather=Tr
     x_local = scatter_utterances(x_all, n_items, item_shape, dtype, device)
     y_local = process_fn(x_local)
     return gather_utterances(y_local, n_items) if gather else y_local
+
+
+def separate_sharded(model_factory, x_all, n_items, item_shape, dtype, device, iteration=100, init_fn=None,
+                     gather=True, comm_device=None):
+    """Config 5: `n_items` independent utterances separated by the reference-surface classes, a contiguous block per
+    rank as ONE batched launch sequence (leading utterance axis B = n_local).
+
+    model_factory() -> a fresh model (GaussILRMA / AuxLaplaceIVA / ...).  init_fn(model, lo, hi) may assign the
+    initial state of utterances lo..hi-1 (the reference draws it from the global NumPy RNG per call; a sharded run
+    must draw per UTTERANCE so that the result does not depend on the partition).  comm_device: where the edge
+    buffers live (default = `device`, i.e. RCCL on HBM buffers; "cpu" stages the edges through host memory for a
+    gloo group).  Returns (Y on the root | None, model of this rank)."""
+    rank, world = _world()
+    lo, hi = shard_range(n_items, world, rank)
+    comm_device = device if comm_device is None else comm_device
+    x_local = scatter_utterances(x_all, n_items, item_shape, dtype, comm_device)
+    model = model_factory()
+    if hi > lo:
+        if init_fn is not None:
+            init_fn(model, lo, hi)
+        y_local = model(x_local.to(device), iteration=iteration)
+        if not isinstance(y_local, torch.Tensor):
+            y_local = torch.from_numpy(y_local)
+        y_local = y_local.to(comm_device)
+    else:
+        y_local = torch.empty((0,) + tuple(item_shape), dtype=dtype, device=comm_device)
+    return (gather_utterances(y_local, n_items) if gather else y_local), model
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# F-sharded single utterance (SURVEY.md 8e "within one utterance", 8 f2; ref src/bss/ilrma.py:421-428, 304-307)
+# ---------------------------------------------------------------------------------------------------------------
+def all_gather_ordered_sum(t):
+    """Deterministic all-reduce(SUM): all-gather the per-rank partial, then every rank adds the `world` partials in
+    RANK ORDER.  A ring/tree all-reduce may associate differently from run to run or rank to rank; this form gives
+    every rank the same bits and the same bits as a single process that adds the same per-shard partials in shard
+    order.  The payloads here are tiny (2.N.K.T reals and N scalars per iteration), so the extra bytes are free."""
+    rank, world = _world()
+    if world == 1:
+        return t.clone()
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t.contiguous())
+    out = parts[0].clone()
+    for p in parts[1:]:
+        out += p
+    return out

@@ -11,7 +11,32 @@ import torch
 from . import _lib
 from ._device import Precision, Workspace, context, ptr, require_gpu, stream_ptr
 
-L = _lib.lib
+_RAW = _lib.lib
+
+
+class _DeviceGuardedLib:
+    """libassx entry points called with the engine's device made current for the duration of the call.
+
+    The C library never switches devices (it refuses a call whose context device is not current); torch owns the
+    calling thread's current device, so a model built with device='cuda:1' while cuda:0 is current -- or two models
+    on different GPUs in one process -- are handled here, not by the caller."""
+
+    def __init__(self, dev):
+        self._dev = dev
+
+    def __getattr__(self, name):
+        fn = getattr(_RAW, name)
+        dev, index = self._dev, self._dev.index
+
+        def call(*args):
+            if torch.cuda.current_device() == index:
+                return fn(*args)
+            with torch.cuda.device(dev):
+                return fn(*args)
+
+        call.__name__ = name
+        setattr(self, name, call)
+        return call
 
 
 class Engine:
@@ -20,13 +45,14 @@ class Engine:
         self.prec = Precision(dtype)
         self.ctx = context(self.dev)
         self._ws = Workspace(self.dev)
+        self._L = _DeviceGuardedLib(self.dev)
 
     # ------------------------------------------------------------------ helpers
     def _check(self, rc, what):
         _lib.check(self.ctx, rc, what)
 
     def _scratch(self, B, M, F, T, K):
-        n = L.assx_workspace_bytes(B, M, F, T, max(int(K), 1), self.prec.code)
+        n = self._L.assx_workspace_bytes(B, M, F, T, max(int(K), 1), self.prec.code)
         return self._ws.get(n)
 
     def _st(self):
@@ -48,7 +74,7 @@ class Engine:
     def demix(self, X, W, scale=None, out=None):
         B, M, F, T = self._dims(X)
         Y = out if out is not None else self.empty((B, M, F, T), complex_=True)
-        self._check(L.assx_demix(self.ctx, ptr(X), ptr(W), ptr(scale), ptr(Y), B, M, F, T, self.prec.code, self._st()),
+        self._check(self._L.assx_demix(self.ctx, ptr(X), ptr(W), ptr(scale), ptr(Y), B, M, F, T, self.prec.code, self._st()),
                     "assx_demix")
         return Y
 
@@ -64,14 +90,14 @@ class Engine:
             kind, N = _lib.W_NFT, int(r.shape[1])
         U = self.empty((B, N, F, M, M), complex_=True)
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_cov_accumulate(self.ctx, ptr(X), ptr(r), kind, float(eps), ptr(U), ptr(ws), B, M, N, F, T,
+        self._check(self._L.assx_cov_accumulate(self.ctx, ptr(X), ptr(r), kind, float(eps), ptr(U), ptr(ws), B, M, N, F, T,
                                           self.prec.code, self._st()), "assx_cov_accumulate")
         return U
 
     # ------------------------------------------------------------------ (a5)
     def ip_update(self, U, W, threshold=1e12, status=None):
         B, F, N, M = (int(s) for s in W.shape)
-        self._check(L.assx_ip_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), B, M, F, self.prec.code,
+        self._check(self._L.assx_ip_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), B, M, F, self.prec.code,
                                      self._st()), "assx_ip_update")
         return W
 
@@ -83,7 +109,7 @@ class Engine:
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         mask = (1 << M) - 1 if sources is None else sum(1 << int(n) for n in set(sources))
-        self._check(L.assx_ilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
+        self._check(self._L.assx_ilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
                                                mask, ptr(loss_prev), ptr(ws), B, M, F, T, K, self.prec.code,
                                                self._st()),
                     "assx_ilrma_source_update")
@@ -93,7 +119,7 @@ class Engine:
         """Teff (B,N,F,K) = Z[n,k] Tb[f,k], Veff (B,N,K,T) = V[k,t]; either output may be None."""
         B, N, K = (int(s) for s in Z.shape)
         F, T = int(Tb.shape[1]), int(V.shape[2])
-        self._check(L.assx_ilrma_expand_partitioned(self.ctx, ptr(Z), ptr(Tb), ptr(V), ptr(Teff), ptr(Veff), B, N, F,
+        self._check(self._L.assx_ilrma_expand_partitioned(self.ctx, ptr(Z), ptr(Tb), ptr(V), ptr(Teff), ptr(Veff), B, N, F,
                                                     T, K, self.prec.code, self._st()),
                     "assx_ilrma_expand_partitioned")
 
@@ -101,7 +127,7 @@ class Engine:
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_ilrma_source_update_partitioned(self.ctx, ptr(X), ptr(W), ptr(Z), ptr(Tb), ptr(V),
+        self._check(self._L.assx_ilrma_source_update_partitioned(self.ctx, ptr(X), ptr(W), ptr(Z), ptr(Tb), ptr(V),
                                                            ptr(Teff), ptr(Veff), float(eps), ptr(ws), B, M, F, T, K,
                                                            self.prec.code, self._st()),
                     "assx_ilrma_source_update_partitioned")
@@ -110,20 +136,20 @@ class Engine:
         B, F, N, M = (int(s) for s in W.shape)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, int(n_frames), K)
-        self._check(L.assx_ilrma_normalize_power_bins_partitioned(self.ctx, ptr(W), ptr(Z), ptr(Tb), ptr(power_bins),
+        self._check(self._L.assx_ilrma_normalize_power_bins_partitioned(self.ctx, ptr(W), ptr(Z), ptr(Tb), ptr(power_bins),
                                                                   float(eps), ptr(ws), B, M, F, K, self.prec.code,
                                                                   self._st()),
                     "assx_ilrma_normalize_power_bins_partitioned")
 
     def ip2_update(self, U, W, pair, threshold=1e12, status=None):
         B, F, N, M = (int(s) for s in W.shape)
-        self._check(L.assx_ip2_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), int(pair[0]),
+        self._check(self._L.assx_ip2_update(self.ctx, ptr(U), ptr(W), float(threshold), ptr(status), int(pair[0]),
                                       int(pair[1]), B, M, F, self.prec.code, self._st()), "assx_ip2_update")
         return W
 
     def iss_update(self, U, W, n_frames):
         B, F, N, M = (int(s) for s in W.shape)
-        self._check(L.assx_iss_update(self.ctx, ptr(U), ptr(W), int(n_frames), B, M, F, self.prec.code, self._st()),
+        self._check(self._L.assx_iss_update(self.ctx, ptr(U), ptr(W), int(n_frames), B, M, F, self.prec.code, self._st()),
                     "assx_iss_update")
         return W
 
@@ -133,7 +159,7 @@ class Engine:
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_ilrma_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
+        self._check(self._L.assx_ilrma_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
                                                 float(threshold), ptr(U_out), ptr(C), ptr(power_bins), ptr(status),
                                                 ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_ilrma_spatial_update")
@@ -143,14 +169,14 @@ class Engine:
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_ilrma_cov_partials(self.ctx, ptr(X), ptr(Tb), ptr(V), float(domain), float(eps), ptr(ws),
+        self._check(self._L.assx_ilrma_cov_partials(self.ctx, ptr(X), ptr(Tb), ptr(V), float(domain), float(eps), ptr(ws),
                                               B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_cov_partials")
 
     def demix_power(self, X, W, out=None):
         B, M, F, T = self._dims(X)
         p = out if out is not None else self.empty((B, M))
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_demix_power(self.ctx, ptr(X), ptr(W), ptr(p), ptr(ws), B, M, F, T, self.prec.code,
+        self._check(self._L.assx_demix_power(self.ctx, ptr(X), ptr(W), ptr(p), ptr(ws), B, M, F, T, self.prec.code,
                                        self._st()), "assx_demix_power")
         return p
 
@@ -158,27 +184,27 @@ class Engine:
         B, F, N, M = (int(s) for s in W.shape)
         p = out if out is not None else self.empty((B, M))
         ws = self._scratch(B, M, F, int(T_frames), 1)
-        self._check(L.assx_power_from_cov(self.ctx, ptr(C), ptr(W), ptr(p), ptr(ws), B, M, F, self.prec.code,
+        self._check(self._L.assx_power_from_cov(self.ctx, ptr(C), ptr(W), ptr(p), ptr(ws), B, M, F, self.prec.code,
                                           self._st()), "assx_power_from_cov")
         return p
 
     def ilrma_normalize_power(self, W, Tb, power, domain=2, eps=1e-12):
         B, F, N, M = (int(s) for s in W.shape)
         K = int(Tb.shape[-1])
-        self._check(L.assx_ilrma_normalize_power(self.ctx, ptr(W), ptr(Tb), ptr(power), float(domain), float(eps), B, M,
+        self._check(self._L.assx_ilrma_normalize_power(self.ctx, ptr(W), ptr(Tb), ptr(power), float(domain), float(eps), B, M,
                                                  F, K, self.prec.code, self._st()), "assx_ilrma_normalize_power")
 
     def ilrma_normalize_power_bins(self, W, Tb, power_bins, domain=2, eps=1e-12):
         B, F, N, M = (int(s) for s in W.shape)
         K = int(Tb.shape[-1])
-        self._check(L.assx_ilrma_normalize_power_bins(self.ctx, ptr(W), ptr(Tb), ptr(power_bins), float(domain),
+        self._check(self._L.assx_ilrma_normalize_power_bins(self.ctx, ptr(W), ptr(Tb), ptr(power_bins), float(domain),
                                                       float(eps), B, M, F, K, self.prec.code, self._st()),
                     "assx_ilrma_normalize_power_bins")
 
     def ilrma_normalize_pb(self, W, Tb, scale, domain=2):
         B, F, N, M = (int(s) for s in W.shape)
         K = int(Tb.shape[-1])
-        self._check(L.assx_ilrma_normalize_pb(self.ctx, ptr(W), ptr(Tb), ptr(scale), float(domain), B, M, F, K,
+        self._check(self._L.assx_ilrma_normalize_pb(self.ctx, ptr(W), ptr(Tb), ptr(scale), float(domain), B, M, F, K,
                                               self.prec.code, self._st()), "assx_ilrma_normalize_pb")
 
     def ilrma_loss(self, X, W, Tb, V, domain=2, eps=1e-12, out=None):
@@ -186,7 +212,7 @@ class Engine:
         K = int(Tb.shape[-1])
         loss = out if out is not None else self.empty((B,), dtype=torch.float64)
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_ilrma_loss(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps), ptr(loss),
+        self._check(self._L.assx_ilrma_loss(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps), ptr(loss),
                                       ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_loss")
         return loss
 
@@ -194,10 +220,10 @@ class Engine:
     def stft(self, x, window, fft_size, hop):
         """x (C, L) real -> X (C, fft_size//2+1, n_frames) complex; scipy.signal.stft semantics (include/assx.h)."""
         C, n = int(x.shape[0]), int(x.shape[1])
-        T = int(L.assx_stft_num_frames(n, fft_size, hop))
+        T = int(self._L.assx_stft_num_frames(n, fft_size, hop))
         X = self.empty((C, fft_size // 2 + 1, max(T, 0)), complex_=True)
-        ws = self._ws.get(L.assx_stft_workspace_bytes(C, fft_size, max(T, 1), self.prec.code))
-        self._check(L.assx_stft(self.ctx, ptr(x), ptr(window), float(window.sum().item()), ptr(X), ptr(ws), C, n,
+        ws = self._ws.get(self._L.assx_stft_workspace_bytes(C, fft_size, max(T, 1), self.prec.code))
+        self._check(self._L.assx_stft(self.ctx, ptr(x), ptr(window), float(window.sum().item()), ptr(X), ptr(ws), C, n,
                                 fft_size, hop, T, self.prec.code, self._st()), "assx_stft")
         return X
 
@@ -206,10 +232,10 @@ class Engine:
         C, F, T = (int(v) for v in X.shape)
         if F != fft_size // 2 + 1:
             raise ValueError("istft: {} bins do not match fft_size={}".format(F, fft_size))
-        n = int(L.assx_istft_num_samples(fft_size, hop, T))
+        n = int(self._L.assx_istft_num_samples(fft_size, hop, T))
         y = self.empty((C, max(n, 0)))
-        ws = self._ws.get(L.assx_stft_workspace_bytes(C, fft_size, T, self.prec.code))
-        self._check(L.assx_istft(self.ctx, ptr(X), ptr(window), float(window.sum().item()), ptr(y), ptr(ws), C,
+        ws = self._ws.get(self._L.assx_stft_workspace_bytes(C, fft_size, T, self.prec.code))
+        self._check(self._L.assx_istft(self.ctx, ptr(X), ptr(window), float(window.sum().item()), ptr(y), ptr(ws), C,
                                  fft_size, hop, T, self.prec.code, self._st()), "assx_istft")
         return y
 
@@ -218,7 +244,7 @@ class Engine:
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_tilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
+        self._check(self._L.assx_tilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
                                                 ptr(ws), B, M, F, T, K, self.prec.code, self._st()),
                     "assx_tilrma_source_update")
 
@@ -227,7 +253,7 @@ class Engine:
         B, M, F, T = self._dims(X)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_tilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
+        self._check(self._L.assx_tilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
                                                  ptr(Xi), ptr(C), ptr(power_bins), ptr(status), ptr(ws), B, M, F, T,
                                                  K, self.prec.code, self._st()), "assx_tilrma_spatial_update")
         return W
@@ -237,7 +263,7 @@ class Engine:
         K = int(Tb.shape[-1])
         loss = out if out is not None else self.empty((B,), dtype=torch.float64)
         ws = self._scratch(B, M, F, T, K)
-        self._check(L.assx_tilrma_loss(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps), ptr(loss),
+        self._check(self._L.assx_tilrma_loss(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps), ptr(loss),
                                        ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_tilrma_loss")
         return loss
 
@@ -247,7 +273,7 @@ class Engine:
         r = out if out is not None else self.empty((B, M, T))
         loss = self.empty((B,), dtype=torch.float64) if with_loss else None
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_auxiva_weights(self.ctx, ptr(X), ptr(W), int(kind), float(eps), ptr(r), ptr(loss), ptr(ws),
+        self._check(self._L.assx_auxiva_weights(self.ctx, ptr(X), ptr(W), int(kind), float(eps), ptr(r), ptr(loss), ptr(ws),
                                           B, M, F, T, self.prec.code, self._st()), "assx_auxiva_weights")
         return r, loss
 
@@ -255,7 +281,7 @@ class Engine:
                               spatial=_lib.SPATIAL_IP, pair=(0, 1)):
         B, M, F, T = self._dims(X)
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_auxiva_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
+        self._check(self._L.assx_auxiva_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(r), float(eps), float(threshold),
                                                  ptr(U_out), ptr(status), ptr(ws), B, M, F, T, self.prec.code,
                                                  self._st()), "assx_auxiva_spatial_update")
 
@@ -264,7 +290,7 @@ class Engine:
         B, M, F, T = self._dims(X)
         scale = self.empty((B, M, F), complex_=True)
         ws = self._scratch(B, M, F, T, 1)
-        self._check(L.assx_projection_back_scale(self.ctx, ptr(X), ptr(W), int(ref), ptr(scale), ptr(status), ptr(ws),
+        self._check(self._L.assx_projection_back_scale(self.ctx, ptr(X), ptr(W), int(ref), ptr(scale), ptr(status), ptr(ws),
                                                  B, M, F, T, self.prec.code, self._st()), "assx_projection_back_scale")
         return scale
 
@@ -272,19 +298,28 @@ class Engine:
         B, N, F, T = self._dims(Y)
         scale = self.empty((B, N, F), complex_=True)
         ws = self._scratch(B, N, F, T, 1)
-        self._check(L.assx_projection_back(self.ctx, ptr(Y), ptr(reference), ptr(scale), ptr(status), ptr(ws), B, N, F,
+        self._check(self._L.assx_projection_back(self.ctx, ptr(Y), ptr(reference), ptr(scale), ptr(status), ptr(ws), B, N, F,
                                            T, self.prec.code, self._st()), "assx_projection_back")
         return scale
 
+    # ------------------------------------------------------------------ least-squares demixing filter
+    def compute_demix_filter(self, Y, X, status=None):
+        """W (B,F,M,M) = (Y X^H)(X X^H)^-1 per bin for Y, X (B,M,F,T)."""
+        B, M, F, T = self._dims(X)
+        W = self.empty((B, F, M, M), complex_=True)
+        self._check(self._L.assx_compute_demix_filter(self.ctx, ptr(Y), ptr(X), ptr(W), ptr(status), B, M, F, T,
+                                                      self.prec.code, self._st()), "assx_compute_demix_filter")
+        return W
+
     # ------------------------------------------------------------------ NMF
     def _nmf_scratch(self, B, F, T, K):
-        return self._ws.get(L.assx_nmf_workspace_bytes(B, F, T, K, self.prec.code))
+        return self._ws.get(self._L.assx_nmf_workspace_bytes(B, F, T, K, self.prec.code))
 
     def nmf_update(self, kind, X, Tb, V, domain=2, eps=1e-12, param=0.0):
         B, F, T = (int(s) for s in X.shape)
         K = int(Tb.shape[-1])
         ws = self._nmf_scratch(B, F, T, K)
-        self._check(L.assx_nmf_update_ex(self.ctx, int(kind), float(domain), float(param), float(eps), ptr(X), ptr(Tb),
+        self._check(self._L.assx_nmf_update_ex(self.ctx, int(kind), float(domain), float(param), float(eps), ptr(X), ptr(Tb),
                                          ptr(V), ptr(ws), B, F, T, K, self.prec.code, self._st()), "assx_nmf_update_ex")
 
     def nmf_loss(self, kind, X, Tb, V, domain=2, eps=1e-12, out=None, param=0.0):
@@ -292,7 +327,7 @@ class Engine:
         K = int(Tb.shape[-1])
         loss = out if out is not None else self.empty((B,), dtype=torch.float64)
         ws = self._nmf_scratch(B, F, T, K)
-        self._check(L.assx_nmf_loss_ex(self.ctx, int(kind), float(domain), float(param), float(eps), ptr(X), ptr(Tb),
+        self._check(self._L.assx_nmf_loss_ex(self.ctx, int(kind), float(domain), float(param), float(eps), ptr(X), ptr(Tb),
                                        ptr(V), ptr(loss), ptr(ws), B, F, T, K, self.prec.code, self._st()),
                     "assx_nmf_loss_ex")
         return loss

@@ -5,17 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (re-executes this file under
+torch.distributed.run on 127.0.0.1); under an external launcher WORLD_SIZE must equal N.  One process per GPU, RCCL.
+
 One "step" = one GaussILRMA.update_once() (source model + spatial model + power normalisation, loss recording
 off) over this rank's batch of utterances, inputs resident in HBM.  N=1 workload = BASELINE.json config 4
 (M=4, F=1025, T=4096, K=4, one utterance); N>1 = the same per-GPU workload on every rank (independent utterances,
 no data-path collective: "weak" scaling); value = utterance-iterations/s over all ranks.
 
-Rank 0 prints ONE JSON line with `roofline` (covariance-accumulate kernel, HIP events on the launch stream) and,
-at N=1, `cpu_baseline` (the NumPy oracle on the same workload, timed on this host).
+Rank 0 prints ONE JSON line with
+  roofline      covariance-accumulate kernel alone, HIP events on the launch stream, one utterance (X = 268.7 MB,
+                within 0.1 % of the 256 MiB Infinity Cache) -- and `roofline_b8`, the same kernel on 8 utterances in
+                one launch (2.15 GB: nothing of X survives in the cache), the figure to quote for sustained HBM rate;
+  cpu_baseline  (N=1) the NumPy oracle on the same workload timed on this host: streaming form (`value`) and the
+                reference's own materialising XX/R form on a quarter of the frames (`reference_form`);
+  config5       (N>1, or --config5) 64 seeded utterances block-partitioned over the ranks, one batched launch
+                sequence per rank, the reference's default 100 iterations + final projection back:
+                `value` without the edges, `value_incl_edges` with scatter X / gather Y over RCCL.
 """
 import argparse
 import json
 import os
+import platform
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,9 +55,36 @@ def parse():
     p.add_argument("--basis", type=int, default=4)
     p.add_argument("--power-statistic", default="covariance", choices=["covariance", "direct"])
     p.add_argument("--kernel-reps", type=int, default=50, help="launches of the covariance kernel for the roofline leg")
+    p.add_argument("--roofline-b8", type=int, default=8, help="utterances of the beyond-cache roofline leg (0 = skip)")
     p.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
+    p.add_argument("--cpu-reference-form", default="quarter", choices=["quarter", "full", "off"],
+                   help="reference-form (materialising XX/R) CPU leg: on T/4 frames (default), the full shape, or not")
     p.add_argument("--with-loss", action="store_true", help="also report it/s with recordable_loss=True")
+    p.add_argument("--config5", default="auto", choices=["auto", "on", "off"],
+                   help="config-5 leg (64 utterances sharded over the ranks); auto = only when N > 1")
+    p.add_argument("--config5-utterances", type=int, default=64)
+    p.add_argument("--config5-iterations", type=int, default=100)
     return p.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU) and relay their output."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks "
+                         "than asked for.\n" % (args.gpus, have))
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def synth_mixture(torch, dev, B, M, F, T, seed):
@@ -61,15 +101,175 @@ def synth_mixture(torch, dev, B, M, F, T, seed):
     return X
 
 
+def cov_contract_bytes(B, M, F, T, K, r, lds_ok=True):
+    """Algorithmic bytes of ONE covariance-accumulate launch (weights rebuilt in-kernel from Tb, V)."""
+    c = 2 * r
+    nbytes = B * (M * F * T * c + (M * F * K + M * K * T) * r + M * F * M * M * c)
+    name = "cov_stream_kernel"
+    if K > 4:
+        rpi = 2 if r == 8 else 4                      # rows per LDS-direct instruction (csrc/assx_cov_wide.hpp)
+        lds = 2 * ((M * K + rpi - 1) // rpi * rpi) * 64 * r + 8 * M * K * r
+        if lds <= 144 * 1024 and os.environ.get("ASSX_COV_WIDE", "1") != "0":
+            name = "cov_wide_kernel (+ cov_wide_finalize_kernel)"   # still "weights rebuilt in-kernel"
+        else:
+            # the source variance is materialised first (write N.F.T reals), then read back as (N,F,T) weights --
+            # the "weights materialised" contract of SURVEY.md 8d plus the map's own write
+            nbytes += B * 2 * M * F * T * r
+            name = "source_variance_map_kernel + cov_stream_kernel (N,F,T weights)"
+    return nbytes, name
+
+
+def time_cov_kernel(torch, eng, X, Td, Vd, reps):
+    """Mean duration (ms) of assx_ilrma_cov_partials = exactly one launch of the covariance kernel."""
+    for _ in range(5):
+        eng.ilrma_cov_partials(X, Td, Vd)
+    stream = torch.cuda.current_stream(eng.dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(reps):
+        eng.ilrma_cov_partials(X, Td, Vd)
+    e1.record(stream)
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def host_description():
+    model = platform.processor() or ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    info = {"cpu_model": model, "logical_cpus": os.cpu_count(), "numpy": np.__version__}
+    try:
+        from threadpoolctl import threadpool_info
+        pools = threadpool_info()
+        info["blas"] = ["%s %s (%s threads)" % (p.get("internal_api"), p.get("version"), p.get("num_threads"))
+                        for p in pools if p.get("user_api") == "blas"]
+        info["threads"] = max([p.get("num_threads", 1) for p in pools] + [1])
+    except Exception:
+        info["blas"] = []
+        info["threads"] = os.cpu_count()
+    return info
+
+
+def cpu_baseline_leg(args, Xh, M, F, T, K):
+    """The oracle (a NumPy port of the reference's update_once) on the GPU box's host cores; a reported baseline,
+    not the optimisation target.  Streaming form on the full utterance; reference (materialising) form on T/4."""
+    from oracle import oracle_np as orc  # reported baseline only; never on the product path
+    host = host_description()
+    np.random.seed(111)
+    Tb, V = np.random.rand(M, F, K), np.random.rand(M, K, T)
+    W = np.tile(np.eye(M, dtype=np.complex128), (F, 1, 1))
+    W, Tb, V, _ = orc.ilrma_update_once(Xh, W, Tb, V)  # warm-up (page faults, thread pools)
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_iters):
+        W, Tb, V, _ = orc.ilrma_update_once(Xh, W, Tb, V)
+    dt = time.perf_counter() - t0
+    out = {"value": round(args.cpu_iters / dt, 4), "unit": "iterations/s", "cores": int(host["threads"]),
+           "kind": "port",
+           "sample": "%d full update_once() iterations of the NumPy oracle (streaming covariance) on one "
+                     "M=%d F=%d T=%d K=%d complex128 utterance, after 1 warm-up" % (args.cpu_iters, M, F, T, K),
+           "host": host}
+    if args.cpu_reference_form != "off":
+        Ts = T if args.cpu_reference_form == "full" else max(T // 4, 1)
+        Xs = np.ascontiguousarray(Xh[:, :, :Ts])
+        np.random.seed(111)
+        Tb, V = np.random.rand(M, F, K), np.random.rand(M, K, Ts)
+        W = np.tile(np.eye(M, dtype=np.complex128), (F, 1, 1))
+        t0 = time.perf_counter()
+        orc.ilrma_update_once_reference_form(Xs, W, Tb, V)
+        dt = time.perf_counter() - t0
+        out["reference_form"] = {
+            "value": round(Ts / T / dt, 4), "unit": "iterations/s (scaled to T=%d)" % T, "seconds_measured": round(dt, 2),
+            "sample": "1 update_once() in the reference's materialising form (XX (F,T,M,M), XX/R (N,F,T,M,M) "
+                      "= %.2f GB, .mean) on M=%d F=%d T=%d of the same utterance; cost is linear in T, value = "
+                      "(T_sample/T)/seconds" % (M * F * Ts * M * M * 16 / 1e9, M, F, Ts)}
+    return out
+
+
+def config5_leg(args, torch, D, dev, rank, world, M, F, T, K):
+    """64 seeded utterances -> shard_range blocks -> one batched GaussILRMA call per rank -> gather."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    U, iters = args.config5_utterances, args.config5_iterations
+    cplx = torch.complex128 if args.dtype == "float64" else torch.complex64
+    x_all = None
+    if rank == 0:
+        x_all = torch.empty((U, M, F, T), dtype=cplx, device=dev)
+        for u0 in range(0, U, 8):  # utterance u has seed u (SURVEY.md 8d: "64 utterances of cfg4 with seeds 0..63")
+            for u in range(u0, min(u0 + 8, U)):
+                x_all[u] = synth_mixture(torch, dev, 1, M, F, T, seed=u)[0].to(cplx)
+
+    def init_fn(model, lo, hi):
+        st = [np.random.RandomState(111 + u) for u in range(lo, hi)]
+        model.basis = np.stack([s.rand(M, F, K) for s in st])
+        model.activation = np.stack([s.rand(M, K, T) for s in st])
+
+    def factory():
+        return GaussILRMA(n_basis=K, recordable_loss=False, dtype=args.dtype, device=dev)
+
+    lo, hi = D.shard_range(U, world, rank)
+    # warm-up of the compute path at this batch size (workspace growth, clocks), outside every timed region
+    if hi > lo:
+        warm = factory()
+        init_fn(warm, lo, hi)
+        gen = torch.Generator(device=dev).manual_seed(7)
+        xw = torch.view_as_complex(torch.randn((hi - lo, M, F, T, 2), dtype=torch.float64 if cplx == torch.complex128
+                                               else torch.float32, device=dev, generator=gen))
+        warm(xw, iteration=2)
+        del warm, xw
+    D.barrier(dev)
+    t0 = time.perf_counter()
+    x_local = D.scatter_utterances(x_all, U, (M, F, T), cplx, dev)
+    D.barrier(dev)
+    t1 = time.perf_counter()
+    model = factory()
+    if hi > lo:
+        init_fn(model, lo, hi)
+        y_local = model(x_local, iteration=iters)
+    else:
+        y_local = torch.empty((0, M, F, T), dtype=cplx, device=dev)
+    D.barrier(dev)
+    t2 = time.perf_counter()
+    y_all = D.gather_utterances(y_local, U)
+    D.barrier(dev)
+    t3 = time.perf_counter()
+    compute = D.max_over_ranks(t2 - t1, device=dev)
+    total = D.max_over_ranks(t3 - t0, device=dev)
+    if rank != 0:
+        return None
+    ok = bool(torch.isfinite(torch.view_as_real(y_all)).all().item())
+    return {"utterances": U, "iterations": iters, "utterances_per_gpu": D.shard_sizes(U, world),
+            "value": round(U * iters / compute, 2), "value_incl_edges": round(U * iters / total, 2),
+            "unit": "utterance-iterations/s", "seconds_compute": round(compute, 4),
+            "seconds_scatter": round(t1 - t0, 4), "seconds_gather": round(t3 - t2, 4),
+            "edge_bytes": 2 * U * M * F * T * (16 if args.dtype == "float64" else 8) * (world - 1) // world,
+            "outputs_finite": ok,
+            "note": "GaussILRMA()(X_block, iteration=%d) per rank incl. the final projection back; edges = grouped "
+                    "RCCL send/recv root<->peers of X and Y" % iters}
+
+
 def main():
     args = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        self_launch(args)
+    if env_world is not None and int(env_world) != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher set WORLD_SIZE=%s; they must agree.\n"
+                         % (args.gpus, env_world))
+        sys.exit(2)
+
     import torch
     import torch.distributed as dist
 
     from audio_source_separation_amd import distributed as D
-    rank, world, local_rank = D.init_from_env(backend="nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    rank, world, local_rank = D.init_from_env(backend="nccl" if args.gpus > 1 else None)
     n_gpus = world
     dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+    comm = {"backend": (dist.get_backend() if dist.is_initialized() else None),
+            "world_size": (dist.get_world_size() if dist.is_initialized() else 1)}
 
     from audio_source_separation_amd.bss.ilrma import GaussILRMA
 
@@ -104,6 +304,47 @@ def main():
         return D.max_over_ranks(time.perf_counter() - t0, device=dev)
 
     model = make_model(False)
+
+    # ---------------- roofline legs first (rank 0): the covariance-accumulate kernel alone, HIP events on the launch
+    # stream.  Running them before the timed steps also brings the clocks up, so a short --steps run is not low.
+    roofline = roofline_b8 = None
+    r = 8 if args.dtype == "float64" else 4
+    if rank == 0:
+        eng = model._engine
+        nbytes, kernel_name = cov_contract_bytes(B, M, F, T, K, r)
+        ms = time_cov_kernel(torch, eng, model._X, model._Td, model._Vd, args.kernel_reps)
+        achieved = nbytes / (ms * 1e-3) / 1e9
+        # HBM traffic per launch: NOT measured in this run -- read from the committed PMC passes of the same kernel
+        # and shape (tools/pmc_traffic.py -> profiles/cov_traffic.json); null when there is no matching record
+        traffic = traffic_source = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "cov_traffic.json")))
+            rec = tj[args.dtype] if K <= 4 else tj.get("wide_k%d" % K, {}).get(args.dtype)
+            if rec and (M, F, T) == (4, 1025, 4096):
+                traffic = int(round(rec["traffic_bytes"] * B))
+                traffic_source = "profiles/cov_traffic.json (separate rocprofv3 --pmc passes, %s)" % rec.get(
+                    "collected", "round 1")
+        except Exception:
+            pass
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "traffic_source": traffic_source, "kernel_ms": round(ms, 5),
+                    "algorithmic_bytes": nbytes, "utterances_per_launch": B}
+        if args.roofline_b8 > 0 and args.roofline_b8 != B:
+            B8 = args.roofline_b8
+            X8 = torch.cat([Xrun[:1]] * B8, dim=0).contiguous() if B == 1 else Xrun[:1].repeat(B8, 1, 1, 1)
+            T8 = model._Td[:1].repeat(B8, 1, 1, 1).contiguous()
+            V8 = model._Vd[:1].repeat(B8, 1, 1, 1).contiguous()
+            nb8, _ = cov_contract_bytes(B8, M, F, T, K, r)
+            ms8 = time_cov_kernel(torch, eng, X8, T8, V8, max(args.kernel_reps // 4, 5))
+            a8 = nb8 / (ms8 * 1e-3) / 1e9
+            roofline_b8 = {"bound": "hbm", "kernel": kernel_name, "achieved": round(a8, 1), "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": round(a8 / HBM_PEAK_GBS, 4), "traffic": None,
+                           "kernel_ms": round(ms8, 5), "algorithmic_bytes": nb8, "utterances_per_launch": B8,
+                           "note": "working set %.2f GB >> 256 MiB Infinity Cache" % (nb8 / 1e9)}
+            del X8, T8, V8
+            torch.cuda.empty_cache()
+
     elapsed = timed_steps(model, args.steps, args.warmup)
     model._check_status()
     total_units = n_gpus * B * args.steps  # utterance-iterations
@@ -114,72 +355,22 @@ def main():
         ml = make_model(True)
         dt = timed_steps(ml, args.steps, args.warmup, with_loss=True)
         extra["value_with_loss"] = n_gpus * B * args.steps / dt
+        del ml
 
-    # ---------------- roofline leg: the covariance-accumulate kernel alone, HIP events on the launch stream
-    roofline = None
-    if rank == 0:
-        eng = model._engine
-        c = 16 if args.dtype == "float64" else 8
-        r = c // 2
-        # algorithmic bytes per launch (weights rebuilt in-kernel from Tb,V), per utterance x B
-        bytes_per_launch = B * (M * F * T * c + (M * F * K + M * K * T) * r + M * F * M * M * c)
-        kernel_name = "cov_stream_kernel"
-        if K > 4:
-            rpi = 2 if r == 8 else 4                      # rows per LDS-direct instruction (csrc/assx_cov_wide.hpp)
-            lds = 2 * ((M * K + rpi - 1) // rpi * rpi) * 64 * r + 8 * M * K * r
-            if lds <= 144 * 1024 and os.environ.get("ASSX_COV_WIDE", "1") != "0":
-                # activation tile shared by 8 bins through LDS: still the "weights rebuilt in-kernel" contract
-                kernel_name = "cov_wide_kernel (+ cov_wide_finalize_kernel)"
-            else:
-                # the source variance is materialised first (write N.F.T reals), then read back as (N,F,T) weights --
-                # the "weights materialised" contract of SURVEY.md 8d plus the map's own write
-                bytes_per_launch += B * 2 * M * F * T * r
-                kernel_name = "source_variance_map_kernel + cov_stream_kernel (N,F,T weights)"
-        for _ in range(5):
-            eng.ilrma_cov_partials(model._X, model._Td, model._Vd)
-        stream = torch.cuda.current_stream(dev)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        for _ in range(args.kernel_reps):
-            eng.ilrma_cov_partials(model._X, model._Td, model._Vd)
-        e1.record(stream)
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / args.kernel_reps
-        achieved = bytes_per_launch / (ms * 1e-3) / 1e9
-        # HBM traffic per launch from the committed PMC passes (tools/pmc_traffic.py; same kernel, same shape)
-        traffic = None
+    # ---------------- config 5: sharded batch of utterances with and without the RCCL edges
+    config5 = None
+    if args.config5 == "on" or (args.config5 == "auto" and n_gpus > 1):
+        del model
+        torch.cuda.empty_cache()
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "cov_traffic.json")))[args.dtype]
-            if (M, F, T, K) == (4, 1025, 4096, 4):
-                traffic = int(round(tj["traffic_bytes"] * B))
-        except Exception:
-            pass
-        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "kernel_ms": round(ms, 5), "algorithmic_bytes": bytes_per_launch}
+            config5 = config5_leg(args, torch, D, dev, rank, world, M, F, T, K)
+        except Exception as exc:  # the headline line must survive a failure of this leg
+            config5 = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
     # ---------------- CPU baseline: the NumPy oracle on the same workload (rank 0, N=1 only)
     cpu_baseline = None
     if rank == 0 and n_gpus == 1 and args.cpu_iters > 0:
-        from oracle import oracle_np as orc  # reported baseline only; never on the product path
-        try:
-            from threadpoolctl import threadpool_info
-            cores = max([i.get("num_threads", 1) for i in threadpool_info()] + [1])
-        except Exception:
-            cores = os.cpu_count()
-        Xh = X[0].cpu().numpy()
-        np.random.seed(111)
-        Tb, V = np.random.rand(M, F, K), np.random.rand(M, K, T)
-        W = np.tile(np.eye(M, dtype=np.complex128), (F, 1, 1))
-        W, Tb, V, _ = orc.ilrma_update_once(Xh, W, Tb, V)  # warm-up (page faults, thread pools)
-        t0 = time.perf_counter()
-        for _ in range(args.cpu_iters):
-            W, Tb, V, _ = orc.ilrma_update_once(Xh, W, Tb, V)
-        dt = time.perf_counter() - t0
-        cpu_baseline = {"value": round(args.cpu_iters / dt, 4), "unit": "iterations/s", "cores": int(cores),
-                        "kind": "port",
-                        "sample": "%d full update_once() iterations of the NumPy oracle (streaming covariance) on one "
-                                  "M=%d F=%d T=%d K=%d complex128 utterance, after 1 warm-up" % (args.cpu_iters, M, F, T, K)}
+        cpu_baseline = cpu_baseline_leg(args, X[0].cpu().numpy(), M, F, T, K)
 
     if rank == 0:
         out = {
@@ -198,14 +389,18 @@ def main():
             "config": {"workload": "gauss_ilrma_ip update_once, M=%d F=%d T=%d K=%d, normalize=power, loss off" % (M, F, T, K),
                        "utterances_per_gpu": B, "power_statistic": args.power_statistic,
                        "parallelism": "utterance-sharded x%d, no data-path collective" % n_gpus},
+            "comm": comm,
             "roofline": roofline,
+            "roofline_b8": roofline_b8,
             "cpu_baseline": cpu_baseline,
         }
+        if config5 is not None:
+            out["config5"] = config5
         out.update(extra)
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[dev.index])
         dist.destroy_process_group()
 
 

@@ -1,6 +1,12 @@
 /*
  * assx.h -- C-ABI of the MI355X-native iterative source-separation hot path.
  *
+ * Scope of this boundary: the DEVICE side of ONE rank.  Every entry point is communication-free; multi-GPU runs are
+ * one process per GPU, each with its own context, and the only inter-GPU traffic (scatter of the mixtures, gather of
+ * the separated outputs -- utterances are independent, src/bss/ilrma.py:203-273) is issued by the host language
+ * through its RCCL binding (audio_source_separation_amd/distributed.py).  There are
+ * deliberately no assx_comm_* symbols.
+ *
  * The reference (tky823/audio_source_separation) has NO plugin / FFI / operator API: its
  * boundary is the Python class surface.  This header is therefore the
  * NEW device boundary that the package's own Python classes (and any other host language)
@@ -27,6 +33,8 @@
  *   - Return: 0 ok; <0 invalid argument (ASSX_E_*); >0 a hipError_t.  Nothing throws across the
  *     boundary; assx_last_error(ctx) returns the message of the last failure on that context.
  *   - One context per (device, host thread); contexts are not thread-safe.
+ *   - The library never changes the calling thread's current device.  The caller makes the context's device current
+ *     (hipSetDevice) before every call; a call made with another device current is refused with ASSX_E_ARG.
  */
 #ifndef ASSX_H
 #define ASSX_H
@@ -231,6 +239,14 @@ int assx_projection_back_scale(assx_ctx* ctx, const void* X, const void* W, int 
 /* General form on a materialised Y (B,N,F,T) and an explicit reference (B,F,T). */
 int assx_projection_back(assx_ctx* ctx, const void* Y, const void* reference, void* scale,
                          int32_t* status, void* ws, int B, int N, int F, int T, int dtype, void* stream);
+
+/* ---- (a9) least-squares demixing filter --------------------------------------------------- */
+/* ILRMAbase.compute_demix_filter / IVAbase.compute_demix_filter (src/bss/ilrma.py:167-173, src/bss/iva.py:119-125):
+ * W[b,f] = (Y X^H)(X X^H)^{-1} per bin, Y (B,M,F,T) an estimate, X (B,M,F,T) the mixture, W (B,F,M,M).  This is how
+ * the reference rebuilds `demix_filter` from `estimation` for callbacks / the loss / the output of its ISS loop.
+ * 2 <= M <= 8.  An exactly singular X X^H sets ASSX_STATUS_SINGULAR (numpy.linalg.inv would raise LinAlgError). */
+int assx_compute_demix_filter(assx_ctx* ctx, const void* Y, const void* X, void* W, int32_t* status,
+                              int B, int M, int F, int T, int dtype, void* stream);
 
 /* ---- (a1) NMF multiplicative updates ----------------------------------------------------- */
 /* EUCNMF/KLNMF/ISNMF.update_once_mm, ISNMF.update_once_me (src/algorithm/nmf.py:182-207,

@@ -3,6 +3,7 @@ table covers the header, and the host-side class logic that needs no GPU behaves
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -128,6 +129,20 @@ def test_lazy_loss_list_defers_and_resolves():
     assert np.asarray(ll).tolist() == [3.0, 7.5]
     ll.append_device(FakeTensor([1.0, 2.0]), batched=True)       # utterance axis: one value per utterance
     assert np.array_equal(np.asarray(ll[2]), [1.0, 2.0])
+    # mutators with entries still parked: the reference's `loss` is a plain list, users reset / trim it
+    for mutate, expect in ((lambda l: l.clear(), [4.0]), (lambda l: l.insert(0, -1.0), [-1.0, 3.0, 9.0, 4.0]),
+                           (lambda l: l.__delitem__(0), [9.0, 4.0]), (lambda l: l.remove(3.0), [9.0, 4.0]),
+                           (lambda l: l.extend([5.0]), [3.0, 9.0, 5.0, 4.0]),
+                           (lambda l: l.__setitem__(slice(0, 2), [0.0]), [0.0, 4.0])):
+        ll = LazyLossList([3.0])
+        ll.append_device(FakeTensor([9.0]), batched=False)
+        mutate(ll)
+        ll.append_device(FakeTensor([4.0]), batched=False)
+        assert list(ll) == expect
+    ll = LazyLossList([3.0])
+    ll.append_device(FakeTensor([9.0]), batched=False)
+    ll += [1.0]
+    assert isinstance(ll, LazyLossList) and list(ll) == [3.0, 9.0, 1.0]
 
 
 def test_stft_geometry_matches_scipy_semantics():
@@ -157,3 +172,20 @@ def test_workspace_grows_for_wide_basis():
     small = lib.assx_workspace_bytes(1, 4, 1025, 4096, 4, _lib.F64)
     wide = lib.assx_workspace_bytes(1, 4, 1025, 4096, 10, _lib.F64)
     assert wide - small >= 4 * 1025 * 4096 * 8 + lib.assx_nmf_workspace_bytes(4, 1025, 4096, 10, _lib.F64) - 4096
+
+
+def test_bench_gpus_flag_is_honoured_or_refused():
+    """`bench.py --gpus N` must run N ranks or fail loudly -- never silently run one (VERDICT r1 / ADVICE r1)."""
+    import subprocess
+    import torch
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # a launcher that set another world size than --gpus: refused before any GPU work
+    r = subprocess.run([sys.executable, bench, "--gpus", "1"], env=dict(env, WORLD_SIZE="2", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "must agree" in r.stderr
+    # more ranks than visible GPUs: refused by the self-launcher (this container has no GPU at all)
+    want = torch.cuda.device_count() + 1 if torch.cuda.device_count() >= 1 else 2
+    r = subprocess.run([sys.executable, bench, "--gpus", str(want)], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr

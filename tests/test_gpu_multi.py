@@ -1,0 +1,120 @@
+"""Two ranks running the REAL GaussILRMA through `distributed.separate_sharded` (the config-5 driver).
+
+With >= 2 GPUs: one process per GPU, backend "nccl" (= RCCL over xGMI), edge buffers in HBM.  With one GPU (the
+gpurun box): the same two processes share cuda:0 and stage the scatter/gather through host memory over "gloo" --
+everything but the transport is identical.  Either way the sharded result must equal the single-process batched
+result BIT FOR BIT, in the original utterance order, for an even and a ragged split."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+M, F, T, K, ITER = 4, 33, 96, 4, 4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _mixtures(n_items):
+    rng = np.random.default_rng(11)
+    S = (rng.standard_normal((n_items, M, F, T)) + 1j * rng.standard_normal((n_items, M, F, T))) * \
+        rng.random((n_items, M, 1, T)) ** 2
+    A = rng.standard_normal((n_items, F, M, M)) + 1j * rng.standard_normal((n_items, F, M, M))
+    return np.einsum("bfmn,bnft->bmft", A, S)
+
+
+def _init_fn(model, lo, hi):
+    st = [np.random.RandomState(111 + u) for u in range(lo, hi)]
+    model.basis = np.stack([s.rand(M, F, K) for s in st])
+    model.activation = np.stack([s.rand(M, K, T) for s in st])
+
+
+def _factory():
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    return GaussILRMA(n_basis=K, recordable_loss=True)
+
+
+def _worker(rank, world, port, n_items, backend, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == "nccl" else 0),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    from audio_source_separation_amd import distributed as D
+    D.init_from_env(backend=backend)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    comm_dev = dev if backend == "nccl" else "cpu"
+    x_all = torch.from_numpy(_mixtures(n_items)).to(comm_dev) if rank == 0 else None
+    y, model = D.separate_sharded(_factory, x_all, n_items, (M, F, T), torch.complex128, dev, iteration=ITER,
+                                  init_fn=_init_fn, comm_device=comm_dev)
+    lo, hi = D.shard_range(n_items, world, rank)
+    loss = np.asarray(model.loss) if hi > lo else None  # (ITER+1, n_local)
+    tmax = D.max_over_ranks(1.0 + rank, device=comm_dev)
+    D.barrier(dev)
+    q.put((rank, None if y is None else y.cpu().numpy(), loss, tmax))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [4, 5])
+def test_two_ranks_real_gauss_ilrma_bit_identical(n_items):
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    y = results[0][1]
+    assert results[1][1] is None and results[0][3] == 2.0 and results[1][3] == 2.0
+    # single process, all utterances in one batched call
+    single = _factory()
+    _init_fn(single, 0, n_items)
+    ref = single(_mixtures(n_items), iteration=ITER)
+    assert y.shape == ref.shape and np.array_equal(y, ref)
+    loss = np.concatenate([r[2] for r in results if r[2] is not None], axis=1)
+    assert np.array_equal(loss, np.asarray(single.loss))
+
+
+def test_rccl_single_rank_group_and_bench_under_launcher():
+    """RCCL itself on this box: a 1-rank "nccl" group (all-reduce, barrier), then bench.py under torch.distributed.run
+    exactly as the driver launches it (rendezvous on 127.0.0.1), with the config-5 leg on a reduced batch."""
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='%d')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "t = torch.ones(4, device='cuda', dtype=torch.float64)\n"
+        "dist.all_reduce(t); dist.barrier(device_ids=[0]); torch.cuda.synchronize()\n"
+        "assert t.sum().item() == 4.0\n"
+        "dist.destroy_process_group(); print('rccl ok')\n" % _free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps",
+           "3", "--warmup", "1", "--bins", "129", "--frames", "512", "--cpu-iters", "0", "--kernel-reps", "3",
+           "--roofline-b8", "2", "--config5", "on", "--config5-utterances", "3", "--config5-iterations", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    import json
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["roofline_b8"]["utterances_per_launch"] == 2
+    assert out["config5"]["utterances"] == 3 and out["config5"]["outputs_finite"] and out["config5"]["value"] > 0

@@ -333,3 +333,23 @@ def test_consistent_gauss_ilrma():
         assert rel_err(W, g["W_%d" % k]) < 1e-9 and rel_err(T, g["T_%d" % k]) < 1e-9 and rel_err(V, g["V_%d" % k]) < 1e-9
     np.testing.assert_allclose(out["loss"], g["loss"], rtol=1e-10)
     assert rel_err(out["Y"], g["Y_out"]) < 1e-9
+
+
+def test_reference_form_covariance_equals_streaming_form():
+    """The materialising XX/R form (ilrma.py:503-511; only bench.py's cpu_baseline times it) and the streaming form
+    used everywhere else are the same U; and against the reference-formed U of the stage fixture."""
+    g = load_golden("ilrma_stages")
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((3, 7, 50)) + 1j * rng.standard_normal((3, 7, 50))
+    R = rng.random((3, 7, 50)) + 1e-3
+    assert rel_err(orc.weighted_covariance_reference_form(X, R), orc.weighted_covariance(X, R)) < 1e-14
+    r = rng.random((3, 50))
+    assert rel_err(orc.weighted_covariance_reference_form(X, r), orc.weighted_covariance(X, r)) < 1e-14
+    T, V = rng.random((3, 7, 2)), rng.random((3, 2, 50))
+    W = np.tile(np.eye(3, dtype=np.complex128), (7, 1, 1))
+    a = orc.ilrma_update_once_reference_form(X, W.copy(), T, V)
+    b = orc.ilrma_update_once(X, W.copy(), T, V)
+    for x, y in zip(a, b[:3]):
+        assert rel_err(x, y) < 1e-12
+    # the reference's own U (formed by ilrma.py:503-511 inside update_spatial_model_ip) from its T1, V1
+    assert rel_err(orc.weighted_covariance_reference_form(g["X"], orc.ilrma_variance(g["T1"], g["V1"])), g["U"]) < 1e-13
