@@ -333,31 +333,46 @@ __global__ void __launch_bounds__(64)
   // partial records covering this bin (FROM_PART): computed once, 32-bit arithmetic (NB < 2^31 is checked on the host)
   int g_lo = 0, g_hi = -1, base = 0;
   if (FROM_PART) {
-    const unsigned q_lo = (unsigned)bf * (unsigned)fp.len;
-    g_lo = (int)(q_lo / (unsigned)fp.L);
-    g_hi = (int)((q_lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+    flat_cover(fp, bf, g_lo, g_hi);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
   }
 
+  // ---- this lane's element of every U_n, fetched up front: the loads of the N sources are independent, the sweep
+  //      below is a serial chain -- inside the loop each source would pay its own round trip to L2 / HBM (with 8
+  //      utterances per launch the records no longer fit the L2: 51 us per utterance instead of 21)
+  Cd uall[N];
+  if (FROM_PART) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) uall[n] = cmake<double>(0.0, 0.0);
+    for (int g = g_lo; g <= g_hi; ++g) {
+      const int slot = flat_slot(fp, bf, g);
+      const R* p = part + ((size_t)g * fp.S + slot) * N * MM;
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        uall[n].x += (double)p[n * MM + base];
+        if (i != j) uall[n].y += (double)p[n * MM + base + 1];
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      if (i > j) uall[n].y = -uall[n].y;
+      uall[n] = cmake<double>(uall[n].x * inv_T, uall[n].y * inv_T);
+    }
+  } else {
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const Cx<R> v = U[(((size_t)b * N + n) * F + f) * MM + i * M + j];
+      uall[n] = cmake<double>((double)v.x, (double)v.y);
+    }
+  }
+
 #pragma unroll 1
   for (int n = 0; n < N; ++n) {
-    // ---- this lane's element of U_n
-    Cd u;
-    if (FROM_PART) {
-      double re = 0.0, im = 0.0;
-      for (int g = g_lo; g <= g_hi; ++g) {
-        const int slot = (int)bf - (int)(((unsigned)g * (unsigned)fp.L) / (unsigned)fp.len);
-        const R* p = part + (((size_t)g * fp.S + slot) * N + n) * MM;
-        re += (double)p[base];
-        if (i != j) im += (double)p[base + 1];
-      }
-      if (i > j) im = -im;
-      u = cmake<double>(re * inv_T, im * inv_T);
-    } else {
-      const Cx<R> v = U[(((size_t)b * N + n) * F + f) * MM + i * M + j];
-      u = cmake<double>((double)v.x, (double)v.y);
-    }
+    Cd u = uall[0];
+#pragma unroll
+    for (int q = 1; q < N; ++q)
+      if (q == n) u = uall[q];
     // ---- A = W @ U_n
     Cd a = cmake<double>(0.0, 0.0);
 #pragma unroll
@@ -432,15 +447,15 @@ __global__ void __launch_bounds__(64)
   // this lane's element (i, j) of every source's covariance (the weights are fixed during the sweep)
   Cd u[N];
   if (FROM_PART) {
-    const unsigned q_lo = (unsigned)bf * (unsigned)fp.len;
-    const int g_lo = (int)(q_lo / (unsigned)fp.L), g_hi = (int)((q_lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+    int g_lo, g_hi;
+    flat_cover(fp, bf, g_lo, g_hi);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
 #pragma unroll
     for (int s = 0; s < N; ++s) {
       double re = 0.0, im = 0.0;
       for (int g = g_lo; g <= g_hi; ++g) {
-        const int slot = (int)bf - (int)(((unsigned)g * (unsigned)fp.L) / (unsigned)fp.len);
+        const int slot = flat_slot(fp, bf, g);
         const R* p = part + (((size_t)g * fp.S + slot) * N + s) * MM;
         re += (double)p[base];
         if (i != j) im += (double)p[base + 1];
@@ -531,13 +546,13 @@ __global__ void __launch_bounds__(64)
   }
   auto load_u = [&](int src) -> Cd {
     if (FROM_PART) {
-      const unsigned q_lo = (unsigned)bf * (unsigned)fp.len;
-      const int g_lo = (int)(q_lo / (unsigned)fp.L), g_hi = (int)((q_lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+      int g_lo, g_hi;
+      flat_cover(fp, bf, g_lo, g_hi);
       const int lo = i < j ? i : j, hi = i < j ? j : i;
       const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
       double re = 0.0, im = 0.0;
       for (int g = g_lo; g <= g_hi; ++g) {
-        const int slot = (int)bf - (int)(((unsigned)g * (unsigned)fp.L) / (unsigned)fp.len);
+        const int slot = flat_slot(fp, bf, g);
         const R* p = part + (((size_t)g * fp.S + slot) * N + src) * MM;
         re += (double)p[base];
         if (i != j) im += (double)p[base + 1];
@@ -941,12 +956,11 @@ __global__ void __launch_bounds__(64) logdet_kernel(const Cx<R>* __restrict__ W,
 // logdet_kernel left at lpart[b][ncov ..).  One workgroup per utterance, fixed summation order.
 __global__ void __launch_bounds__(REDUCE_THREADS) ilrma_loss_finish_kernel(const double* __restrict__ lpart,
                                                                           double* __restrict__ loss, int F, int ncov,
-                                                                          int lstride, long long items_per_utt, int L) {
+                                                                          int lstride) {
   __shared__ double sm[REDUCE_THREADS];
   const int b = blockIdx.x;
-  const int g_lo = (int)(((long long)b * items_per_utt) / L), g_hi = (int)((((long long)b + 1) * items_per_utt - 1) / L);
   double s = 0.0;
-  for (int i = threadIdx.x; i <= g_hi - g_lo; i += REDUCE_THREADS) s += lpart[(size_t)b * lstride + i];
+  for (int i = threadIdx.x; i < ncov; i += REDUCE_THREADS) s += lpart[(size_t)b * lstride + i];
   for (int f = threadIdx.x; f < F; f += REDUCE_THREADS) s += lpart[(size_t)b * lstride + ncov + f];
   sm[threadIdx.x] = s;
   __syncthreads();
@@ -1067,7 +1081,8 @@ inline int env_int(const char* name, int dflt) {
 inline void t_split(int B, int F, int T, int* TS, int* tchunk) {
   static const int target = env_int("ASSX_TARGET_WAVES", 8192);
   static const int forced = env_int("ASSX_TS", 0);
-  int ts = forced > 0 ? forced : (int)((target + (size_t)B * F - 1) / ((size_t)B * F));
+  (void)B;  // the split is a function of ONE utterance's geometry: batched == per-utterance, bit for bit
+  int ts = forced > 0 ? forced : (int)((target + (size_t)F - 1) / ((size_t)F));
   int max_ts = (T + 255) / 256;  // at least 4 frames per lane
   if (ts > max_ts) ts = max_ts;
   if (ts < 1) ts = 1;
@@ -1082,7 +1097,8 @@ inline void f_split(int B, int F, int T, int* FS, int* fchunk) {
   static const int target = env_int("ASSX_TARGET_WGS", 1024);
   static const int forced = env_int("ASSX_FS", 0);
   const int TB = (T + WAVE - 1) / WAVE;
-  int fs = forced > 0 ? forced : (int)((target + (size_t)B * TB - 1) / ((size_t)B * TB));
+  (void)B;
+  int fs = forced > 0 ? forced : (int)((target + (size_t)TB - 1) / ((size_t)TB));
   int max_fs = (F + 7) / 8;  // at least 2 bins per wave
   if (fs > max_fs) fs = max_fs;
   if (fs < 1) fs = 1;
@@ -1199,21 +1215,21 @@ template <typename R, int M>
 constexpr int cov_lane_split() { return 1; }
 inline FlatPart flat_cov(int B, int F, int T, int LS) {
   const int fb = WAVE / LS, tbk = (T + fb - 1) / fb;
-  return make_flat((long long)B * F * tbk, tbk, g_target(8));
+  return make_flat(B, (long long)F * tbk, tbk, g_target(8));
 }
 inline FlatPart flat_basis(int B, int F, int T) {  // basis_stream_kernel: 1 wave per workgroup, 2 waves/SIMD
-  return make_flat((long long)B * F * tblocks(T), tblocks(T), g_target(8));
+  return make_flat(B, (long long)F * tblocks(T), tblocks(T), g_target(8));
 }
 inline FlatPart flat_act(int B, int F, int T) {    // act_stream_kernel: ACT_NH waves per workgroup, 2 waves/SIMD
-  return make_flat((long long)B * tblocks(T) * F, F, g_target(8 / ACT_NH));
+  return make_flat(B, (long long)tblocks(T) * F, F, g_target(8 / ACT_NH));
 }
 
 inline FlatPart flat_cov_wide(int B, int F, int T) {  // cov_wide_kernel: COVW_BINS waves per workgroup, one workgroup per CU
-  return make_flat((long long)B * ((F + COVW_BINS - 1) / COVW_BINS) * tblocks(T), tblocks(T), g_target(1));
+  return make_flat(B, (long long)((F + COVW_BINS - 1) / COVW_BINS) * tblocks(T), tblocks(T), g_target(1));
 }
 
-inline FlatPart flat_loss(int F, int T) {  // loss_stream_kernel: per-utterance partition (grid.y = B)
-  return make_flat((long long)F * tblocks(T), tblocks(T), g_target(8));
+inline FlatPart flat_loss(int F, int T) {  // loss_stream_kernel: the utterance index is grid.y
+  return make_flat(1, (long long)F * tblocks(T), tblocks(T), g_target(8));
 }
 
 inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
@@ -1267,18 +1283,24 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
 
 template <typename Fn>
 int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
+  // ASSX_DEV_ONLY_M4_F64 (build.sh with ASSX_DEV=1): instantiate the headline configuration only -- a third of the
+  // compile time while a kernel is being tuned.  Never shipped: the full build is what the tests run.
   if (dtype == ASSX_F64) {
     switch (M) {
+#if !defined(ASSX_DEV_ONLY_M4_F64)
       case 2: return fn(double(), IntC<2>());
       case 3: return fn(double(), IntC<3>());
+#endif
       case 4: return fn(double(), IntC<4>());
     }
   } else if (dtype == ASSX_F32) {
+#if !defined(ASSX_DEV_ONLY_M4_F64)
     switch (M) {
       case 2: return fn(float(), IntC<2>());
       case 3: return fn(float(), IntC<3>());
       case 4: return fn(float(), IntC<4>());
     }
+#endif
   } else {
     return fail(ctx, ASSX_E_ARG, "dtype must be ASSX_F32 or ASSX_F64, got %d", dtype);
   }
@@ -1657,7 +1679,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
       } else {
         const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
         const FlatPart fb = flat_basis(B, F, T);
-        const int ncov = (int)(((long long)F * tblocks(T) + fb.L - 1) / fb.L) + 1;  // workgroups touching one utterance
+        const int ncov = fb.Gu;  // workgroups of one utterance (the partition is per utterance)
         lstride = ncov + F;  // [per-workgroup data terms | F log-det terms]
         ASSX_REQUIRE(ctx, (size_t)B * lstride * sizeof(double) <= L.small - L.lpart, ASSX_E_UNSUPPORTED,
                      "workspace too small for the fused loss partials");
@@ -1677,6 +1699,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
                            (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
         ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
       }
+      NmfGroupScope grp(ctx, MM);
       return assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype,
                              stream);
     }
@@ -1696,7 +1719,10 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
       hipError_t e = hipMemcpyAsync(Tt, Tb, nT * sizeof(R), hipMemcpyDeviceToDevice, st);
       if (e == hipSuccess) e = hipMemcpyAsync(Vt, V, nV * sizeof(R), hipMemcpyDeviceToDevice, st);
       if (e != hipSuccess) return fail(ctx, (int)e, "hipMemcpyAsync(model copy): %s", hipGetErrorString(e));
-      rc = assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tt, Vt, (char*)ws + L.nmf, B * MM, F, T, K, dtype, stream);
+      {
+        NmfGroupScope grp(ctx, MM);
+        rc = assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, pw, Tt, Vt, (char*)ws + L.nmf, B * MM, F, T, K, dtype, stream);
+      }
       if (rc) return rc;
       hipLaunchKernelGGL((masked_model_copy_kernel<R>), dim3(blocks_for(nT + nV, 256)), dim3(256), 0, st, (const R*)Tt,
                          (const R*)Vt, (R*)Tb, (R*)V, B, MM, (size_t)F * K, (size_t)K * T, source_mask);
@@ -1707,7 +1733,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     if (rc) return rc;
     if (lpart) {
       hipLaunchKernelGGL(ilrma_loss_finish_kernel, dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lpart, loss_prev,
-                         F, lstride - F, lstride, (long long)F * tblocks(T), fp.L);
+                         F, lstride - F, lstride);
       ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_finish_kernel");
     }
     hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
@@ -1774,11 +1800,12 @@ int assx_ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const voi
                          (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
       ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
       const int TBk = tblocks(T);
-      const FlatPart fpb{(long long)B * F * TBk, TBk, TBk, B * F, 1};   // one record per bin
-      const FlatPart fpa{(long long)B * TBk * F, F, F, B * TBk, 1};     // one record per frame block
+      const FlatPart fpb{(long long)F * TBk, TBk, TBk, B * F, 1, F, F};      // one record per bin
+      const FlatPart fpa{(long long)TBk * F, F, F, B * TBk, 1, TBk, TBk};    // one record per frame block
       auto sums = [&](int half) -> int {
         const void* np = nullptr;
         int slabs = 0;
+        NmfGroupScope grp(ctx, MM);
         int r2 = nmf_half_partials(ctx, ASSX_NMF_IS_MM, 2.0, 0.0, eps, half, pw, Teff, Veff, nws, B * MM, F, T, K, dtype,
                                    st, &np, &slabs);
         if (r2) return r2;
@@ -2115,6 +2142,7 @@ int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void*
       hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
                          (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
       ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+      NmfGroupScope grp(ctx, MM);
       return assx_nmf_update_ex(ctx, ASSX_NMF_T_RAW, 2.0, nu, eps, pw, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype,
                                 stream);
     }

@@ -13,9 +13,20 @@
 struct assx_ctx {
   int device;
   char err[512];
+  // matrices per independent problem in the NMF entry points (1 = plain NMF; the ILRMA source model sets N: its
+  // batch is B utterances x N sources).  The split-T / split-F slab counts are derived from ONE problem's geometry,
+  // never from the batch size, so that a batched call sums in the same order as per-item calls (bit-identical).
+  int nmf_group;
 };
 
 namespace assx {
+
+struct NmfGroupScope {  // sets assx_ctx::nmf_group for the NMF calls made inside the scope
+  assx_ctx* c;
+  int old;
+  NmfGroupScope(assx_ctx* ctx, int group) : c(ctx), old(ctx->nmf_group) { c->nmf_group = group; }
+  ~NmfGroupScope() { c->nmf_group = old; }
+};
 
 constexpr int WAVE = 64;
 

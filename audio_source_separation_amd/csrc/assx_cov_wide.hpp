@@ -40,8 +40,8 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = (int)blockIdx.x;
-  const long long q0 = (long long)g * fp.L;
-  const long long q1 = (q0 + fp.L < fp.NB) ? q0 + fp.L : fp.NB;
+  long long q0, q1;
+  flat_range(fp, g, q0, q1);
   if (q0 >= q1) return;
   const int nblk = (int)(q1 - q0);
   const int jg_first = (int)(q0 / TBk);
@@ -158,10 +158,11 @@ __global__ void __launch_bounds__(256) cov_wide_finalize_kernel(const R* __restr
   const int b = idx / ((size_t)HM * F * N);
   const int FG = (F + WB - 1) / WB;
   const long long j = (long long)b * FG + f / WB;
-  const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
+  int g_lo, g_hi;
+  flat_cover(fp, j, g_lo, g_hi);
   R re = 0, im = 0;
   for (int g = g_lo; g <= g_hi; ++g) {
-    const int slot = (int)(j - ((long long)g * fp.L) / fp.len);
+    const int slot = flat_slot(fp, j, g);
     const R* p = part + ((((size_t)g * fp.S + slot) * WB + f % WB) * N + n) * HM;
     if (m == l) {
       re += p[m];

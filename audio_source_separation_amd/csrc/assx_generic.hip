@@ -25,22 +25,23 @@ __device__ inline bool gj_inverse_rt(Cd* A, int M) {
     if (!(best > 0.0)) ok = false;
     if (p != c)
       for (int j = 0; j < M; ++j) cswap(A[c * M + j], A[p * M + j]);
-    Cd ipv = cdiv(cmake<double>(1.0, 0.0), A[c * M + c]);
-    A[c * M + c] = cmake<double>(1.0, 0.0);
-    for (int j = 0; j < M; ++j) A[c * M + j] = cmul(A[c * M + j], ipv);
+    // eliminate with the UNSCALED pivot row and the factor l = A[r][c] / pivot (the LU multiplier): an exactly
+    // dependent row then cancels to exact zeros and the next pivot search reports the singularity, as zgetrf does
+    const Cd pv = A[c * M + c];
     for (int r = 0; r < M; ++r) {
       if (r == c) continue;
-      Cd f = A[r * M + c];
-      A[r * M + c] = cmake<double>(0.0, 0.0);
+      const Cd f = cdiv(A[r * M + c], pv);
       for (int j = 0; j < M; ++j) {
+        if (j == c) continue;
         Cd a = A[c * M + j], v = A[r * M + j];
-        v.x = fma(-f.x, a.x, v.x);
-        v.x = fma(f.y, a.y, v.x);
-        v.y = fma(-f.x, a.y, v.y);
-        v.y = fma(-f.y, a.x, v.y);
+        v.x = v.x - (f.x * a.x - f.y * a.y);
+        v.y = v.y - (f.x * a.y + f.y * a.x);
         A[r * M + j] = v;
       }
+      A[r * M + c] = cmake<double>(-f.x, -f.y);
     }
+    const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
+    for (int j = 0; j < M; ++j) A[c * M + j] = (j == c) ? ipv : cmul(A[c * M + j], ipv);
   }
   for (int c = M - 1; c >= 0; --c) {
     int p = piv[c];
@@ -95,10 +96,10 @@ __global__ __launch_bounds__(256) void lsq_demix_kernel(const Cx<R>* __restrict_
         }
 #pragma unroll
         for (int j = 0; j < M; ++j) {  // acc += s conj(x_j)
-          acc[i][j].x = fma(s.x, x[j].x, acc[i][j].x);
-          acc[i][j].x = fma(s.y, x[j].y, acc[i][j].x);
-          acc[i][j].y = fma(s.y, x[j].x, acc[i][j].y);
-          acc[i][j].y = fma(-s.x, x[j].y, acc[i][j].y);
+          // the products are rounded separately (no fma) so that s conj(x_j) is EXACTLY Hermitian-symmetric for
+          // rows of X: identical channels then give an exactly singular X X^H, as they do in the reference's zgemm
+          acc[i][j].x += __dmul_rn(s.x, x[j].x) + __dmul_rn(s.y, x[j].y);
+          acc[i][j].y += __dmul_rn(s.y, x[j].x) - __dmul_rn(s.x, x[j].y);
         }
       }
     }

@@ -270,10 +270,14 @@ inline int nmf_env_int(const char* name, int dflt) {
 }
 
 // split counts of the MFMA path (deterministic: no device query)
-inline void mfma_basis_split(int B, int F, int T, int* TS, int* tchunk) {
+inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ? ctx->nmf_group : 1; }
+
+// `group` = matrices per independent problem (assx_ctx::nmf_group), NOT the batch size: the slab count must not
+// depend on how many problems share the launch
+inline void mfma_basis_split(int group, int F, int T, int* TS, int* tchunk) {
   const int fg = (F + 63) / 64;
   const int wgs = nmf_env_int("ASSX_NMF_BASIS_WGS", 512);
-  int ts = (wgs + fg * B - 1) / (fg * B);  // one resident round; fewer slabs for the finalize
+  int ts = (wgs + fg * group - 1) / (fg * group);  // one resident round; fewer slabs for the finalize
   const int max_ts = (T + 63) / 64;
   if (ts > max_ts) ts = max_ts;
   if (ts < 1) ts = 1;
@@ -281,10 +285,10 @@ inline void mfma_basis_split(int B, int F, int T, int* TS, int* tchunk) {
   *tchunk = chunk;
   *TS = (T + chunk - 1) / chunk;
 }
-inline void mfma_act_split(int B, int F, int T, int* FS, int* fchunk) {
+inline void mfma_act_split(int group, int F, int T, int* FS, int* fchunk) {
   const int tg = (T + 15) / 16;
   const int wgs = nmf_env_int("ASSX_NMF_ACT_WGS", 1024);
-  int fs = (wgs + tg * B - 1) / (tg * B);
+  int fs = (wgs + tg * group - 1) / (tg * group);
   const int max_fs = (F + 63) / 64;
   if (fs > max_fs) fs = max_fs;
   if (fs < 1) fs = 1;
@@ -300,15 +304,15 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   size_t off = align_up((size_t)B * 2 * F * T * r, 256);
   w.part = off;
   // split-K slabs: basis (2B, F, K) x splits_t ; activation (2B, K, T) x splits_f  (bounded above)
-  const size_t tiles_b = (size_t)((F + BM - 1) / BM) * ((K + BN - 1) / BN) * 2 * B;
-  const size_t tiles_a = (size_t)((K + BM - 1) / BM) * ((T + BN - 1) / BN) * 2 * B;
+  const size_t tiles_b = (size_t)((F + BM - 1) / BM) * ((K + BN - 1) / BN) * 2;  // group = 1: the most slabs
+  const size_t tiles_a = (size_t)((K + BM - 1) / BM) * ((T + BN - 1) / BN) * 2;
   const size_t sb = pick_splits((int)tiles_b, T), sa = pick_splits((int)tiles_a, F);
   size_t pmax = sb * 2 * B * F * K;
   if (sa * 2 * B * K * T > pmax) pmax = sa * 2 * B * K * T;
   {
     int TS, tchunk, FS, fchunk;
-    mfma_basis_split(B, F, T, &TS, &tchunk);
-    mfma_act_split(B, F, T, &FS, &fchunk);
+    mfma_basis_split(1, F, T, &TS, &tchunk);
+    mfma_act_split(1, F, T, &FS, &fchunk);
     if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
     if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
   }
@@ -316,7 +320,7 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   w.lpart = off;
   {
     int FS, fchunk;
-    mfma_act_split(B, F, T, &FS, &fchunk);
+    mfma_act_split(1, F, T, &FS, &fchunk);
     size_t nl = (size_t)B * F * ((T + 255) / 256);
     if ((size_t)B * FS * ((T + 15) / 16) > nl) nl = (size_t)B * FS * ((T + 15) / 16);
     off += align_up(nl * 8, 256);
@@ -334,8 +338,8 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   int TS, tchunk, FS, fchunk;
-  mfma_basis_split(B, F, T, &TS, &tchunk);
-  mfma_act_split(B, F, T, &FS, &fchunk);
+  mfma_basis_split(nmf_group(ctx), F, T, &TS, &tchunk);
+  mfma_act_split(nmf_group(ctx), F, T, &FS, &fchunk);
   const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
   hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X, \
@@ -405,7 +409,7 @@ int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double
     g.zb_outer = (long)K * T;
     g.zb_inner = 0;
     g.Z = 2 * B;
-    const int tiles = ((F + BM - 1) / BM) * ((K + BN - 1) / BN) * g.Z;
+    const int tiles = ((F + BM - 1) / BM) * ((K + BN - 1) / BN) * 2 * nmf_group(ctx);
     g.splits = pick_splits(tiles, T);
     g.kchunk = ((T + g.splits - 1) / g.splits + BK - 1) / BK * BK;
     g.splits = (T + g.kchunk - 1) / g.kchunk;
@@ -437,7 +441,7 @@ int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double
     g.zb_outer = 2 * (long)FT;
     g.zb_inner = (long)FT;
     g.Z = 2 * B;
-    const int tiles = ((K + BM - 1) / BM) * ((T + BN - 1) / BN) * g.Z;
+    const int tiles = ((K + BM - 1) / BM) * ((T + BN - 1) / BN) * 2 * nmf_group(ctx);
     g.splits = pick_splits(tiles, F);
     g.kchunk = ((F + g.splits - 1) / g.splits + BK - 1) / BK * BK;
     g.splits = (F + g.kchunk - 1) / g.kchunk;
@@ -459,8 +463,8 @@ template <typename R, int KT>
 static int nmf_half_launch(assx_ctx* ctx, const TermSpec& ts, int half, const void* X, const void* Tb, const void* V,
                            R* part, int B, int F, int T, int K, double eps, hipStream_t st, int* slabs) {
   int TS, tchunk, FS, fchunk;
-  mfma_basis_split(B, F, T, &TS, &tchunk);
-  mfma_act_split(B, F, T, &FS, &fchunk);
+  mfma_basis_split(nmf_group(ctx), F, T, &TS, &tchunk);
+  mfma_act_split(nmf_group(ctx), F, T, &FS, &fchunk);
   if (half == NMF_HALF_BASIS) {
     hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, -1>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X,
                        (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts);
@@ -551,7 +555,7 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
   if (K <= NMF_MFMA_MAX_K && !no_mfma) {
     int FS, fchunk;
-    mfma_act_split(B, F, T, &FS, &fchunk);
+    mfma_act_split(nmf_group(ctx), F, T, &FS, &fchunk);
     const dim3 g2((T + 15) / 16, FS, B);
 #define NMF_LOSS_LAUNCH(RT, KTV)                                                                                 \
   hipLaunchKernelGGL((nmf_loss_mfma_kernel<RT, KTV>), g2, dim3(256), 0, st, (const RT*)X, (const RT*)Tb,          \

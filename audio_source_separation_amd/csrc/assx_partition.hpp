@@ -39,11 +39,12 @@ template <typename R>
 __device__ __forceinline__ void basis_records(const R* __restrict__ part, const FlatPart& fp, int N, int K, int F,
                                               int b, int f, int n, int k, R& num, R& den) {
   const long long j = (long long)b * F + f;
-  const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
+  int g_lo, g_hi;
+  flat_cover(fp, j, g_lo, g_hi);
   num = 0;
   den = 0;
   for (int g = g_lo; g <= g_hi; ++g) {
-    const int slot = (int)(j - ((long long)g * fp.L) / fp.len);
+    const int slot = flat_slot(fp, j, g);
     const R* p = part + (((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2;
     num += p[0];
     den += p[1];
@@ -127,11 +128,12 @@ __global__ void __launch_bounds__(256) part_act_kernel(const R* __restrict__ par
   const int TBk = (T + WAVE - 1) / WAVE;
   const long long j = (long long)b * TBk + t / WAVE;
   const int lane = t % WAVE;
-  const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
+  int g_lo, g_hi;
+  flat_cover(fp, j, g_lo, g_hi);
   R num = 0, den = 0;
   for (int n = 0; n < N; ++n)
     for (int g = g_lo; g <= g_hi; ++g) {
-      const int slot = (int)(j - ((long long)g * fp.L) / fp.len);
+      const int slot = flat_slot(fp, j, g);
       const R* p = part + ((((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2) * WAVE + lane;
       num += p[0];
       den += p[WAVE];

@@ -27,24 +27,55 @@ struct Dims {
   int B, F, T, K;
 };
 
+// Flat partition of a (utterance, group, item-in-group) space among workgroups.  The partition is made PER UTTERANCE
+// and replicated: an utterance's NB items are cut into Gu contiguous ranges of L items (the last one shorter), and
+// workgroup g works on range g % Gu of utterance g / Gu.  A range therefore never crosses an utterance, and -- the
+// point -- which items are summed together, and in which order, depends only on the utterance's own geometry, not
+// on how many utterances share the launch: a batched call is bit-identical to per-utterance calls, and a batch
+// sharded over ranks is bit-identical to the same batch on one rank.
 struct FlatPart {
-  long long NB;  // items in the flattened space
+  long long NB;  // items of ONE utterance
   int len;       // items per group (a group = one bin's frame blocks, or one frame block's bins)
   int L;         // items per workgroup
-  int G;         // workgroups
+  int G;         // workgroups in the launch (= B * Gu)
   int S;         // partial-record slots per workgroup
+  int Gu;        // workgroups per utterance
+  int Ju;        // groups per utterance (NB / len)
 };
 
-inline FlatPart make_flat(long long NB, int len, long long G_target) {
+inline FlatPart make_flat(int B, long long NB, int len, long long G_target) {
   FlatPart p;
   p.NB = NB;
   p.len = len;
   long long G = G_target < NB ? G_target : NB;
   if (G < 1) G = 1;
   p.L = (int)((NB + G - 1) / G);
-  p.G = (int)((NB + p.L - 1) / p.L);
+  p.Gu = (int)((NB + p.L - 1) / p.L);
+  p.G = B * p.Gu;
   p.S = (p.L + len - 2) / len + 1;
+  p.Ju = (int)(NB / len);
   return p;
+}
+
+// producer side: the GLOBAL item range [q0, q1) of workgroup g (global item = utterance * NB + item in utterance)
+__host__ __device__ __forceinline__ void flat_range(const FlatPart& fp, int g, long long& q0, long long& q1) {
+  const int b = g / fp.Gu, gl = g - b * fp.Gu;
+  const long long lo = (long long)gl * fp.L;
+  const long long hi = (lo + fp.L < fp.NB) ? lo + fp.L : fp.NB;
+  q0 = (long long)b * fp.NB + lo;
+  q1 = (long long)b * fp.NB + hi;
+}
+// consumer side: the workgroups g_lo..g_hi whose records cover GLOBAL group j (= utterance * Ju + group), and the
+// slot of that group inside workgroup g's block of records
+__host__ __device__ __forceinline__ void flat_cover(const FlatPart& fp, long long j, int& g_lo, int& g_hi) {
+  const int b = (int)(j / fp.Ju);
+  const unsigned lo = (unsigned)(j - (long long)b * fp.Ju) * (unsigned)fp.len;
+  g_lo = b * fp.Gu + (int)(lo / (unsigned)fp.L);
+  g_hi = b * fp.Gu + (int)((lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
+}
+__host__ __device__ __forceinline__ int flat_slot(const FlatPart& fp, long long j, int g) {
+  const int b = g / fp.Gu, gl = g - b * fp.Gu;
+  return (int)(j - (long long)b * fp.Ju) - (int)(((unsigned)gl * (unsigned)fp.L) / (unsigned)fp.len);
 }
 
 // (utterance, bin, frame-block) cursor advanced incrementally: a 64-bit division per block would cost more
@@ -247,8 +278,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   if (q0 >= q1) return;
   const int nblk = (int)(q1 - q0);
   const int bf_first = (int)(q0 / TBk);  // the only divisions: once per workgroup
@@ -542,10 +573,11 @@ __global__ void __launch_bounds__(256) cov_stream_finalize_kernel(const R* __res
   const int n = (idx / ((size_t)HM * F)) % N;
   const int b = idx / ((size_t)HM * F * N);
   const long long j = (long long)b * F + f;
-  const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
+  int g_lo, g_hi;
+  flat_cover(fp, j, g_lo, g_hi);
   R re = 0, im = 0;
   for (int g = g_lo; g <= g_hi; ++g) {
-    const int slot = (int)(j - ((long long)g * fp.L) / fp.len);
+    const int slot = flat_slot(fp, j, g);
     const R* p = part + (((size_t)g * fp.S + slot) * N + n) * HM;
     if (m == l) {
       re += p[m];
@@ -592,8 +624,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   if (q0 >= q1) return;
   const int nblk = (int)(q1 - q0);
   const int bf_first = (int)(q0 / TBk);  // the only divisions: once per workgroup
@@ -764,8 +796,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   if (q0 >= q1) return;
   const int nblk = (int)(q1 - q0);
   const int bf_first = (int)(q0 / TBk);
@@ -931,8 +963,7 @@ __global__ void __launch_bounds__(64, MINW)
       if (LOSS && (cc.b != cur.b || !more)) {  // leaving utterance cur.b: publish this workgroup's share of its loss
         double tot = lacc + (double)le * 0.6931471805599453 + log(lm);
         tot = wave_allreduce_sum<double>(tot);
-        const long long first_item = (long long)cur.b * F * TBk;
-        if (lane == 0) lpart[(size_t)cur.b * lstride + (g - (int)(first_item / a.fp.L))] = tot;
+        if (lane == 0) lpart[(size_t)cur.b * lstride + (g - cur.b * a.fp.Gu)] = tot;
         lacc = 0.0;
         lm = 1.0;
         le = 0;
@@ -968,10 +999,11 @@ __global__ void __launch_bounds__(256) basis_stream_finalize_kernel(const R* __r
   if (!((src_mask >> n) & 1u)) return;  // pairwise source-model update: only the selected sources move
   const int b = idx / ((size_t)K * F * N);
   const long long j = (long long)b * F + f;
-  const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
+  int g_lo, g_hi;
+  flat_cover(fp, j, g_lo, g_hi);
   R num = 0, den = 0;
   for (int g = g_lo; g <= g_hi; ++g) {
-    const int slot = (int)(j - ((long long)g * fp.L) / fp.len);
+    const int slot = flat_slot(fp, j, g);
     const R* p = part + (((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2;
     num += p[0];
     den += p[1];
@@ -995,8 +1027,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x), b = blockIdx.y;
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   double acc = 0.0;
   // sum log R is carried as log(prod R): running mantissa product + integer exponent (frexp once per block), ONE
   // log per lane at the end instead of N per frame.
@@ -1148,8 +1180,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x), b = blockIdx.y;
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   double acc = 0.0;
   double lm = 1.0, tm = 1.0;  // running mantissa products of R and of 1 + (2/nu) P/R (see loss_stream_kernel)
   int le = 0, te = 0;
@@ -1315,8 +1347,8 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int TBk = (T + WAVE - 1) / WAVE;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   if (q0 >= q1) return;
   const long long bt_first = q0 / F;
   const long long bt_last = (q1 - 1) / F;
@@ -1451,8 +1483,8 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int TBk = (T + WAVE - 1) / WAVE;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  const long long q0 = (long long)g * a.fp.L;
-  const long long q1 = (q0 + a.fp.L < a.fp.NB) ? q0 + a.fp.L : a.fp.NB;
+  long long q0, q1;
+  flat_range(a.fp, g, q0, q1);
   if (q0 >= q1) return;
   const long long bt_first = q0 / F;
   const long long bt_last = (q1 - 1) / F;
@@ -1611,11 +1643,12 @@ __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __res
   const int t = tb * WAVE + lane;
   const bool upd = (src_mask >> n) & 1u;
   const long long j = (long long)b * TBk + tb;
-  const int g_lo = (int)((j * fp.len) / fp.L), g_hi = (int)(((j + 1) * fp.len - 1) / fp.L);
+  int g_lo, g_hi;
+  flat_cover(fp, j, g_lo, g_hi);
   R num = 0, den = 0;
   if (upd) {
     for (int g = g_lo + q; g <= g_hi; g += 4) {
-      const int slot = (int)(j - ((long long)g * fp.L) / fp.len);
+      const int slot = flat_slot(fp, j, g);
       const R* p = part + ((((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2) * WAVE + lane;
       num += p[0];
       den += p[WAVE];

@@ -4,18 +4,21 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused-function"
+# ASSX_DEV=1: kernel-tuning build (M = 4, float64 instantiations of the BSS kernels only; objects kept apart in dev/)
+OBJ=.
+if [ "${ASSX_DEV:-0}" = 1 ]; then FLAGS="$FLAGS -DASSX_DEV_ONLY_M4_F64"; OBJ=dev; mkdir -p dev; fi
 pids=()
 for src in assx_api assx_bss assx_nmf assx_stft assx_generic; do
   stale=0
-  [ -f "$src.o" ] || stale=1
+  [ -f "$OBJ/$src.o" ] || stale=1
   for dep in "$src.hip" *.hpp ../../include/assx.h build.sh; do
-    [ "$dep" -nt "$src.o" ] && stale=1
+    [ "$dep" -nt "$OBJ/$src.o" ] && stale=1
   done
   if [ "$stale" = 1 ]; then
-    $HIPCC $FLAGS -c "$src.hip" -o "$src.o" &
+    $HIPCC $FLAGS -c "$src.hip" -o "$OBJ/$src.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so assx_api.o assx_bss.o assx_nmf.o assx_stft.o assx_generic.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o
 echo "built $(pwd)/libassx.so"

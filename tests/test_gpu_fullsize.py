@@ -223,10 +223,13 @@ def test_compute_demix_filter(dtype, M):
     assert isinstance(Wt, torch.Tensor) and tuple(Wt.shape) == (2, F, M, M)
     assert rel_err(Wt[0].cpu().numpy(), ref) < tol and rel_err(Wt[1].cpu().numpy(), ref[::-1]) < tol
     # an exactly singular X X^H raises like numpy.linalg.inv
-    Xs = X.copy()
-    Xs[1] = Xs[0]
-    with pytest.raises(np.linalg.LinAlgError):
-        m.compute_demix_filter(Y, Xs)
+    for make in (lambda a: a.__setitem__(1, a[0]), lambda a: a.__setitem__(M - 1, 0)):  # duplicated / silent channel
+        Xs = X.copy()
+        make(Xs)
+        with pytest.raises(np.linalg.LinAlgError):
+            orc.compute_demix_filter(Y, Xs)
+        with pytest.raises(np.linalg.LinAlgError):
+            m.compute_demix_filter(Y, Xs)
 
 
 def test_iss_callback_can_rebuild_the_filter():
