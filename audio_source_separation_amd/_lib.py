@@ -57,6 +57,8 @@ SIGNATURES = {
     "assx_tilrma_loss": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_auxiva_weights": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_auxiva_spatial_update": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_idlma_space_update": (_i, [_vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_fastmnmf_update_diagonalizer": (_i, [_vp, _vp, _vp, _vp, _vp, _d, _d, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back_scale": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_projection_back": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_compute_demix_filter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -1185,6 +1185,30 @@ __global__ void __launch_bounds__(64) tilrma_xi_wide_kernel(const Cx<R>* __restr
   }
 }
 
+// (f4) weights of the other callers of the covariance + IP kernels.
+// GaussIDLMA.update_space_model (sss/idlma.py:182): R = dnn_output ** (2 / domain), elementwise (B,N,F,T).
+template <typename R>
+__global__ void __launch_bounds__(256) pow_map_kernel(const R* __restrict__ in, R* __restrict__ out, size_t n, PowSpec p) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = powspec<R>(in[i], p);
+}
+// FastMultichannelISNMF.update_diagonalizer (bss/mnmf.py:868): R[f,t,m] = sum_n Lambda[n,f,t] g[n,f,m], laid out
+// (B,M,F,T) so that channel m's variances are one weight set of the covariance kernel.  Sources are added in
+// ascending order, as numpy.sum(axis=0) does.
+template <typename R>
+__global__ void __launch_bounds__(256) mix_variance_kernel(const R* __restrict__ Lambda, const R* __restrict__ g,
+                                                          R* __restrict__ out, int M, int N, int F, int T) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, f = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const size_t FT = (size_t)F * T;
+  for (int m = 0; m < M; ++m) {
+    R acc = 0;
+    for (int n = 0; n < N; ++n)
+      acc += Lambda[((size_t)b * N + n) * FT + (size_t)f * T + t] * g[(((size_t)b * N + n) * F + f) * M + m];
+    out[((size_t)b * M + m) * FT + (size_t)f * T + t] = acc;
+  }
+}
+
 struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte aligned
   size_t part;     // reduction partials (largest user: activation update)
   size_t u;        // dense U (B,N,F,M,M) complex
@@ -2188,6 +2212,54 @@ int assx_tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void
     if (rc) return rc;
     // inverse without a condition-number guard (ilrma.py:968-976); the normaliser is floored at eps
     return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, C, power_bins, INFINITY, status, B, F, st, eps);
+  });
+}
+
+// ---- (f4) other callers of covariance-accumulate + IP ------------------------------------------------------------
+int assx_idlma_space_update(assx_ctx* ctx, const void* X, void* W, const void* dnn_output, double domain, double eps,
+                            double threshold, void* R_scratch, int32_t* status, void* ws, int B, int M, int F, int T,
+                            int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && dnn_output && ws, ASSX_E_NULL, "assx_idlma_space_update: NULL array");
+  ASSX_REQUIRE(ctx, domain > 0.0, ASSX_E_ARG, "domain must be > 0, got %g", domain);
+  ASSX_REQUIRE(ctx, domain == 2.0 || R_scratch, ASSX_E_NULL, "assx_idlma_space_update: R_scratch is needed for domain != 2");
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const void* r = dnn_output;
+    if (domain != 2.0) {
+      const size_t n = (size_t)B * MM * F * T;
+      hipLaunchKernelGGL((pow_map_kernel<R>), dim3(blocks_for(n, 256)), dim3(256), 0, st, (const R*)dnn_output,
+                         (R*)R_scratch, n, make_pow(2.0 / domain));
+      ASSX_LAUNCH_CHECK(ctx, "pow_map_kernel");
+      r = R_scratch;
+    }
+    FlatPart fp;
+    int rc = run_cov_partial<R, MM>(ctx, WK_NFT, X, r, nullptr, nullptr, 1, 2.0, eps, ws, B, F, T, st, &fp);
+    if (rc) return rc;
+    return run_ip<R, MM>(ctx, nullptr, ws, fp, T, W, nullptr, nullptr, threshold, status, B, F, st);
+  });
+}
+
+int assx_fastmnmf_update_diagonalizer(assx_ctx* ctx, const void* X, void* Q, const void* Lambda, const void* g,
+                                      double eps, double threshold, void* R_scratch, int32_t* status, void* ws, int B,
+                                      int M, int N, int F, int T, int dtype, void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && Q && Lambda && g && R_scratch && ws, ASSX_E_NULL, "assx_fastmnmf_update_diagonalizer: NULL array");
+  ASSX_REQUIRE(ctx, N >= 1, ASSX_E_ARG, "n_sources must be >= 1, got %d", N);
+  hipStream_t st = (hipStream_t)stream;
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    hipLaunchKernelGGL((mix_variance_kernel<R>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st, (const R*)Lambda,
+                       (const R*)g, (R*)R_scratch, MM, N, F, T);
+    ASSX_LAUNCH_CHECK(ctx, "mix_variance_kernel");
+    FlatPart fp;
+    int rc = run_cov_partial<R, MM>(ctx, WK_NFT, X, R_scratch, nullptr, nullptr, 1, 2.0, eps, ws, B, F, T, st, &fp);
+    if (rc) return rc;
+    // condition-number guard AND the eps floor on the normaliser (mnmf.py:876-884)
+    return run_ip<R, MM>(ctx, nullptr, ws, fp, T, Q, nullptr, nullptr, threshold, status, B, F, st, eps);
   });
 }
 

@@ -285,6 +285,29 @@ class Engine:
                                                  ptr(U_out), ptr(status), ptr(ws), B, M, F, T, self.prec.code,
                                                  self._st()), "assx_auxiva_spatial_update")
 
+    # ------------------------------------------------------------------ other callers of cov + IP (row f4)
+    def idlma_space_update(self, X, W, dnn_output, domain=2, eps=1e-12, threshold=1e12, status=None):
+        """GaussIDLMA.update_space_model: W (B,F,N,M) in place from the source variances dnn_output (B,N,F,T)."""
+        B, M, F, T = self._dims(X)
+        ws = self._scratch(B, M, F, T, 1)
+        scratch = None if float(domain) == 2.0 else self.empty((B, M, F, T))
+        self._check(self._L.assx_idlma_space_update(self.ctx, ptr(X), ptr(W), ptr(dnn_output), float(domain), float(eps),
+                                                    float(threshold), ptr(scratch), ptr(status), ptr(ws), B, M, F, T,
+                                                    self.prec.code, self._st()), "assx_idlma_space_update")
+        return W
+
+    def fastmnmf_update_diagonalizer(self, X, Q, Lambda, g, eps=1e-12, threshold=1e12, status=None):
+        """FastMultichannelISNMF.update_diagonalizer: Q (B,F,M,M) in place; Lambda (B,N,F,T), g (B,N,F,M)."""
+        B, M, F, T = self._dims(X)
+        N = int(Lambda.shape[1])
+        ws = self._scratch(B, M, F, T, 1)
+        scratch = self.empty((B, M, F, T))
+        self._check(self._L.assx_fastmnmf_update_diagonalizer(self.ctx, ptr(X), ptr(Q), ptr(Lambda), ptr(g), float(eps),
+                                                              float(threshold), ptr(scratch), ptr(status), ptr(ws), B, M,
+                                                              N, F, T, self.prec.code, self._st()),
+                    "assx_fastmnmf_update_diagonalizer")
+        return Q
+
     # ------------------------------------------------------------------ projection back
     def projection_back_scale(self, X, W, ref=0, status=None):
         B, M, F, T = self._dims(X)

@@ -231,6 +231,23 @@ int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_
                                void* U_out, int32_t* status, void* ws,
                                int B, int M, int F, int T, int dtype, void* stream);
 
+/* ---- (f4) the other callers of covariance-accumulate + IP --------------------------------------------------- */
+/* GaussIDLMA.update_space_model (src/sss/idlma.py:175-210): R = dnn_output^(2/domain) floored at eps, U_n = mean_t
+ * x x^H / R_n, then the IP sweep of assx_ip_update on W.  dnn_output (B,N,F,T) real is the caller's source-variance
+ * estimate (in the reference: a DNN's output; the network itself is out of scope).  R_scratch: caller-owned
+ * (B,N,F,T) reals, used only when domain != 2 (may be NULL otherwise). */
+int assx_idlma_space_update(assx_ctx* ctx, const void* X, void* W, const void* dnn_output, double domain, double eps,
+                            double threshold, void* R_scratch, int32_t* status, void* ws,
+                            int B, int M, int F, int T, int dtype, void* stream);
+/* FastMultichannelISNMF.update_diagonalizer (src/bss/mnmf.py:848-888): R[f,t,m] = sum_n Lambda[n,f,t] g[n,f,m]
+ * floored at eps, V_m = mean_t x x^H / R[.,.,m], then for every channel m: q = (Q V_m)^{-1} e_m,
+ * Q[m,:] = conj(q) / max(sqrt(q^H V_m q), eps) unless cond_2(Q V_m) >= threshold.  Q (B,F,M,M) complex in place;
+ * Lambda (B,N,F,T) real = the sources' NMF variances (basis @ activation); g (B,N,F,M) real = spatial_covariance;
+ * N = n_sources is free (it need not equal M).  R_scratch: caller-owned (B,M,F,T) reals. */
+int assx_fastmnmf_update_diagonalizer(assx_ctx* ctx, const void* X, void* Q, const void* Lambda, const void* g,
+                                      double eps, double threshold, void* R_scratch, int32_t* status, void* ws,
+                                      int B, int M, int N, int F, int T, int dtype, void* stream);
+
 /* ---- (a8) projection back --------------------------------------------------------------- */
 /* projection_back(Y, reference) for a 2-D reference (src/algorithm/projection_back.py:13-21) with
  * Y = W X formed on the fly and reference = X[ref]:  scale[b,n,f] = (x_ref Y^H (Y Y^H)^{-1})[n]. */

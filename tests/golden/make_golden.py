@@ -571,6 +571,49 @@ def gen_stft():
     save("stft", cases=np.array([(L, N, hop, wf == "hamming") for L, N, hop, wf in cases]), **out)
 
 
+def gen_f4():
+    """Other callers of the covariance + IP kernels: the reference's own methods on seeded state."""
+    from sss.idlma import GaussIDLMA
+    from bss.mnmf import FastMultichannelISNMF
+    F, T = 17, 96
+    for M, domain in ((2, 2), (3, 1), (4, 2), (4, 1.5)):
+        rng = np.random.default_rng(900 + M)
+        X = convolutive_mixture(M, F, T, 901 + M)
+        W0 = np.eye(M)[None] + 0.3 * (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M)))
+        dnn = rng.random((M, F, T)) ** 2 + 1e-3
+        dnn[0, 3, :5] = 0.0  # hits the eps floor (idlma.py:189)
+        m = object.__new__(GaussIDLMA)
+        m.input, m.demix_filter, m.dnn_output = X, W0.copy(), dnn.copy()
+        m.domain, m.eps, m.threshold = domain, 1e-12, 1e12
+        m.n_sources = m.n_channels = M
+        m.n_bins, m.n_frames = F, T
+        m.update_space_model()
+        save("f4_idlma_m%d_d%s" % (M, str(domain).replace(".", "")), X=X, W0=W0, dnn_output=dnn, domain=float(domain),
+             W1=m.demix_filter)
+    for M, N, K, part in ((2, 2, 3, False), (3, 2, 4, False), (4, 3, 3, False), (4, 5, 2, True)):
+        rng = np.random.default_rng(950 + M + N)
+        X = convolutive_mixture(M, F, T, 951 + M)
+        Q0 = np.eye(M)[None] + 0.3 * (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M)))
+        g = rng.random((N, F, M)) + 1e-2
+        m = object.__new__(FastMultichannelISNMF)
+        m.input, m.diagonalizer, m.spatial_covariance = X, Q0.copy(), g.copy()
+        m.partitioning = part
+        if part:
+            Z = rng.random((N, K))
+            m.latent = Z / Z.sum(axis=0)
+            m.basis, m.activation = rng.random((F, K)), rng.random((K, T))
+            Lam = (m.latent[:, None, :] * m.basis[None]) @ m.activation[None]
+        else:
+            m.basis, m.activation = rng.random((N, F, K)), rng.random((N, K, T))
+            Lam = m.basis @ m.activation
+        m.eps, m.threshold = 1e-12, 1e12
+        m.n_bins, m.n_channels, m.n_sources = F, M, N
+        m.update_diagonalizer()
+        extra = dict(latent=m.latent) if part else {}
+        save("f4_fastmnmf_m%d_n%d%s" % (M, N, "_part" if part else ""), X=X, Q0=Q0, g=g, basis=m.basis,
+             activation=m.activation, variance=Lam, partitioning=part, Q1=m.diagonalizer, **extra)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
         for name in sys.argv[1:]:
@@ -591,3 +634,4 @@ if __name__ == "__main__":
     gen_tilrma_k10()
     gen_consistent()
     gen_part_k10()
+    gen_f4()

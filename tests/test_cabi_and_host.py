@@ -189,3 +189,21 @@ def test_bench_gpus_flag_is_honoured_or_refused():
     r = subprocess.run([sys.executable, bench, "--gpus", str(want)], env=env, capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 2 and "refusing" in r.stderr
+
+
+def test_wav_io_round_trip(tmp_path):
+    """read_wav / write_wav (utils_audio.py:4-18): 16-bit PCM, 2**15 scaling, clipping, channel_last handling."""
+    from audio_source_separation_amd.utils.utils_audio import read_wav, write_wav
+    rng = np.random.default_rng(0)
+    x = np.clip(0.3 * rng.standard_normal((2, 800)), -1.5, 1.5)  # (n_channels, n_samples), some samples clip
+    path = str(tmp_path / "mix.wav")
+    write_wav(path, x, 16000, channel_last=False)
+    y, sr = read_wav(path)
+    assert sr == 16000 and y.shape == (800, 2) and y.dtype == np.float64
+    expect = np.clip(x * 32768, -32768, 32767).astype(np.int16).T / 32768
+    assert np.array_equal(y, expect)
+    write_wav(path, y[:, 0], sr)
+    y1, _ = read_wav(path)
+    assert np.array_equal(y1, y[:, 0])
+    with pytest.raises(ValueError):
+        write_wav(path, np.zeros((2, 2, 2)), sr)

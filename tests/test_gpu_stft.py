@@ -107,3 +107,29 @@ def test_wav_to_wav(dtype):
     y = istft(Y, fft_size=512, hop_size=128, length=L, dtype=dtype)
     assert y.shape == (2, L) and np.isfinite(y).all()
     assert rel_err(y, orc.istft(Y, 512, 128, length=L)) < tol(dtype, 1e-12, 2e-5)
+
+
+def test_wav_file_to_wav_file(dtype, tmp_path):
+    """The whole chain through FILES: write_wav -> read_wav -> stft -> GaussILRMA -> istft -> write_wav -> read_wav
+    (ref: utils_audio.py:4-18 either side of ilrma.py:1289-1299), device tensors between the two file ends."""
+    import torch
+    from audio_source_separation_amd.transform import stft, istft
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    from audio_source_separation_amd.utils.utils_audio import read_wav, write_wav
+    rng = np.random.default_rng(12)
+    L, sr = 8000, 16000
+    s = 0.2 * rng.standard_normal((2, L)) * (1.0 + 0.9 * np.sin(np.arange(L) / 300.0 + np.array([[0.0], [1.5]])))
+    x = np.array([[1.0, 0.6], [0.5, 1.0]]) @ s
+    src, dst = str(tmp_path / "mix.wav"), str(tmp_path / "sep.wav")
+    write_wav(src, x, sr, channel_last=False)
+    mix, sr2 = read_wav(src)                       # (L, 2)
+    X = stft(torch.from_numpy(mix.T.copy()).cuda(), fft_size=256, hop_size=64, dtype=dtype)
+    np.random.seed(5)
+    Y = GaussILRMA(n_basis=2, dtype=dtype)(X, iteration=10)
+    y = istft(Y, fft_size=256, hop_size=64, length=L, dtype=dtype)
+    assert isinstance(y, torch.Tensor) and tuple(y.shape) == (2, L)
+    write_wav(dst, y, sr2, channel_last=False)
+    out, sr3 = read_wav(dst)
+    assert sr3 == sr and out.shape == (L, 2) and np.isfinite(out).all()
+    q = np.clip(y.cpu().numpy().astype(np.float64) * 32768, -32768, 32767).astype(np.int16).T / 32768
+    assert np.array_equal(out, q)

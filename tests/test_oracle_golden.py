@@ -353,3 +353,21 @@ def test_reference_form_covariance_equals_streaming_form():
         assert rel_err(x, y) < 1e-12
     # the reference's own U (formed by ilrma.py:503-511 inside update_spatial_model_ip) from its T1, V1
     assert rel_err(orc.weighted_covariance_reference_form(g["X"], orc.ilrma_variance(g["T1"], g["V1"])), g["U"]) < 1e-13
+
+
+F4_IDLMA = ["f4_idlma_m2_d2", "f4_idlma_m3_d1", "f4_idlma_m4_d2", "f4_idlma_m4_d15"]
+F4_FASTMNMF = ["f4_fastmnmf_m2_n2", "f4_fastmnmf_m3_n2", "f4_fastmnmf_m4_n3", "f4_fastmnmf_m4_n5_part"]
+
+
+@pytest.mark.parametrize("name", F4_IDLMA)
+def test_f4_idlma_update_space_model(name):
+    g = load_golden(name)
+    W1 = orc.idlma_update_space_model(g["X"], g["W0"], g["dnn_output"], float(g["domain"]))
+    assert rel_err(W1, g["W1"]) < 1e-11
+
+
+@pytest.mark.parametrize("name", F4_FASTMNMF)
+def test_f4_fastmnmf_update_diagonalizer(name):
+    g = load_golden(name)
+    Q1 = orc.fastmnmf_update_diagonalizer(g["X"], g["Q0"], g["g"], g["variance"])
+    assert rel_err(Q1, g["Q1"]) < 1e-11
