@@ -17,9 +17,11 @@
 #include "assx_common.hpp"
 #include "assx_small_linalg.hpp"
 #include "assx_stream.hpp"
+#include "assx_group_linalg.hpp"
 #include "assx_partition.hpp"
 #include "assx_cov_wide.hpp"
 #include "assx_nmf_internal.hpp"
+#include "assx_widem.hpp"
 
 using namespace assx;
 
@@ -223,452 +225,6 @@ __global__ void __launch_bounds__(64) ilrma_loss_wide_kernel(const Cx<R>* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// (a5) IP sweep.  A group of GW = next_pow2(M*M) lanes owns one bin (b, f): lane (i, j) holds element (i, j) of
-//      W and of the working matrix, rows/columns travel by in-group shuffles.  Gauss-Seidel over the sources
-//      (sequential), Gauss-Jordan with partial pivoting inside, all in float64.  The 1025 bins of one utterance
-//      become 257 waves spread over the chip instead of 17 latency-bound single-lane waves (30 us -> a few us).
-//      FROM_PART: the covariance arrives as the streaming kernel's partial records (cov_stream_kernel) and is
-//      reduced here (saves the separate finalize launch); otherwise as dense U (B,N,F,M,M).
-//      Optionally emits pw[b][n][f] = w_n^H C_f w_n (the per-bin share of the power normalisation statistic).
-// ------------------------------------------------------------------------------------------
-template <int GW>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-  for (int off = GW / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, GW);
-  return v;
-}
-template <int GW>
-__device__ __forceinline__ Cd group_shfl(Cd v, int src) {
-  return cmake<double>(__shfl(v.x, src, GW), __shfl(v.y, src, GW));
-}
-
-// In-group Gauss-Jordan inverse with partial pivoting (LAPACK's pivot rule: first max of |re|+|im|) of the M x M
-// matrix whose element (i, j) lives in lane (i, j) of a GW-lane group.  Returns this lane's element of the inverse.
-template <int M, int GW>
-__device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singular) {
-  int piv[M];
-#pragma unroll
-  for (int c = 0; c < M; ++c) {
-    int p = c;
-    double best = -1.0;
-#pragma unroll
-    for (int r = c; r < M; ++r) {
-      const double m1 = cabs1(group_shfl<GW>(a, r * M + c));
-      if (m1 > best) {
-        best = m1;
-        p = r;
-      }
-    }
-    if (!(best > 0.0)) singular = true;
-    piv[c] = p;
-    const int src_i = (i == c) ? p : ((i == p) ? c : i);
-    a = group_shfl<GW>(a, src_i * M + j);  // row interchange c <-> p
-    const Cd pv = group_shfl<GW>(a, c * M + c);
-    const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
-    const Cd acj = group_shfl<GW>(a, c * M + j);
-    const Cd rcj = cmul((j == c) ? cmake<double>(1.0, 0.0) : acj, ipv);
-    const Cd fic = group_shfl<GW>(a, i * M + c);
-    if (i == c) {
-      a = rcj;
-    } else {
-      const Cd base = (j == c) ? cmake<double>(0.0, 0.0) : a;
-      a = cmake<double>(base.x - (fic.x * rcj.x - fic.y * rcj.y), base.y - (fic.x * rcj.y + fic.y * rcj.x));
-    }
-  }
-#pragma unroll
-  for (int c = M - 1; c >= 0; --c) {  // undo the row interchanges as column interchanges
-    const int p = piv[c];
-    const int src_j = (j == c) ? p : ((j == p) ? c : j);
-    a = group_shfl<GW>(a, i * M + src_j);
-  }
-  return a;
-}
-
-// cond_2(A) < thr from A (a0) and its inverse (ainv), element (i, j) per lane: Frobenius bounds, exact spectral
-// norms only inside the factor-M band (every lane gathers both matrices; rare).
-template <int M, int GW>
-__device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bool singular, double thr) {
-  constexpr int MM = M * M;
-  const double nA2 = group_sum<GW>(active ? cabs2(a0) : 0.0);
-  const double nI2 = group_sum<GW>(active ? cabs2(ainv) : 0.0);
-  const double condF = sqrt(nA2) * sqrt(nI2);
-  const bool amb = !singular && (condF == condF) && condF >= thr && condF < thr * (double)M;
-  bool ok = !singular && (condF == condF) && condF < thr;
-  if (__any(amb)) {
-    Cd ma[MM], mi[MM];
-#pragma unroll
-    for (int q = 0; q < MM; ++q) {
-      ma[q] = group_shfl<GW>(a0, q);
-      mi[q] = group_shfl<GW>(ainv, q);
-    }
-    if (amb) ok = spectral_norm_slow(ma, M) * spectral_norm_slow(mi, M) < thr;
-  }
-  return ok;
-}
-
-template <typename R, int M, bool FROM_PART>
-__global__ void __launch_bounds__(64)
-    ip_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
-                    Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
-                    int32_t* __restrict__ status, int B, int F, double den_floor) {
-  constexpr int N = M;
-  constexpr int MM = M * M;
-  constexpr int GW = next_pow2_c(MM);
-  constexpr int GPW = WAVE / GW;  // groups per wave
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int e = lane & (GW - 1);
-  const long long grp = (long long)blockIdx.x * GPW + lane / GW;
-  const bool in_range = grp < (long long)B * F;
-  const long long bf = in_range ? grp : (long long)B * F - 1;  // out-of-range groups shadow the last bin, store nothing
-  const bool active = e < MM;
-  const int i = active ? e / M : 0, j = active ? e % M : 0;
-  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
-
-  Cd w;
-  {
-    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
-    w = cmake<double>((double)v.x, (double)v.y);
-  }
-  int flags = 0;
-  // partial records covering this bin (FROM_PART): computed once, 32-bit arithmetic (NB < 2^31 is checked on the host)
-  int g_lo = 0, g_hi = -1, base = 0;
-  if (FROM_PART) {
-    flat_cover(fp, bf, g_lo, g_hi);
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
-  }
-
-  // ---- this lane's element of every U_n, fetched up front: the loads of the N sources are independent, the sweep
-  //      below is a serial chain -- inside the loop each source would pay its own round trip to L2 / HBM (with 8
-  //      utterances per launch the records no longer fit the L2: 51 us per utterance instead of 21)
-  Cd uall[N];
-  if (FROM_PART) {
-#pragma unroll
-    for (int n = 0; n < N; ++n) uall[n] = cmake<double>(0.0, 0.0);
-    for (int g = g_lo; g <= g_hi; ++g) {
-      const int slot = flat_slot(fp, bf, g);
-      const R* p = part + ((size_t)g * fp.S + slot) * N * MM;
-#pragma unroll
-      for (int n = 0; n < N; ++n) {
-        uall[n].x += (double)p[n * MM + base];
-        if (i != j) uall[n].y += (double)p[n * MM + base + 1];
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      if (i > j) uall[n].y = -uall[n].y;
-      uall[n] = cmake<double>(uall[n].x * inv_T, uall[n].y * inv_T);
-    }
-  } else {
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const Cx<R> v = U[(((size_t)b * N + n) * F + f) * MM + i * M + j];
-      uall[n] = cmake<double>((double)v.x, (double)v.y);
-    }
-  }
-
-#pragma unroll 1
-  for (int n = 0; n < N; ++n) {
-    Cd u = uall[0];
-#pragma unroll
-    for (int q = 1; q < N; ++q)
-      if (q == n) u = uall[q];
-    // ---- A = W @ U_n
-    Cd a = cmake<double>(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < M; ++k) cfma(a, group_shfl<GW>(w, i * M + k), group_shfl<GW>(u, k * M + j));
-    const Cd a0 = a;
-    bool singular = false;
-    a = group_gj_inverse<M, GW>(a, i, j, singular);
-    // ---- cond_2(WU) < threshold ?
-    const bool ok = group_cond_below<M, GW>(a0, a, active, singular, thr);
-    if (singular) flags |= ASSX_STATUS_SINGULAR;       // numpy.linalg.solve raises here
-    else if (!ok) flags |= ASSX_STATUS_COND_REJECT;    // keep the old row (np.where(condition, ..., w_n_Hermite))
-    // ---- w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
-    const Cd wi = group_shfl<GW>(a, i * M + n);
-    const Cd wj = group_shfl<GW>(a, j * M + n);
-    Cd term = cmul(cmul(cconj(wi), u), wj);
-    if (!active) term = cmake<double>(0.0, 0.0);
-    const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
-    Cd den = csqrt_principal(q);
-    if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
-    if (ok && !singular && i == n) w = cdiv(cconj(wj), den);
-  }
-
-  if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
-  if (pw) {  // per-bin share of mean|y_n|^2 = mean_f w_n^H C_f w_n
-    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
-    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const Cd wni = group_shfl<GW>(w, n * M + i);
-      const Cd wnj = group_shfl<GW>(w, n * M + j);
-      const Cd t1 = cmul(wni, c);
-      double term = t1.x * wnj.x + t1.y * wnj.y;  // Re(W[n,i] C[i,j] conj(W[n,j]))
-      if (!active) term = 0.0;
-      const double sum = group_sum<GW>(term);
-      if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
-    }
-  }
-  if (flags && status && in_range && e == 0) atomicOr(&status[b], flags);
-}
-
-// ------------------------------------------------------------------------------------------
-// (f1) ISS sweep (ilrma.py:537-564, iva.py:525-542, 758-775).  The reference applies the rank-1 updates to
-//      Y (N passes that read and rewrite Y).  Y = W X stays linear in W, so the statistics are quadratic forms of
-//      the SAME weighted covariances the IP path uses:
-//          sum_t y_s conj(y_n) / r_s = T w_s U_s w_n^H ,   sum_t |y_n|^2 / r_s = T w_n U_s w_n^H
-//      (sums, not means: the reference omits the 1/T of the paper) and the update is W[s,:] -= v_s W[n,:].
-//      One pass over X (cov_stream_kernel) + this per-bin kernel, same lane-group layout as ip_group_kernel.
-// ------------------------------------------------------------------------------------------
-template <typename R, int M, bool FROM_PART>
-__global__ void __launch_bounds__(64)
-    iss_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
-                     double n_frames, Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw,
-                     int B, int F) {
-  constexpr int N = M;
-  constexpr int MM = M * M;
-  constexpr int GW = next_pow2_c(MM);
-  constexpr int GPW = WAVE / GW;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int e = lane & (GW - 1);
-  const long long grp = (long long)blockIdx.x * GPW + lane / GW;
-  const bool in_range = grp < (long long)B * F;
-  const long long bf = in_range ? grp : (long long)B * F - 1;
-  const bool active = e < MM;
-  const int i = active ? e / M : 0, j = active ? e % M : 0;
-  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
-
-  Cd w;
-  {
-    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
-    w = cmake<double>((double)v.x, (double)v.y);
-  }
-  // this lane's element (i, j) of every source's covariance (the weights are fixed during the sweep)
-  Cd u[N];
-  if (FROM_PART) {
-    int g_lo, g_hi;
-    flat_cover(fp, bf, g_lo, g_hi);
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
-    const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-      double re = 0.0, im = 0.0;
-      for (int g = g_lo; g <= g_hi; ++g) {
-        const int slot = flat_slot(fp, bf, g);
-        const R* p = part + (((size_t)g * fp.S + slot) * N + s) * MM;
-        re += (double)p[base];
-        if (i != j) im += (double)p[base + 1];
-      }
-      if (i > j) im = -im;
-      u[s] = cmake<double>(re * inv_T, im * inv_T);
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-      const Cx<R> v = U[(((size_t)b * N + s) * F + f) * MM + i * M + j];
-      u[s] = cmake<double>((double)v.x, (double)v.y);
-    }
-  }
-
-#pragma unroll 1
-  for (int n = 0; n < N; ++n) {
-    const Cd wn_i = group_shfl<GW>(w, n * M + i);
-    const Cd wn_jc = cconj(group_shfl<GW>(w, n * M + j));
-    Cd vmine = cmake<double>(0.0, 0.0);  // v_s for this lane's row s = i
-#pragma unroll
-    for (int s = 0; s < N; ++s) {
-      const Cd ws_i = group_shfl<GW>(w, s * M + i);
-      const Cd uw = cmul(u[s], wn_jc);          // U_s[i][j] conj(W[n][j])
-      Cd tq = cmul(ws_i, uw);                   // W[s][i] U_s[i][j] conj(W[n][j])
-      Cd td = cmul(wn_i, uw);                   // W[n][i] U_s[i][j] conj(W[n][j])
-      if (!active) {
-        tq = cmake<double>(0.0, 0.0);
-        td = tq;
-      }
-      const Cd q = cmake<double>(group_sum<GW>(tq.x), group_sum<GW>(tq.y));
-      const double d = group_sum<GW>(td.x);     // Hermitian form: real
-      Cd v;
-      if (s == n) v = cmake<double>(1.0 - 1.0 / sqrt(n_frames * d), 0.0);
-      else v = cmake<double>(q.x / d, q.y / d);
-      if (i == s) vmine = v;
-    }
-    const Cd wn_j = cconj(wn_jc);
-    const Cd dlt = cmul(vmine, wn_j);           // all rows use the OLD row n (Y - V_n Y[n] is evaluated at once)
-    w = cmake<double>(w.x - dlt.x, w.y - dlt.y);
-  }
-
-  if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
-  if (pw) {
-    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
-    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const Cd wni = group_shfl<GW>(w, n * M + i);
-      const Cd wnj = group_shfl<GW>(w, n * M + j);
-      const Cd t1 = cmul(wni, c);
-      double term = t1.x * wnj.x + t1.y * wnj.y;
-      if (!active) term = 0.0;
-      const double sum = group_sum<GW>(term);
-      if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// (f1) IP2 / pairwise update of rows (pm, pn) (ilrma.py:566-633, iva.py:544-599).  Same lane-group layout.
-//      P_x = (W U_x)^{-1} [e_pm e_pn];  V_x = P_x^H U_x P_x (2x2);  eig(V_pn^{-1} V_pm), eigenvectors sorted by
-//      descending eigenvalue with LAPACK zgeev's convention (unit 2-norm, largest component real) so that W, not
-//      only |W|, matches the reference;  w_x = conj(P_x v_x / sqrt(v_x^H V_x v_x)).  Both rows use the OLD W.
-// ------------------------------------------------------------------------------------------
-template <typename R, int M, bool FROM_PART>
-__global__ void __launch_bounds__(64)
-    ip2_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
-                     Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
-                     int32_t* __restrict__ status, int B, int F, int pm, int pn) {
-  constexpr int N = M;
-  constexpr int MM = M * M;
-  constexpr int GW = next_pow2_c(MM);
-  constexpr int GPW = WAVE / GW;
-  const int lane = threadIdx.x & (WAVE - 1);
-  const int e = lane & (GW - 1);
-  const long long grp = (long long)blockIdx.x * GPW + lane / GW;
-  const bool in_range = grp < (long long)B * F;
-  const long long bf = in_range ? grp : (long long)B * F - 1;
-  const bool active = e < MM;
-  const int i = active ? e / M : 0, j = active ? e % M : 0;
-  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
-
-  Cd w;
-  {
-    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
-    w = cmake<double>((double)v.x, (double)v.y);
-  }
-  auto load_u = [&](int src) -> Cd {
-    if (FROM_PART) {
-      int g_lo, g_hi;
-      flat_cover(fp, bf, g_lo, g_hi);
-      const int lo = i < j ? i : j, hi = i < j ? j : i;
-      const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
-      double re = 0.0, im = 0.0;
-      for (int g = g_lo; g <= g_hi; ++g) {
-        const int slot = flat_slot(fp, bf, g);
-        const R* p = part + (((size_t)g * fp.S + slot) * N + src) * MM;
-        re += (double)p[base];
-        if (i != j) im += (double)p[base + 1];
-      }
-      if (i > j) im = -im;
-      return cmake<double>(re * inv_T, im * inv_T);
-    }
-    const Cx<R> v = U[(((size_t)b * N + src) * F + f) * MM + i * M + j];
-    return cmake<double>((double)v.x, (double)v.y);
-  };
-  int flags = 0;
-  const int col[2] = {pm, pn};
-  Cd ux[2], inv[2];
-  bool okx[2];
-  Cd V[2][2][2];  // V[x][a][b], x = 0 -> source pm, 1 -> source pn
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {
-    ux[x] = load_u(col[x]);
-    Cd a = cmake<double>(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < M; ++k) cfma(a, group_shfl<GW>(w, i * M + k), group_shfl<GW>(ux[x], k * M + j));
-    const Cd a0 = a;
-    bool singular = false;
-    a = group_gj_inverse<M, GW>(a, i, j, singular);
-    okx[x] = group_cond_below<M, GW>(a0, a, active, singular, thr);
-    if (singular) flags |= ASSX_STATUS_SINGULAR;  // numpy.linalg.inv raises
-    else if (!okx[x]) flags |= ASSX_STATUS_COND_REJECT;
-    inv[x] = a;
-#pragma unroll
-    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) {
-        const Cd pia = group_shfl<GW>(a, i * M + col[aa]);
-        const Cd pjb = group_shfl<GW>(a, j * M + col[bb]);
-        Cd term = cmul(cmul(cconj(pia), ux[x]), pjb);
-        if (!active) term = cmake<double>(0.0, 0.0);
-        V[x][aa][bb] = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
-      }
-  }
-  // VV = V_pn^{-1} V_pm  (2x2)
-  const Cd detn = csub(cmul(V[1][0][0], V[1][1][1]), cmul(V[1][0][1], V[1][1][0]));
-  if (detn.x == 0.0 && detn.y == 0.0) flags |= ASSX_STATUS_SINGULAR;
-  const Cd idet = cdiv(cmake<double>(1.0, 0.0), detn);
-  const Cd ni[2][2] = {{cmul(V[1][1][1], idet), cmul(cmake<double>(-V[1][0][1].x, -V[1][0][1].y), idet)},
-                       {cmul(cmake<double>(-V[1][1][0].x, -V[1][1][0].y), idet), cmul(V[1][0][0], idet)}};
-  Cd VV[2][2];
-#pragma unroll
-  for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-    for (int bb = 0; bb < 2; ++bb) VV[aa][bb] = cadd(cmul(ni[aa][0], V[0][0][bb]), cmul(ni[aa][1], V[0][1][bb]));
-  // eigenvalues of the 2x2
-  const Cd htr = cscale(cadd(VV[0][0], VV[1][1]), 0.5);
-  const Cd det = csub(cmul(VV[0][0], VV[1][1]), cmul(VV[0][1], VV[1][0]));
-  const Cd disc = csqrt_principal(csub(cmul(htr, htr), det));
-  Cd lam[2] = {cadd(htr, disc), csub(htr, disc)};
-  // numpy argsort of complex = lexicographic (real, imag); order[::-1] -> largest first
-  const bool first_big = (lam[0].x > lam[1].x) || (lam[0].x == lam[1].x && lam[0].y >= lam[1].y);
-  if (!first_big) {
-    const Cd t = lam[0];
-    lam[0] = lam[1];
-    lam[1] = t;
-  }
-  Cd wrow[2];  // this lane's new W[pm][j] / W[pn][j]
-#pragma unroll
-  for (int x = 0; x < 2; ++x) {  // x = 0: eigenvector of the larger eigenvalue -> row pm; x = 1 -> row pn
-    // eigenvector of VV for lam[x]: the better conditioned of [b, lam - a] and [lam - d, c]
-    const Cd c1[2] = {VV[0][1], csub(lam[x], VV[0][0])};
-    const Cd c2[2] = {csub(lam[x], VV[1][1]), VV[1][0]};
-    const double n1 = cabs2(c1[0]) + cabs2(c1[1]), n2 = cabs2(c2[0]) + cabs2(c2[1]);
-    Cd v[2] = {n1 >= n2 ? c1[0] : c2[0], n1 >= n2 ? c1[1] : c2[1]};
-    const double nrm = sqrt(n1 >= n2 ? n1 : n2);
-    v[0] = cscale(v[0], 1.0 / nrm);
-    v[1] = cscale(v[1], 1.0 / nrm);
-    // zgeev: rotate so that the component of largest modulus is real (first one on ties)
-    const int kbig = (cabs2(v[1]) > cabs2(v[0])) ? 1 : 0;
-    const double mag = sqrt(cabs2(v[kbig]));
-    const Cd rot = cscale(cconj(v[kbig]), 1.0 / mag);
-    v[0] = cmul(v[0], rot);
-    v[1] = cmul(v[1], rot);
-    v[kbig].y = 0.0;
-    // normalise by sqrt(v^H V_x v)
-    Cd q = cmake<double>(0.0, 0.0);
-#pragma unroll
-    for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-      for (int bb = 0; bb < 2; ++bb) cfma(q, cmul(cconj(v[aa]), V[x][aa][bb]), v[bb]);
-    const Cd den = csqrt_principal(q);
-    v[0] = cdiv(v[0], den);
-    v[1] = cdiv(v[1], den);
-    // w_x[c] = conj(P_x[c][0] v0 + P_x[c][1] v1), c = channel = this lane's column j
-    const Cd p0 = group_shfl<GW>(inv[x], j * M + pm);
-    const Cd p1 = group_shfl<GW>(inv[x], j * M + pn);
-    wrow[x] = cconj(cadd(cmul(p0, v[0]), cmul(p1, v[1])));
-  }
-  if (i == pm && okx[0] && !(flags & ASSX_STATUS_SINGULAR)) w = wrow[0];
-  if (i == pn && okx[1] && !(flags & ASSX_STATUS_SINGULAR)) w = wrow[1];
-
-  if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
-  if (pw) {
-    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
-    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
-#pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const Cd wni = group_shfl<GW>(w, n * M + i);
-      const Cd wnj = group_shfl<GW>(w, n * M + j);
-      const Cd t1 = cmul(wni, c);
-      double term = t1.x * wnj.x + t1.y * wnj.y;
-      if (!active) term = 0.0;
-      const double sum = group_sum<GW>(term);
-      if (in_range && e == 0) pw[((size_t)b * N + n) * F + f] = sum;
-    }
-  }
-  if (flags && status && in_range && e == 0) atomicOr(&status[b], flags);
-}
-
-// ------------------------------------------------------------------------------------------
 // (a2) activation half: lanes own t; 4 waves stride over the f-split; LDS cross-wave reduce
 //      part[b][fs][(n*K + k)*2 + s][t]
 // ------------------------------------------------------------------------------------------
@@ -851,17 +407,7 @@ __global__ void __launch_bounds__(256) normalize_pb_kernel(Cx<R>* __restrict__ W
 // ------------------------------------------------------------------------------------------
 // (a7) ILRMA negative log-likelihood partials: part[b][ts*F + f] (double)
 // ------------------------------------------------------------------------------------------
-template <int M, typename R>
-__device__ __forceinline__ double neg2T_logabsdet(const Cx<R>* __restrict__ W, size_t bf, int T) {
-  Cd A[M][M];
-  const Cx<R>* p = W + bf * (M * M);
-#pragma unroll
-  for (int n = 0; n < M; ++n)
-#pragma unroll
-    for (int m = 0; m < M; ++m) A[n][m] = cmake<double>((double)p[n * M + m].x, (double)p[n * M + m].y);
-  Cd det = lu_det<M>(A);
-  return -2.0 * (double)T * log(hypot(det.x, det.y));
-}
+// neg2T_logabsdet: assx_group_linalg.hpp
 
 // ------------------------------------------------------------------------------------------
 // AuxIVA: s[b,n,t] = sum_f |y_n(f,t)|^2 partials over f-splits: part[b][fs][n][t]
@@ -1328,7 +874,9 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
   } else {
     return fail(ctx, ASSX_E_ARG, "dtype must be ASSX_F32 or ASSX_F64, got %d", dtype);
   }
-  return fail(ctx, ASSX_E_UNSUPPORTED, "only 2 <= M <= 4 channels are supported, got M=%d", M);
+  return fail(ctx, ASSX_E_UNSUPPORTED,
+              "this entry point supports 2 <= M <= 4 channels, got M=%d (5 <= M <= 8 is available for the Gauss-ILRMA / "
+              "AuxIVA / projection-back entry points, not for t-ILRMA or the partitioning function)", M);
 }
 
 #define CHECK_COMMON(ctx, B, M, F, T)                                                        \
@@ -1592,6 +1140,7 @@ extern "C" {
 
 size_t assx_workspace_bytes(int B, int M, int F, int T, int K, int dtype) {
   if (B < 1 || M < 1 || F < 1 || T < 1) return 0;
+  if (widem::handles(M)) return widem::workspace_bytes(B, M, F, T, K, dtype);
   return ws_layout(B, M, F, T, K, dtype).total;
 }
 
@@ -1599,6 +1148,7 @@ int assx_demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, v
                int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Y, ASSX_E_NULL, "assx_demix: NULL array");
+  if (widem::handles(M)) return widem::demix(ctx, X, W, scale, Y, B, M, F, T, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1619,6 +1169,7 @@ int assx_cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind,
                "assx_cov_accumulate: bad r_kind %d", r_kind);
   ASSX_REQUIRE(ctx, r_kind == ASSX_W_NONE ? (N == 1) : (N == M && r != nullptr), ASSX_E_ARG,
                "assx_cov_accumulate: N must be 1 (unweighted) or M with weights, got N=%d M=%d", N, M);
+  if (widem::handles(M)) return widem::cov_accumulate(ctx, X, r, r_kind, eps, U, ws, B, M, N, F, T, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1631,6 +1182,7 @@ int assx_ip_update(assx_ctx* ctx, const void* U, void* W, double threshold, int3
                    int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, 1);
   ASSX_REQUIRE(ctx, U && W, ASSX_E_NULL, "assx_ip_update: NULL array");
+  if (widem::handles(M)) return widem::ip_update(ctx, U, W, threshold, status, B, M, F, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1645,6 +1197,7 @@ int assx_ip2_update(assx_ctx* ctx, const void* U, void* W, double threshold, int
   ASSX_REQUIRE(ctx, U && W, ASSX_E_NULL, "assx_ip2_update: NULL array");
   ASSX_REQUIRE(ctx, pair_m >= 0 && pair_m < M && pair_n >= 0 && pair_n < M && pair_m != pair_n, ASSX_E_ARG,
                "bad update pair (%d, %d) for %d sources", pair_m, pair_n, M);
+  if (widem::handles(M)) return widem::ip2_update(ctx, U, W, threshold, status, pair_m, pair_n, B, M, F, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1657,6 +1210,7 @@ int assx_ip2_update(assx_ctx* ctx, const void* U, void* W, double threshold, int
 int assx_iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, int M, int F, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, 1);
   ASSX_REQUIRE(ctx, U && W && n_frames >= 1, ASSX_E_NULL, "assx_iss_update: NULL array / bad n_frames");
+  if (widem::handles(M)) return widem::iss_update(ctx, U, W, n_frames, B, M, F, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1678,6 +1232,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
   ASSX_REQUIRE(ctx, X && W && Tb && V && ws, ASSX_E_NULL, "assx_ilrma_source_update: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
+  if (widem::handles(M)) return widem::ilrma_source_update(ctx, X, W, Tb, V, domain, eps, source_mask, loss_prev, ws, B, M, F, T, K, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1918,6 +1473,9 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n
   ASSX_REQUIRE(ctx, spatial != ASSX_SPATIAL_IP2 || (pair_m >= 0 && pair_m < M && pair_n >= 0 && pair_n < M &&
                                                     pair_m != pair_n),
                ASSX_E_ARG, "bad update pair (%d, %d) for %d sources", pair_m, pair_n, M);
+  if (widem::handles(M))
+    return widem::ilrma_spatial_update(ctx, spatial, pair_m, pair_n, X, W, Tb, V, domain, eps, threshold, U_out, C, power_bins,
+                                       status, ws, B, M, F, T, K, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1961,6 +1519,7 @@ int assx_demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, v
                      int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && power && ws, ASSX_E_NULL, "assx_demix_power: NULL array");
+  if (widem::handles(M)) return widem::demix_power(ctx, X, W, power, ws, B, M, F, T, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -1981,6 +1540,7 @@ int assx_power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power
                         int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, 1);
   ASSX_REQUIRE(ctx, C && W && power && ws, ASSX_E_NULL, "assx_power_from_cov: NULL array");
+  if (widem::handles(M)) return widem::power_from_cov(ctx, C, W, power, ws, B, M, F, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -2062,6 +1622,11 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && Tb && V && loss && ws, ASSX_E_NULL, "%s: NULL array", who);
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
+  if (widem::handles(M)) {
+    ASSX_REQUIRE(ctx, nu < 0.0, ASSX_E_UNSUPPORTED, "%s: t-ILRMA is not on the wide-channel path (M = %d > 4)", who, M);
+    if (wrote_P) *wrote_P = false;
+    return widem::ilrma_loss(ctx, X, W, Tb, V, domain, eps, loss, ws, B, M, F, T, K, dtype, (hipStream_t)stream);
+  }
   hipStream_t st = (hipStream_t)stream;
   const WsLayout L = ws_layout(B, M, F, T, K, dtype);
   double* lpart = (double*)((char*)ws + L.lpart);
@@ -2268,6 +1833,7 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_weights: NULL array");
   ASSX_REQUIRE(ctx, kind == ASSX_IVA_LAPLACE || kind == ASSX_IVA_GAUSS, ASSX_E_ARG, "bad AuxIVA kind %d", kind);
+  if (widem::handles(M)) return widem::auxiva_weights(ctx, X, W, kind, eps, r, loss, ws, B, M, F, T, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   const WsLayout L = ws_layout(B, M, F, T, 1, dtype);
   double* lpart = (double*)((char*)ws + L.lpart);
@@ -2301,6 +1867,9 @@ int assx_auxiva_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_
                                int T, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && r && ws, ASSX_E_NULL, "assx_auxiva_spatial_update: NULL array");
+  if (widem::handles(M))
+    return widem::auxiva_spatial_update(ctx, spatial, pair_m, pair_n, X, W, r, eps, threshold, U_out, status, ws, B, M, F, T,
+                                        dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -2328,6 +1897,7 @@ int assx_projection_back_scale(assx_ctx* ctx, const void* X, const void* W, int 
   CHECK_COMMON(ctx, B, M, F, T);
   ASSX_REQUIRE(ctx, X && W && scale && ws, ASSX_E_NULL, "assx_projection_back_scale: NULL array");
   ASSX_REQUIRE(ctx, ref >= 0 && ref < M, ASSX_E_ARG, "reference_id %d out of range for %d channels", ref, M);
+  if (widem::handles(M)) return widem::projection_back_scale(ctx, X, W, ref, scale, status, ws, B, M, F, T, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -2349,6 +1919,7 @@ int assx_projection_back(assx_ctx* ctx, const void* Y, const void* reference, vo
                          int B, int N, int F, int T, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, N, F, T);
   ASSX_REQUIRE(ctx, Y && reference && scale && ws, ASSX_E_NULL, "assx_projection_back: NULL array");
+  if (widem::handles(N)) return widem::projection_back(ctx, Y, reference, scale, status, B, N, F, T, dtype, (hipStream_t)stream);
   hipStream_t st = (hipStream_t)stream;
   return dispatch_rm(ctx, dtype, N, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);

@@ -1,7 +1,8 @@
-// Entry points whose channel count is a small run-time number (2 <= M <= 8) and that are NOT on the per-iteration
-// path: the least-squares demixing filter of ILRMAbase/IVAbase.compute_demix_filter
-// (ref src/bss/ilrma.py:167-173, src/bss/iva.py:119-125).
+// Per-bin least squares (A B^H)(B B^H)^{-1} for a small run-time channel count (2 <= M <= 8), NOT on the per-iteration
+// path: the demixing filter of ILRMAbase/IVAbase.compute_demix_filter (ref src/bss/ilrma.py:167-173,
+// src/bss/iva.py:119-125) and, for M > 4, the projection-back scale (ref src/algorithm/projection_back.py:13-21).
 #include "assx_small_linalg.hpp"
+#include "assx_widem.hpp"
 
 namespace assx {
 
@@ -51,21 +52,23 @@ __device__ inline bool gj_inverse_rt(Cd* A, int M) {
   return ok;
 }
 
-// One workgroup (4 waves) per (utterance, bin).  The 2M rows of the stacked matrix [Y; X] are dealt to the waves
-// round-robin; a wave accumulates  S[r][j] = sum_t s_r(t) conj(x_j(t))  for its rows over all frames (lanes own
-// frames, coalesced 64-frame row segments), in float64 whatever the storage type.  Rows 0..M-1 of S are Y X^H, rows
-// M..2M-1 are X X^H.  Then W = (Y X^H) (X X^H)^{-1}.
+// One workgroup (4 waves) per (utterance, bin).  The na + M rows of the stacked matrix [A; B] are dealt to the waves
+// round-robin; a wave accumulates  S[r][j] = sum_t s_r(t) conj(b_j(t))  for its rows over all frames (lanes own
+// frames, coalesced 64-frame row segments), in float64 whatever the storage type.  Rows 0..na-1 of S are A B^H, the
+// rest is B B^H.  Then out = (A B^H) (B B^H)^{-1}.
 template <typename R, int M>
-__global__ __launch_bounds__(256) void lsq_demix_kernel(const Cx<R>* __restrict__ Y, const Cx<R>* __restrict__ X,
-                                                        Cx<R>* __restrict__ W, int32_t* __restrict__ status, int F,
-                                                        int T) {
-  constexpr int RW = (2 * M + 3) / 4;  // rows per wave
-  __shared__ Cd S[2 * M][M];
+__global__ __launch_bounds__(256) void stack_gram_solve_kernel(const Cx<R>* __restrict__ A, size_t a_bstride, int na,
+                                                               const Cx<R>* __restrict__ Bm, Cx<R>* __restrict__ out,
+                                                               size_t ob, size_t of, size_t oi, size_t oj,
+                                                               int32_t* __restrict__ status, int F, int T) {
+  constexpr int RW = (8 + M + 3) / 4;  // rows per wave (na <= 8)
+  __shared__ Cd S[8 + M][M];
   const int f = blockIdx.x, b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t plane = (size_t)F * T;
-  const Cx<R>* Xb = X + (size_t)b * M * plane + (size_t)f * T;
-  const Cx<R>* Yb = Y + (size_t)b * M * plane + (size_t)f * T;
+  const Cx<R>* Xb = Bm + (size_t)b * M * plane + (size_t)f * T;
+  const Cx<R>* Ab = A + (size_t)b * a_bstride + (size_t)f * T;
+  const int rows = na + M;
 
   Cd acc[RW][M];
 #pragma unroll
@@ -83,21 +86,21 @@ __global__ __launch_bounds__(256) void lsq_demix_kernel(const Cx<R>* __restrict_
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
       const int r = wave + 4 * i;
-      if (r < 2 * M) {
+      if (r < rows) {
         Cd s;
-        if (r < M) {
-          Cx<R> v = Yb[(size_t)r * plane + t];
+        if (r < na) {
+          Cx<R> v = Ab[(size_t)r * plane + t];
           s = cmake<double>((double)v.x, (double)v.y);
         } else {
           s = x[0];
 #pragma unroll
           for (int j = 1; j < M; ++j)
-            if (r - M == j) s = x[j];
+            if (r - na == j) s = x[j];
         }
 #pragma unroll
         for (int j = 0; j < M; ++j) {  // acc += s conj(x_j)
           // the products are rounded separately (no fma) so that s conj(x_j) is EXACTLY Hermitian-symmetric for
-          // rows of X: identical channels then give an exactly singular X X^H, as they do in the reference's zgemm
+          // rows of B: identical channels then give an exactly singular B B^H, as they do in the reference's zgemm
           acc[i][j].x += __dmul_rn(s.x, x[j].x) + __dmul_rn(s.y, x[j].y);
           acc[i][j].y += __dmul_rn(s.y, x[j].x) - __dmul_rn(s.x, x[j].y);
         }
@@ -110,46 +113,55 @@ __global__ __launch_bounds__(256) void lsq_demix_kernel(const Cx<R>* __restrict_
 #pragma unroll
     for (int j = 0; j < M; ++j) {
       double re = wave_allreduce_sum(acc[i][j].x), im = wave_allreduce_sum(acc[i][j].y);
-      if (lane == 0 && r < 2 * M) S[r][j] = cmake<double>(re, im);
+      if (lane == 0 && r < rows) S[r][j] = cmake<double>(re, im);
     }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    bool ok = gj_inverse_rt(&S[M][0], M);
+    bool ok = gj_inverse_rt(&S[na][0], M);
     if (!ok && status) atomicOr(&status[b], ASSX_STATUS_SINGULAR);
   }
   __syncthreads();
-  if (threadIdx.x < M * M) {
+  if ((int)threadIdx.x < na * M) {
     const int n = threadIdx.x / M, m = threadIdx.x % M;
     Cd w = cmake<double>(0.0, 0.0);
-    for (int k = 0; k < M; ++k) cfma(w, S[n][k], S[M + k][m]);
-    W[(((size_t)b * F + f) * M + n) * M + m] = cmake<R>((R)w.x, (R)w.y);
+    for (int k = 0; k < M; ++k) cfma(w, S[n][k], S[na + k][m]);
+    out[(size_t)b * ob + (size_t)f * of + (size_t)n * oi + (size_t)m * oj] = cmake<R>((R)w.x, (R)w.y);
   }
 }
 
 template <typename R>
-static int launch_lsq(assx_ctx* ctx, int M, const void* Y, const void* X, void* W, int32_t* status, int B, int F, int T,
-                      hipStream_t st) {
+static int launch_sgs(assx_ctx* ctx, const void* A, size_t a_bstride, int na, const void* Bm, int M, void* out, size_t ob,
+                      size_t of, size_t oi, size_t oj, int32_t* status, int B, int F, int T, hipStream_t st) {
   dim3 grid(F, B);
   switch (M) {
-#define ASSX_LSQ_CASE(MM)                                                                                       \
-  case MM:                                                                                                      \
-    hipLaunchKernelGGL((lsq_demix_kernel<R, MM>), grid, dim3(256), 0, st, (const Cx<R>*)Y, (const Cx<R>*)X,     \
-                       (Cx<R>*)W, status, F, T);                                                                \
+#define ASSX_SGS_CASE(MM)                                                                                          \
+  case MM:                                                                                                         \
+    hipLaunchKernelGGL((stack_gram_solve_kernel<R, MM>), grid, dim3(256), 0, st, (const Cx<R>*)A, a_bstride, na,    \
+                       (const Cx<R>*)Bm, (Cx<R>*)out, ob, of, oi, oj, status, F, T);                               \
     break;
-    ASSX_LSQ_CASE(2)
-    ASSX_LSQ_CASE(3)
-    ASSX_LSQ_CASE(4)
-    ASSX_LSQ_CASE(5)
-    ASSX_LSQ_CASE(6)
-    ASSX_LSQ_CASE(7)
-    ASSX_LSQ_CASE(8)
-#undef ASSX_LSQ_CASE
+    ASSX_SGS_CASE(2)
+    ASSX_SGS_CASE(3)
+    ASSX_SGS_CASE(4)
+    ASSX_SGS_CASE(5)
+    ASSX_SGS_CASE(6)
+    ASSX_SGS_CASE(7)
+    ASSX_SGS_CASE(8)
+#undef ASSX_SGS_CASE
     default:
-      return fail(ctx, ASSX_E_UNSUPPORTED, "assx_compute_demix_filter: 2 <= M <= 8 required, got %d", M);
+      return fail(ctx, ASSX_E_UNSUPPORTED, "2 <= M <= 8 required, got %d", M);
   }
-  ASSX_LAUNCH_CHECK(ctx, "lsq_demix_kernel");
+  ASSX_LAUNCH_CHECK(ctx, "stack_gram_solve_kernel");
   return 0;
+}
+
+int stack_gram_solve(assx_ctx* ctx, const void* A, size_t a_batch_stride, int na, const void* Bm, int M, void* out,
+                     size_t ob, size_t of, size_t oi, size_t oj, int32_t* status, int B, int F, int T, int dtype,
+                     hipStream_t st) {
+  if (na < 1 || na > 8) return fail(ctx, ASSX_E_UNSUPPORTED, "stack_gram_solve: 1 <= na <= 8 required, got %d", na);
+  if (dtype == ASSX_F64) return launch_sgs<double>(ctx, A, a_batch_stride, na, Bm, M, out, ob, of, oi, oj, status, B, F, T, st);
+  if (dtype == ASSX_F32) return launch_sgs<float>(ctx, A, a_batch_stride, na, Bm, M, out, ob, of, oi, oj, status, B, F, T, st);
+  return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
 }
 
 }  // namespace assx
@@ -161,8 +173,8 @@ extern "C" int assx_compute_demix_filter(assx_ctx* ctx, const void* Y, const voi
   ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d", B, F, T);
   ASSX_REQUIRE(ctx, Y && X && W, ASSX_E_NULL, "assx_compute_demix_filter: NULL array");
-  ASSX_REQUIRE(ctx, dtype == ASSX_F32 || dtype == ASSX_F64, ASSX_E_ARG, "bad dtype %d", dtype);
-  hipStream_t st = (hipStream_t)stream;
-  if (dtype == ASSX_F64) return launch_lsq<double>(ctx, M, Y, X, W, status, B, F, T, st);
-  return launch_lsq<float>(ctx, M, Y, X, W, status, B, F, T, st);
+  ASSX_REQUIRE(ctx, M >= 2 && M <= 8, ASSX_E_UNSUPPORTED, "assx_compute_demix_filter: 2 <= M <= 8 required, got %d", M);
+  const size_t plane = (size_t)F * T;
+  return stack_gram_solve(ctx, Y, (size_t)M * plane, M, X, M, W, (size_t)F * M * M, (size_t)M * M, (size_t)M, 1, status, B,
+                          F, T, dtype, (hipStream_t)stream);
 }

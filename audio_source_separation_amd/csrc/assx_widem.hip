@@ -1,0 +1,546 @@
+// Wide-channel path (5 <= M <= 8): see assx_widem.hpp for the design.  Reference citations are next to the entry
+// points in include/assx.h; the arithmetic contract (floors, exponents, Gauss-Seidel order) is the M <= 4 path's.
+#include "assx_widem.hpp"
+#include "assx_group_linalg.hpp"
+
+namespace assx {
+namespace widem {
+
+constexpr int RB = 512;       // partial sums per reduced row (fixed: the summation order never depends on the runtime)
+constexpr int RED_THREADS = 256;
+
+inline unsigned nblk(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+struct Ws {
+  size_t map0, map1, u, lpart, nmf, tmp, total;
+};
+static Ws layout(int B, int M, int F, int T, int K, int dtype) {
+  const size_t r = dtype == ASSX_F64 ? 8 : 4;
+  const int Kc = K < 1 ? 1 : K;
+  Ws w;
+  size_t off = 0;
+  w.map0 = off;  // P (real) -- or, together with map1, Y (complex)
+  off += align_up((size_t)B * M * F * T * r, 256);
+  w.map1 = off;  // R (real)
+  off += align_up((size_t)B * M * F * T * r, 256);
+  w.u = off;
+  off += align_up((size_t)B * M * F * M * M * 2 * r, 256);
+  w.lpart = off;
+  off += align_up((size_t)B * ((size_t)M * RB + (size_t)M * ((T + 255) / 256) + F + 64) * 8, 256);
+  w.nmf = off;
+  off += align_up(assx_nmf_workspace_bytes(B * M, F, T, Kc, dtype), 256);
+  w.tmp = off;
+  off += align_up(((size_t)B * M * F * Kc + (size_t)B * M * Kc * T) * r, 256);
+  w.total = off;
+  return w;
+}
+size_t workspace_bytes(int B, int M, int F, int T, int K, int dtype) { return layout(B, M, F, T, K, dtype).total; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// y = W x per (f, t); W_f staged in LDS (M*M complex), x in registers.  Writes Y (optionally scaled) and / or |y|^2.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename R, int M>
+__global__ void __launch_bounds__(256) demix_map_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                       const Cx<R>* __restrict__ scale, Cx<R>* __restrict__ Y,
+                                                       R* __restrict__ P, int F, int T) {
+  __shared__ Cx<R> w[M * M];
+  const int f = blockIdx.y, b = blockIdx.z;
+  if (threadIdx.x < M * M) w[threadIdx.x] = W[((size_t)b * F + f) * (M * M) + threadIdx.x];
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const size_t FT = (size_t)F * T, base = (size_t)b * M * FT + (size_t)f * T + t;
+  Cx<R> x[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) x[m] = X[base + m * FT];
+#pragma unroll
+  for (int n = 0; n < M; ++n) {
+    Cx<R> s = cmake<R>(0, 0);
+#pragma unroll
+    for (int m = 0; m < M; ++m) cfma(s, w[n * M + m], x[m]);
+    if (P) P[base + n * FT] = cabs2(s);
+    if (Y) {
+      if (scale) s = cmul(s, scale[((size_t)b * M + n) * F + f]);
+      Y[base + n * FT] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weighted covariance of one bin per workgroup.  Wave w accumulates sources n = w, w + 4, ... one after the other
+// (a source's packed Hermitian sums fill the wave's registers: 36 complex at M = 8), lanes own frames; X_f is re-read
+// from L2 per source.  U[b,n,f] = (1/T) sum_t x x^H / max(r_n, eps), dense output.
+// ------------------------------------------------------------------------------------------------------------------
+enum { RK_NONE = 0, RK_NT = 1, RK_NFT = 2 };
+
+template <typename R, int M>
+__global__ void __launch_bounds__(256) cov_bin_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ r, int r_kind,
+                                                     int N, R eps, Cx<R>* __restrict__ U, int F, int T, R inv_T) {
+  constexpr int NH = M * (M + 1) / 2;
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t FT = (size_t)F * T;
+  const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * T;
+  for (int n = wave; n < N; n += 4) {
+    const R* rn = nullptr;
+    if (r_kind == RK_NT) rn = r + ((size_t)b * N + n) * T;
+    else if (r_kind == RK_NFT) rn = r + ((size_t)b * N + n) * FT + (size_t)f * T;
+    R ar[NH], ai[NH];
+#pragma unroll
+    for (int q = 0; q < NH; ++q) ar[q] = ai[q] = 0;
+    for (int t = lane; t < T; t += WAVE) {
+      Cx<R> x[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
+      const R wgt = rn ? fast_rcp(floor_eps<R>(rn[t], eps)) : (R)1;
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < M; ++i) {
+        const R sx = wgt * x[i].x, sy = wgt * x[i].y;
+#pragma unroll
+        for (int j = i; j < M; ++j, ++q) {  // x_i conj(x_j)
+          ar[q] = fma(sx, x[j].x, ar[q]);
+          ar[q] = fma(sy, x[j].y, ar[q]);
+          if (j != i) {
+            ai[q] = fma(sy, x[j].x, ai[q]);
+            ai[q] = fma(-sx, x[j].y, ai[q]);
+          }
+        }
+      }
+    }
+    Cx<R>* un = U + (((size_t)b * N + n) * F + f) * (M * M);
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+      for (int j = i; j < M; ++j, ++q) {
+        const R re = wave_allreduce_sum<R>(ar[q]) * inv_T;
+        const R im = (j != i) ? wave_allreduce_sum<R>(ai[q]) * inv_T : (R)0;
+        if (lane == 0) {
+          un[i * M + j] = cmake<R>(re, im);
+          if (j != i) un[j * M + i] = cmake<R>(re, -im);
+        }
+      }
+  }
+}
+
+// R[bn,f,t] = (sum_k Tb[bn,f,k] V[bn,k,t])^(2/domain)   (floored by the reader, ilrma.py:499-509)
+template <typename R>
+__global__ void __launch_bounds__(256) variance_map_kernel(const R* __restrict__ Tb, const R* __restrict__ V,
+                                                          R* __restrict__ Rm, int F, int T, int K, PowSpec p2d) {
+  const int f = blockIdx.y, bn = blockIdx.z;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const R* tb = Tb + ((size_t)bn * F + f) * K;
+  const R* vb = V + (size_t)bn * K * T + t;
+  R tv = 0;
+  for (int k = 0; k < K; ++k) tv = fma(tb[k], vb[(size_t)k * T], tv);
+  Rm[((size_t)bn * F + f) * T + t] = powspec<R>(tv, p2d);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// deterministic reductions over the maps
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum(double s, double* sm) {
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = RED_THREADS / 2; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+    __syncthreads();
+  }
+  return sm[0];
+}
+
+// out[row * ostride + blockIdx.x] = sum over this block's chunk of a[row][.]  (TERM: P/R + log R of two maps)
+template <typename R, bool TERM>
+__global__ void __launch_bounds__(RED_THREADS) map_sum_kernel(const R* __restrict__ a, const R* __restrict__ rm,
+                                                             double* __restrict__ out, size_t elems, int ostride,
+                                                             R eps) {
+  __shared__ double sm[RED_THREADS];
+  const size_t row = blockIdx.y;
+  const size_t chunk = (elems + gridDim.x - 1) / gridDim.x;
+  const size_t i0 = (size_t)blockIdx.x * chunk, i1 = i0 + chunk < elems ? i0 + chunk : elems;
+  const R* pa = a + row * elems;
+  const R* pr = TERM ? rm + row * elems : nullptr;
+  double s = 0.0;
+  for (size_t i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
+    if (TERM) {
+      const R rr = floor_eps<R>(pr[i], eps);
+      s += (double)(pa[i] / rr) + log((double)rr);
+    } else {
+      s += (double)pa[i];
+    }
+  }
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) out[row * (size_t)ostride + blockIdx.x] = s;
+}
+
+// out[row] = scale * sum_{i < count} in[row * stride + i], fixed order
+template <typename TO>
+__global__ void __launch_bounds__(RED_THREADS) row_sum_kernel(const double* __restrict__ in, TO* __restrict__ out,
+                                                             int stride, int count, double scale) {
+  __shared__ double sm[RED_THREADS];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < count; i += RED_THREADS) s += in[(size_t)blockIdx.x * stride + i];
+  s = block_sum(s, sm);
+  if (threadIdx.x == 0) out[blockIdx.x] = (TO)(s * scale);
+}
+
+template <typename R, int M>
+__global__ void __launch_bounds__(64) logdet_kernel(const Cx<R>* __restrict__ W, double* __restrict__ lpart, int B, int F,
+                                                   int T, int lstride, int offset) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F) return;
+  const int b = idx / F, f = idx % F;
+  lpart[(size_t)b * lstride + offset + f] = neg2T_logabsdet<M, R>(W, (size_t)idx, T);
+}
+
+// AuxIVA statistic from the power map: s[bn,t] = sum_f P[bn,f,t] (ascending f); r = sqrt(s) | s / F; the loss data
+// term of the block goes to lpart[b][n * TB + blockIdx.x]  (iva.py:489-491, 604-619, 722-724, 783-802)
+template <typename R>
+__global__ void __launch_bounds__(RED_THREADS) aux_stat_kernel(const R* __restrict__ P, R* __restrict__ r,
+                                                              double* __restrict__ lpart, int kind, R eps, int N, int F,
+                                                              int T, int lstride) {
+  __shared__ double sm[RED_THREADS];
+  const int bn = blockIdx.y, b = bn / N, n = bn - b * N;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  double term = 0.0;
+  if (t < T) {
+    const R* p = P + (size_t)bn * F * T + t;
+    R s = 0;
+    for (int f = 0; f < F; ++f) s += p[(size_t)f * T];
+    R rv;
+    if (kind == ASSX_IVA_LAPLACE) {
+      rv = sqrt(s);
+      term = 2.0 * (double)rv;
+    } else {
+      rv = s / (R)F;
+      term = (double)F * log((double)floor_eps<R>(rv, eps));
+    }
+    r[(size_t)bn * T + t] = rv;
+  }
+  if (lpart) {
+    term = block_sum(term, sm);
+    if (threadIdx.x == 0) lpart[(size_t)b * lstride + (size_t)n * gridDim.x + blockIdx.x] = term;
+  }
+}
+
+// part[b][n][f] = Re(w_n C_f w_n^H)  (run-time M)
+template <typename R>
+__global__ void __launch_bounds__(256) power_cov_kernel(const Cx<R>* __restrict__ C, const Cx<R>* __restrict__ W,
+                                                       double* __restrict__ part, int B, int F, int M) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * F * M) return;
+  const int n = idx % M, bf = idx / M, b = bf / F, f = bf % F;
+  const Cx<R>* c = C + (size_t)bf * M * M;
+  const Cx<R>* w = W + (size_t)bf * M * M + n * M;
+  double s = 0.0;
+  for (int m = 0; m < M; ++m)
+    for (int l = 0; l < M; ++l) {
+      const double wr = w[m].x, wi = w[m].y, vr = w[l].x, vi = w[l].y, cr = c[m * M + l].x, ci = c[m * M + l].y;
+      const double ar = wr * cr - wi * ci, ai = wr * ci + wi * cr;
+      s += ar * vr + ai * vi;
+    }
+  part[((size_t)b * M + n) * F + f] = s;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) masked_copy_kernel(const R* __restrict__ Tsrc, const R* __restrict__ Vsrc,
+                                                         R* __restrict__ Tdst, R* __restrict__ Vdst, int B, int N,
+                                                         size_t FK, size_t KT, unsigned mask) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nT = (size_t)B * N * FK, nV = (size_t)B * N * KT;
+  if (idx < nT) {
+    if ((mask >> ((idx / FK) % N)) & 1u) Tdst[idx] = Tsrc[idx];
+  } else if (idx < nT + nV) {
+    const size_t j = idx - nT;
+    if ((mask >> ((j / KT) % N)) & 1u) Vdst[j] = Vsrc[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dispatch on (dtype, M)
+// ------------------------------------------------------------------------------------------------------------------
+template <typename Fn>
+static int dispatch(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
+  if (dtype != ASSX_F64 && dtype != ASSX_F32) return fail(ctx, ASSX_E_ARG, "dtype must be ASSX_F32 or ASSX_F64, got %d", dtype);
+#define WIDEM_CASE(MM)                                  \
+  case MM:                                              \
+    return dtype == ASSX_F64 ? fn(double(), IntC<MM>()) : fn(float(), IntC<MM>());
+  switch (M) {
+    WIDEM_CASE(5)
+    WIDEM_CASE(6)
+    WIDEM_CASE(7)
+    WIDEM_CASE(8)
+  }
+#undef WIDEM_CASE
+  return fail(ctx, ASSX_E_UNSUPPORTED, "the wide-channel path handles 5 <= M <= 8, got M=%d", M);
+}
+
+template <typename R, int M>
+static int launch_demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y, void* P, int B, int F,
+                        int T, hipStream_t st) {
+  hipLaunchKernelGGL((demix_map_kernel<R, M>), dim3(nblk(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
+                     (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T);
+  ASSX_LAUNCH_CHECK(ctx, "widem::demix_map_kernel");
+  return 0;
+}
+
+template <typename R, int M>
+static int launch_cov(assx_ctx* ctx, const void* X, const void* r, int r_kind, int N, double eps, void* U, int B, int F,
+                      int T, hipStream_t st) {
+  hipLaunchKernelGGL((cov_bin_kernel<R, M>), dim3(F, B), dim3(256), 0, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
+                     (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T));
+  ASSX_LAUNCH_CHECK(ctx, "widem::cov_bin_kernel");
+  return 0;
+}
+
+template <typename R, int M>
+static int launch_sweep(assx_ctx* ctx, int spatial, int pm, int pn, const void* U, void* W, const void* C, double* pw,
+                        double thr, int32_t* status, int B, int F, int T, hipStream_t st) {
+  const dim3 grid((unsigned)((size_t)B * F)), block(64);  // 64 lanes = one bin (GW = 64 for M >= 5)
+  const FlatPart fp{};
+  if (spatial == ASSX_SPATIAL_IP)
+    hipLaunchKernelGGL((ip_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, 0.0);
+  else if (spatial == ASSX_SPATIAL_ISS)
+    hipLaunchKernelGGL((iss_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                       (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, B, F);
+  else if (spatial == ASSX_SPATIAL_IP2)
+    hipLaunchKernelGGL((ip2_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, pm, pn);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad spatial algorithm %d", spatial);
+  ASSX_LAUNCH_CHECK(ctx, "widem sweep (group kernel)");
+  return 0;
+}
+
+template <typename R>
+static int launch_variance(assx_ctx* ctx, const void* Tb, const void* V, void* Rm, double domain, int BN, int F, int T,
+                           int K, hipStream_t st) {
+  hipLaunchKernelGGL((variance_map_kernel<R>), dim3(nblk(T, 256), F, BN), dim3(256), 0, st, (const R*)Tb, (const R*)V,
+                     (R*)Rm, F, T, K, make_pow(2.0 / domain));
+  ASSX_LAUNCH_CHECK(ctx, "widem::variance_map_kernel");
+  return 0;
+}
+
+// loss[b] = sum_{n,f,t} P/R + log R  -  2 T sum_f log|det W_f|, from the maps already in ws
+template <typename R, int M>
+static int loss_from_maps(assx_ctx* ctx, const Ws& L, const void* W, double eps, double* loss, void* ws, int B, int F,
+                          int T, hipStream_t st) {
+  double* lpart = (double*)((char*)ws + L.lpart);
+  const int lstride = RB + F;
+  hipLaunchKernelGGL((map_sum_kernel<R, true>), dim3(RB, B), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
+                     (const R*)((char*)ws + L.map1), lpart, (size_t)M * F * T, lstride, (R)eps);
+  ASSX_LAUNCH_CHECK(ctx, "widem::map_sum_kernel(loss)");
+  hipLaunchKernelGGL((logdet_kernel<R, M>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B, F,
+                     T, lstride, RB);
+  ASSX_LAUNCH_CHECK(ctx, "widem::logdet_kernel");
+  hipLaunchKernelGGL((row_sum_kernel<double>), dim3(B), dim3(RED_THREADS), 0, st, (const double*)lpart, loss, lstride,
+                     lstride, 1.0);
+  ASSX_LAUNCH_CHECK(ctx, "widem::row_sum_kernel");
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// entry-point bodies
+// ------------------------------------------------------------------------------------------------------------------
+int demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y, int B, int M, int F, int T, int dtype,
+          hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, X, W, scale, Y, nullptr, B, F, T, st);
+  });
+}
+
+int cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U, void* ws, int B, int M,
+                   int N, int F, int T, int dtype, hipStream_t st) {
+  (void)ws;
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    const int rk = r_kind == ASSX_W_NONE ? RK_NONE : (r_kind == ASSX_W_NT ? RK_NT : RK_NFT);
+    return launch_cov<decltype(rt), decltype(mt)::value>(ctx, X, r, rk, N, eps, U, B, F, T, st);
+  });
+}
+
+int ip_update(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int B, int M, int F, int dtype,
+              hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status,
+                                                           B, F, 1, st);
+  });
+}
+int iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, int M, int F, int dtype, hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, ASSX_SPATIAL_ISS, 0, 1, U, W, nullptr, nullptr, 0.0,
+                                                           nullptr, B, F, n_frames, st);
+  });
+}
+int ip2_update(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int pm, int pn, int B, int M, int F,
+               int dtype, hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, ASSX_SPATIAL_IP2, pm, pn, U, W, nullptr, nullptr, thr,
+                                                           status, B, F, 1, st);
+  });
+}
+
+int ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain, double eps,
+               double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, K, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
+    if (rc) return rc;
+    if ((rc = launch_variance<R>(ctx, Tb, V, (char*)ws + L.map1, domain, B * MM, F, T, K, st))) return rc;
+    return loss_from_maps<R, MM>(ctx, L, W, eps, loss, ws, B, F, T, st);
+  });
+}
+
+int ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double domain, double eps,
+                        unsigned source_mask, double* loss_prev, void* ws, int B, int M, int F, int T, int K, int dtype,
+                        hipStream_t st) {
+  const Ws L = layout(B, M, F, T, K, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    void* P = (char*)ws + L.map0;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // P = |W x|^2, once
+    if (rc) return rc;
+    if (loss_prev) {  // the loss of the model at entry needs the same P
+      if ((rc = launch_variance<R>(ctx, Tb, V, (char*)ws + L.map1, domain, B * MM, F, T, K, st))) return rc;
+      if ((rc = loss_from_maps<R, MM>(ctx, L, W, eps, loss_prev, ws, B, F, T, st))) return rc;
+    }
+    const unsigned all = (1u << MM) - 1u;
+    if ((source_mask & all) == 0u) return 0;
+    NmfGroupScope grp(ctx, MM);
+    if ((source_mask & all) == all)  // ilrma.py:409-430 == nmf.py:302-327 with target P, batch B*N
+      return assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, P, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype, st);
+    // pairwise update (ilrma.py:432-481): update copies of every source, copy the selected ones back
+    const size_t nT = (size_t)B * MM * F * K, nV = (size_t)B * MM * K * T;
+    R* Tt = (R*)((char*)ws + L.tmp);
+    R* Vt = Tt + nT;
+    hipError_t e = hipMemcpyAsync(Tt, Tb, nT * sizeof(R), hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(Vt, V, nV * sizeof(R), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(ctx, (int)e, "hipMemcpyAsync(model copy): %s", hipGetErrorString(e));
+    rc = assx_nmf_update(ctx, ASSX_NMF_IS_MM, domain, eps, P, Tt, Vt, (char*)ws + L.nmf, B * MM, F, T, K, dtype, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL((masked_copy_kernel<R>), dim3(nblk(nT + nV, 256)), dim3(256), 0, st, (const R*)Tt, (const R*)Vt,
+                       (R*)Tb, (R*)V, B, MM, (size_t)F * K, (size_t)K * T, source_mask);
+    ASSX_LAUNCH_CHECK(ctx, "widem::masked_copy_kernel");
+    return 0;
+  });
+}
+
+int ilrma_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void* X, void* W, const void* Tb,
+                         const void* V, double domain, double eps, double thr, void* U_out, const void* C,
+                         double* power_bins, int32_t* status, void* ws, int B, int M, int F, int T, int K, int dtype,
+                         hipStream_t st) {
+  const Ws L = layout(B, M, F, T, K, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    void* Rm = (char*)ws + L.map1;
+    void* U = U_out ? U_out : (void*)((char*)ws + L.u);
+    int rc = launch_variance<R>(ctx, Tb, V, Rm, domain, B * MM, F, T, K, st);
+    if (rc) return rc;
+    if ((rc = launch_cov<R, MM>(ctx, X, Rm, RK_NFT, MM, eps, U, B, F, T, st))) return rc;
+    return launch_sweep<R, MM>(ctx, spatial, pm, pn, U, W, C, power_bins, thr, status, B, F, T, st);
+  });
+}
+
+int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* ws, int B, int M, int F, int T,
+                int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, 1, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
+    if (rc) return rc;
+    double* part = (double*)((char*)ws + L.lpart);
+    hipLaunchKernelGGL((map_sum_kernel<R, false>), dim3(RB, B * MM), dim3(RED_THREADS), 0, st,
+                       (const R*)((char*)ws + L.map0), (const R*)nullptr, part, (size_t)F * T, RB, (R)0);
+    ASSX_LAUNCH_CHECK(ctx, "widem::map_sum_kernel(power)");
+    hipLaunchKernelGGL((row_sum_kernel<R>), dim3(B * MM), dim3(RED_THREADS), 0, st, (const double*)part, (R*)power, RB,
+                       RB, 1.0 / ((double)F * (double)T));
+    ASSX_LAUNCH_CHECK(ctx, "widem::row_sum_kernel");
+    return 0;
+  });
+}
+
+int power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power, void* ws, int B, int M, int F, int dtype,
+                   hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    double* part = (double*)ws;
+    hipLaunchKernelGGL((power_cov_kernel<R>), dim3(nblk((size_t)B * F * MM, 256)), dim3(256), 0, st, (const Cx<R>*)C,
+                       (const Cx<R>*)W, part, B, F, MM);
+    ASSX_LAUNCH_CHECK(ctx, "widem::power_cov_kernel");
+    hipLaunchKernelGGL((row_sum_kernel<R>), dim3(B * MM), dim3(RED_THREADS), 0, st, (const double*)part, (R*)power, F, F,
+                       1.0 / (double)F);
+    ASSX_LAUNCH_CHECK(ctx, "widem::row_sum_kernel");
+    return 0;
+  });
+}
+
+int auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, double eps, void* r, double* loss, void* ws,
+                   int B, int M, int F, int T, int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, 1, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
+    if (rc) return rc;
+    const int TB = (int)nblk(T, RED_THREADS);
+    const int lstride = MM * TB + F;
+    double* lpart = loss ? (double*)((char*)ws + L.lpart) : nullptr;
+    hipLaunchKernelGGL((aux_stat_kernel<R>), dim3(TB, B * MM), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
+                       (R*)r, lpart, kind, (R)eps, MM, F, T, lstride);
+    ASSX_LAUNCH_CHECK(ctx, "widem::aux_stat_kernel");
+    if (loss) {
+      hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B,
+                         F, T, lstride, MM * TB);
+      ASSX_LAUNCH_CHECK(ctx, "widem::logdet_kernel");
+      hipLaunchKernelGGL((row_sum_kernel<double>), dim3(B), dim3(RED_THREADS), 0, st, (const double*)lpart, loss, lstride,
+                         lstride, 1.0);
+      ASSX_LAUNCH_CHECK(ctx, "widem::row_sum_kernel");
+    }
+    return 0;
+  });
+}
+
+int auxiva_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void* X, void* W, const void* r, double eps,
+                          double thr, void* U_out, int32_t* status, void* ws, int B, int M, int F, int T, int dtype,
+                          hipStream_t st) {
+  const Ws L = layout(B, M, F, T, 1, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    void* U = U_out ? U_out : (void*)((char*)ws + L.u);
+    int rc = launch_cov<R, MM>(ctx, X, r, RK_NT, MM, eps, U, B, F, T, st);
+    if (rc) return rc;
+    return launch_sweep<R, MM>(ctx, spatial, pm, pn, U, W, nullptr, nullptr, thr, status, B, F, T, st);
+  });
+}
+
+int projection_back_scale(assx_ctx* ctx, const void* X, const void* W, int ref, void* scale, int32_t* status, void* ws,
+                          int B, int M, int F, int T, int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, 1, dtype);
+  const size_t c = dtype == ASSX_F64 ? 16 : 8, plane = (size_t)F * T;
+  void* Y = (char*)ws + L.map0;  // complex map: spans map0 and map1
+  int rc = dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, X, W, nullptr, Y, nullptr, B, F, T, st);
+  });
+  if (rc) return rc;
+  // scale[b,n,f] = (x_ref Y^H (Y Y^H)^{-1})[n]   (projection_back.py:13-21)
+  return stack_gram_solve(ctx, (const char*)X + (size_t)ref * plane * c, (size_t)M * plane, 1, Y, M, scale, (size_t)M * F, 1,
+                          0, (size_t)F, status, B, F, T, dtype, st);
+}
+
+int projection_back(assx_ctx* ctx, const void* Y, const void* reference, void* scale, int32_t* status, int B, int N,
+                    int F, int T, int dtype, hipStream_t st) {
+  return stack_gram_solve(ctx, reference, (size_t)F * T, 1, Y, N, scale, (size_t)N * F, 1, 0, (size_t)F, status, B, F, T,
+                          dtype, st);
+}
+
+}  // namespace widem
+}  // namespace assx

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused
 OBJ=.
 if [ "${ASSX_DEV:-0}" = 1 ]; then FLAGS="$FLAGS -DASSX_DEV_ONLY_M4_F64"; OBJ=dev; mkdir -p dev; fi
 pids=()
-for src in assx_api assx_bss assx_nmf assx_stft assx_generic; do
+for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem; do
   stale=0
   [ -f "$OBJ/$src.o" ] || stale=1
   for dep in "$src.hip" *.hpp ../../include/assx.h build.sh; do
@@ -20,5 +20,5 @@ for src in assx_api assx_bss assx_nmf assx_stft assx_generic; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o
 echo "built $(pwd)/libassx.so"

@@ -24,8 +24,11 @@
  *         U  (B, N, F, M, M) complex   weighted spatial covariance  ilrma.py:511
  *         Y  (B, N, F, T) complex      separated estimate           ilrma.py:153-165
  *     complex = interleaved (re, im) of the real type selected by `dtype`.
- *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 4; one utterance must stay
- *     below 4 GiB in complex128 (M*F*T < 2^28: in-kernel buffer offsets are 32-bit), any number of utterances.
+ *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 8 -- M <= 4 on the streaming
+ *     kernels (every entry point), 5 <= M <= 8 on the wide-channel path (csrc/assx_widem.hpp: materialised |W x|^2 /
+ *     variance maps, one workgroup per bin; every Gauss-ILRMA / AuxIVA / projection-back entry point, IP, ISS and
+ *     IP2; t-ILRMA and the partitioning function return ASSX_E_UNSUPPORTED there).  One utterance must stay below
+ *     4 GiB in complex128 (M*F*T < 2^28: in-kernel buffer offsets are 32-bit), any number of utterances.
  *   - dtype: ASSX_F32 (float / complex64) or ASSX_F64 (double / complex128 = the reference's).
  *   - `ws` is caller-owned device scratch of at least assx_workspace_bytes() bytes.
  *   - `status` is a device int32[B]; kernels OR flags into it (ASSX_STATUS_*), never clear it.

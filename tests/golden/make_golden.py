@@ -614,6 +614,79 @@ def gen_f4():
              activation=m.activation, variance=Lam, partitioning=part, Q1=m.diagonalizer, **extra)
 
 
+def gen_wide_m():
+    """5 <= M <= 8 channels (the reference is generic in M, ilrma.py:61-62): same file formats as the M <= 4 groups, so
+    the same oracle / GPU tests pick them up."""
+    def tag_of(M, K, normalize, domain):
+        return "m%d_k%d_%s_d%s" % (M, K, {"power": "pow", "projection-back": "pb", False: "none"}[normalize],
+                                   str(domain).replace(".", ""))
+    F, T = 13, 256  # enough frames for well-conditioned 8 x 8 covariances: rounding is not amplified beyond the
+    WIDE_ITERS = (1, 2, 5, 10)  # M <= 4 fixtures' tolerances
+    seed = 1300
+    for M, K, normalize, domain in [(5, 3, "power", 2), (6, 10, "projection-back", 1), (8, 4, "power", 2)]:
+        seed += 1
+        X = convolutive_mixture(M, F, T, seed=seed)
+        np.random.seed(seed)
+        state = np.random.get_state()
+        T0, V0 = np.random.rand(M, F, K), np.random.rand(M, K, T)
+        np.random.set_state(state)
+        snap = Snapshot(WIDE_ITERS, with_nmf=True)
+        model = GaussILRMA(n_basis=K, domain=domain, normalize=normalize, callbacks=snap)
+        Y = model(X, iteration=max(WIDE_ITERS))
+        save("ilrma_" + tag_of(M, K, normalize, domain), X=X, M=M, F=F, T=T, K=K, domain=domain,
+             normalize=np.array(str(normalize)), seed=seed, T0=T0, V0=V0, iters=np.asarray(WIDE_ITERS),
+             loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter, T_final=model.basis,
+             V_final=model.activation, **snap.data)
+    for cls, tag, M in ((AuxLaplaceIVA, "laplace", 5), (AuxGaussIVA, "gauss", 6)):
+        X = convolutive_mixture(M, F, T, seed=1320 + M)
+        snap = Snapshot(WIDE_ITERS, with_nmf=False)
+        model = cls(algorithm_spatial="IP", callbacks=snap)
+        Y = model(X, iteration=max(WIDE_ITERS))
+        save("auxiva_%s_m%d" % (tag, M), X=X, M=M, F=F, T=T, kind=tag, iters=np.asarray(WIDE_ITERS),
+             loss=np.asarray(model.loss), Y_out=Y, W_final=model.demix_filter, **snap.data)
+    # ISS
+    M = 5
+    X = convolutive_mixture(M, F, T, seed=1340)
+    snap = Snapshot((1, 2, 5), with_nmf=False)
+    model = AuxLaplaceIVA(algorithm_spatial="ISS", callbacks=snap)
+    Y = model(X, iteration=5)
+    save("iss_auxiva_laplace_m%d" % M, X=X, kind="laplace", iters=np.asarray((1, 2, 5)), loss=np.asarray(model.loss),
+         Y_out=Y, W_final=model.demix_filter, **snap.data)
+    M, K, normalize, domain, seed = 5, 2, "power", 2, 1341
+    X = convolutive_mixture(M, F, T, seed=seed)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    T0, V0 = np.random.rand(M, F, K), np.random.rand(M, K, T)
+    np.random.set_state(state)
+    snap = Snapshot((1, 2, 5), with_nmf=True)
+    model = GaussILRMA(n_basis=K, domain=domain, normalize=normalize, algorithm_spatial="ISS", callbacks=snap)
+    Y = model(X, iteration=5)
+    save("iss_ilrma_" + tag_of(M, K, normalize, domain), X=X, M=M, K=K, domain=domain, normalize=np.array(str(normalize)),
+         seed=seed, T0=T0, V0=V0, iters=np.asarray((1, 2, 5)), loss=np.asarray(model.loss), Y_out=Y,
+         W_final=model.demix_filter, T_final=model.basis, V_final=model.activation, **snap.data)
+    # IP2
+    M = 6
+    X = convolutive_mixture(M, F, T, seed=1350)
+    snap = Snapshot((1, 2, 6), with_nmf=False)
+    model = AuxLaplaceIVA(algorithm_spatial="IP2", callbacks=snap)
+    Y = model(X, iteration=6)
+    save("ip2_auxlaplace_m%d" % M, X=X, iters=np.asarray((1, 2, 6)), loss=np.asarray(model.loss), Y_out=Y,
+         W_final=model.demix_filter, update_pair=np.asarray(model.update_pair), **snap.data)
+    M, K, normalize, domain, alg, seed = 5, 3, "power", 2, "IP2", 1351
+    X = convolutive_mixture(M, F, T, seed=seed)
+    np.random.seed(seed)
+    state = np.random.get_state()
+    T0, V0 = np.random.rand(M, F, K), np.random.rand(M, K, T)
+    np.random.set_state(state)
+    snap = Snapshot((1, 2, 6), with_nmf=True)
+    model = GaussILRMA(n_basis=K, domain=domain, normalize=normalize, algorithm_spatial=alg, callbacks=snap)
+    Y = model(X, iteration=6)
+    save("ip2_ilrma_" + tag_of(M, K, normalize, domain), X=X, M=M, K=K, domain=domain, normalize=np.array(str(normalize)),
+         seed=seed, T0=T0, V0=V0, alg=np.array(alg), iters=np.asarray((1, 2, 6)), loss=np.asarray(model.loss), Y_out=Y,
+         W_final=model.demix_filter, T_final=model.basis, V_final=model.activation,
+         update_pair=np.asarray(model.update_pair), **snap.data)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
         for name in sys.argv[1:]:
@@ -635,3 +708,4 @@ if __name__ == "__main__":
     gen_consistent()
     gen_part_k10()
     gen_f4()
+    gen_wide_m()

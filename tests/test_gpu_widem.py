@@ -1,0 +1,172 @@
+"""Wide-channel path (5 <= M <= 8, csrc/assx_widem.hip): every C-ABI entry point it serves against the oracle on
+seeded inputs, float64 and float32, ragged sizes, batched == single.  The reference is generic in M
+(src/bss/ilrma.py:61-62); model-level parity on the reference's own outputs is in test_gpu_models.py
+(fixtures ilrma_m5 / m6 / m8, auxiva_*_m5 / m6, iss_*_m5, ip2_*_m5 / m6)."""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from oracle import oracle_np as orc
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", params=["float64", "float32"])
+def eng(request):
+    from audio_source_separation_amd.ops import Engine
+    return Engine(dtype=request.param)
+
+
+def tol(eng, t64, t32):
+    return t64 if eng.prec.name == "float64" else t32
+
+
+def dev_c(eng, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.dev, eng.prec.cplx).contiguous()
+
+
+def dev_r(eng, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(eng.dev, eng.prec.real).contiguous()
+
+
+def host(t):
+    a = t.detach().cpu().numpy()
+    return a.astype(np.complex128) if np.iscomplexobj(a) else a.astype(np.float64)
+
+
+def mixture(M, F, T, seed):
+    rng = np.random.default_rng(seed)
+    S = (rng.standard_normal((M, F, T)) + 1j * rng.standard_normal((M, F, T))) * (0.2 + rng.random((M, 1, T)) ** 2)
+    A = rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M))
+    return np.einsum("fmn,nft->mft", A, S)
+
+
+def rand_filters(M, F, seed):
+    rng = np.random.default_rng(seed)
+    return np.eye(M)[None] + 0.2 * (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M)))
+
+
+SHAPES = [(5, 7, 300), (6, 9, 257), (7, 5, 520), (8, 11, 400)]
+
+
+@pytest.mark.parametrize("M,F,T", SHAPES)
+def test_demix_cov_ip(eng, M, F, T):
+    X, W = mixture(M, F, T, 1), rand_filters(M, F, 2)
+    Xd = dev_c(eng, X[None])
+    Y = eng.demix(Xd, dev_c(eng, W[None]))
+    assert rel_err(host(Y)[0], orc.separate(X, W)) < tol(eng, 1e-14, 2e-6)
+    rng = np.random.default_rng(3)
+    r_nt, r_nft = rng.random((M, T)) + 0.05, rng.random((M, F, T)) + 0.05
+    r_nt[0, :3] = 0.0  # eps floor
+    for r in (r_nt, r_nft):
+        U = eng.cov_accumulate(Xd, dev_r(eng, r[None]))
+        assert rel_err(host(U)[0], orc.weighted_covariance(X, r)) < tol(eng, 1e-12, 2e-5)
+    C = eng.cov_accumulate(Xd)
+    assert rel_err(host(C)[0, 0], orc.weighted_covariance(X, np.ones((1, T)))[0]) < tol(eng, 1e-12, 2e-5)
+    Uh = host(U)[0]
+    assert np.array_equal(Uh, Uh.conj().transpose(0, 1, 3, 2))  # Hermitian bit-exact
+    # IP sweep on the oracle's covariance
+    Uo = orc.weighted_covariance(X, r_nft)
+    Wd = dev_c(eng, W[None])
+    st = eng.new_status(1)
+    eng.ip_update(dev_c(eng, Uo[None]), Wd, 1e12, st)
+    Wref, mask = orc.ip_update(W.copy(), Uo)
+    assert mask.all() and int(st.item()) == 0
+    assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-9, 2e-3)
+
+
+@pytest.mark.parametrize("M,K,domain", [(5, 3, 2), (6, 10, 1), (8, 4, 2), (7, 2, 1.5)])
+def test_ilrma_stages(eng, M, K, domain):
+    F, T = 9, 333
+    X, W = mixture(M, F, T, 20 + M), rand_filters(M, F, 21)
+    rng = np.random.default_rng(22)
+    Tb, V = rng.random((M, F, K)) + 0.05, rng.random((M, K, T)) + 0.05
+    Xd, Wd = dev_c(eng, X[None]), dev_c(eng, W[None])
+    # loss
+    got = float(eng.ilrma_loss(Xd, Wd, dev_r(eng, Tb[None]), dev_r(eng, V[None]), domain=domain).item())
+    np.testing.assert_allclose(got, orc.ilrma_loss(X, W, Tb, V, domain), rtol=tol(eng, 1e-12, 1e-5))
+    # source model, with the loss of the entry state riding along
+    Td, Vd = dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    lp = eng.empty((1,), dtype=torch.float64)
+    eng.ilrma_source_update(Xd, Wd, Td, Vd, domain=domain, loss_prev=lp)
+    T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(X, W)) ** 2, Tb, V, domain)
+    assert rel_err(host(Td)[0], T1) < tol(eng, 1e-11, 1e-4) and rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 1e-4)
+    np.testing.assert_allclose(lp.item(), orc.ilrma_loss(X, W, Tb, V, domain), rtol=tol(eng, 1e-12, 1e-5))
+    # pairwise source update: only the selected sources move
+    Td2, Vd2 = dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    eng.ilrma_source_update(Xd, Wd, Td2, Vd2, domain=domain, sources=(1, M - 1))
+    Tg, Vg = host(Td2)[0], host(Vd2)[0]
+    keep = [n for n in range(M) if n not in (1, M - 1)]
+    assert np.array_equal(Tg[keep], dev_r(eng, Tb).cpu().numpy().astype(np.float64)[keep])
+    assert rel_err(Tg[[1, M - 1]], T1[[1, M - 1]]) < tol(eng, 1e-11, 1e-4)
+    assert rel_err(Vg[[1, M - 1]], V1[[1, M - 1]]) < tol(eng, 1e-11, 1e-4)
+    # spatial model + the per-bin power statistic of the updated filters
+    Ud = eng.empty((1, M, F, M, M), complex_=True)
+    C = eng.cov_accumulate(Xd).reshape(1, F, M, M)
+    pb = eng.empty((1, M, F), dtype=torch.float64)
+    st = eng.new_status(1)
+    Wd2 = dev_c(eng, W[None])
+    eng.ilrma_spatial_update(Xd, Wd2, dev_r(eng, T1[None]), dev_r(eng, V1[None]), domain=domain, status=st, U_out=Ud,
+                             C=C, power_bins=pb)
+    Wref, Uref, mask = orc.ilrma_spatial_update_ip(X, W.copy(), T1, V1, domain)
+    assert mask.all() and int(st.item()) == 0
+    assert rel_err(host(Ud)[0], Uref) < tol(eng, 1e-12, 2e-5)
+    assert rel_err(host(Wd2)[0], Wref) < tol(eng, 1e-9, 2e-3)
+    P = np.abs(orc.separate(X, Wref)) ** 2
+    np.testing.assert_allclose(host(pb)[0], P.mean(axis=2), rtol=tol(eng, 1e-9, 2e-3))
+    # power statistics and normalisation
+    p_direct = eng.demix_power(Xd, Wd2)
+    p_cov = eng.power_from_cov(C, Wd2, T)
+    np.testing.assert_allclose(host(p_direct)[0], P.mean(axis=(1, 2)), rtol=tol(eng, 1e-10, 2e-3))
+    np.testing.assert_allclose(host(p_cov)[0], P.mean(axis=(1, 2)), rtol=tol(eng, 1e-9, 2e-3))
+    # projection back
+    sc = eng.projection_back_scale(Xd, Wd2, 1, st)
+    assert rel_err(host(sc)[0], orc.projection_back(orc.separate(X, Wref), X[1])) < tol(eng, 1e-9, 5e-3)
+    Yd = dev_c(eng, orc.separate(X, Wref)[None])
+    sc2 = eng.projection_back(Yd, dev_c(eng, X[1][None]), st)
+    assert rel_err(host(sc2)[0], orc.projection_back(orc.separate(X, Wref), X[1])) < tol(eng, 1e-9, 5e-3)
+
+
+@pytest.mark.parametrize("kind", ["laplace", "gauss"])
+@pytest.mark.parametrize("M", [5, 8])
+def test_auxiva_stages(eng, kind, M):
+    from audio_source_separation_amd import _lib
+    F, T = 9, 300
+    X, W = mixture(M, F, T, 40 + M), rand_filters(M, F, 41)
+    Xd, Wd = dev_c(eng, X[None]), dev_c(eng, W[None])
+    code = _lib.IVA_LAPLACE if kind == "laplace" else _lib.IVA_GAUSS
+    r, loss = eng.auxiva_weights(Xd, Wd, code, with_loss=True)
+    Y = orc.separate(X, W)
+    assert rel_err(host(r)[0], orc.auxiva_weights(Y, kind)) < tol(eng, 1e-12, 2e-5)
+    np.testing.assert_allclose(loss.item(), orc.auxiva_loss(X, W, kind), rtol=tol(eng, 1e-12, 1e-5))
+    st = eng.new_status(1)
+    eng.auxiva_spatial_update(Xd, Wd, r, status=st)
+    Wref, _, mask = orc.auxiva_update_once_ip(X, W.copy(), Y, kind)
+    assert mask.all() and int(st.item()) == 0
+    assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-9, 2e-3)
+
+
+def test_batched_equals_single_and_unsupported_entry_points(eng):
+    from audio_source_separation_amd._lib import AssxError
+    M, F, T, K = 6, 7, 200, 3
+    Xs = np.stack([mixture(M, F, T, 60), mixture(M, F, T, 61)])
+    W = np.stack([rand_filters(M, F, 62), rand_filters(M, F, 63)])
+    rng = np.random.default_rng(64)
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Wb, Tbd, Vbd = dev_c(eng, W), dev_r(eng, Tb), dev_r(eng, V)
+    Xb = dev_c(eng, Xs)
+    eng.ilrma_source_update(Xb, Wb, Tbd, Vbd)
+    eng.ilrma_spatial_update(Xb, Wb, Tbd, Vbd, status=eng.new_status(2))
+    for b in range(2):
+        W1, T1, V1 = dev_c(eng, W[b:b + 1]), dev_r(eng, Tb[b:b + 1]), dev_r(eng, V[b:b + 1])
+        X1 = dev_c(eng, Xs[b:b + 1])
+        eng.ilrma_source_update(X1, W1, T1, V1)
+        eng.ilrma_spatial_update(X1, W1, T1, V1, status=eng.new_status(1))
+        assert torch.equal(W1[0], Wb[b]) and torch.equal(T1[0], Tbd[b]) and torch.equal(V1[0], Vbd[b])
+    # t-ILRMA is not on the wide path: refused with a message, never a fallback
+    with pytest.raises(AssxError, match="2 <= M <= 4"):
+        eng.tilrma_source_update(Xb, Wb, Tbd, Vbd, 1.0)
+    with pytest.raises(AssxError):
+        eng.demix(dev_c(eng, np.zeros((1, 9, 3, 70), dtype=np.complex128)),
+                  dev_c(eng, np.zeros((1, 3, 9, 9), dtype=np.complex128)))  # M = 9

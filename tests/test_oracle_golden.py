@@ -15,7 +15,8 @@ from conftest import GOLDEN, load_golden, rel_err
 from oracle import oracle_np as orc
 
 NMF_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "nmf_*.npz")))
-AUX_FILES = ["auxiva_%s_m%d" % (k, m) for k in ("laplace", "gauss") for m in (2, 3, 4)]
+AUX_FILES = ["auxiva_%s_m%d" % (k, m) for k in ("laplace", "gauss") for m in (2, 3, 4)] + \
+    ["auxiva_laplace_m5", "auxiva_gauss_m6"]  # wide-channel path (5 <= M <= 8)
 ILRMA_FILES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ilrma_m*.npz")))
 
 
@@ -174,7 +175,7 @@ def test_edge_zeros():
         assert rel_err(res["Y"], g["Y_out"]) < 1e-8
 
 
-ISS_AUX = ["iss_auxiva_%s_m%d" % (k, m) for k in ("laplace", "gauss") for m in (2, 3, 4)]
+ISS_AUX = ["iss_auxiva_%s_m%d" % (k, m) for k in ("laplace", "gauss") for m in (2, 3, 4)] + ["iss_auxiva_laplace_m5"]
 ISS_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "iss_ilrma_*.npz")))
 
 
@@ -205,7 +206,7 @@ def test_iss_ilrma(name):
 IP2_ILRMA = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "ip2_ilrma_*.npz")))
 
 
-@pytest.mark.parametrize("M", [2, 3, 4])
+@pytest.mark.parametrize("M", [2, 3, 4, 6])
 def test_ip2_auxlaplace(M):
     g = load_golden("ip2_auxlaplace_m%d" % M)
     iters = [int(k) for k in g["iters"]]
