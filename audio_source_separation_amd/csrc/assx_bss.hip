@@ -1161,6 +1161,22 @@ int assx_demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, v
   });
 }
 
+int assx_ilrma_power_map(assx_ctx* ctx, const void* X, const void* W, void* P, int B, int M, int F, int T, int dtype,
+                         void* stream) {
+  CHECK_COMMON(ctx, B, M, F, T);
+  ASSX_REQUIRE(ctx, X && W && P, ASSX_E_NULL, "assx_ilrma_power_map: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M)) return widem::power_map(ctx, X, W, P, B, M, F, T, dtype, st);
+  return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                       (const Cx<R>*)X, (const Cx<R>*)W, (R*)P, Dims{B, F, T, 0});
+    ASSX_LAUNCH_CHECK(ctx, "demix_power_map_kernel");
+    return 0;
+  });
+}
+
 int assx_cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U, void* ws, int B,
                         int M, int N, int F, int T, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, T);

@@ -207,6 +207,50 @@ __global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__
   }
 }
 
+// The two halves of nmf_finalize_kernel as separate steps (F-sharded mode: the sums of a bin shard travel through an
+// all-reduce before they are applied).  sums[s][b][i], s = 0 numerator, 1 denominator; same strand order.
+template <typename R>
+__global__ void __launch_bounds__(256) nmf_sum_slabs_kernel(const R* __restrict__ part, R* __restrict__ sums, int B,
+                                                           size_t count, int splits) {
+  __shared__ R sn[4][64], sd[4][64];
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const size_t idx = (size_t)blockIdx.x * 64 + o;
+  const bool ok = idx < (size_t)B * count;
+  const size_t b = ok ? idx / count : 0, i = ok ? idx % count : 0;
+  R num = 0, den = 0;
+  if (ok) {
+#pragma unroll 4
+    for (int s = q; s < splits; s += 4) {
+      const R* pq = part + ((size_t)s * B * 2 + b * 2) * count + i;
+      num += pq[0];
+      den += pq[count];
+    }
+  }
+  sn[q][o] = num;
+  sd[q][o] = den;
+  __syncthreads();
+  if (q == 0 && ok) {
+    sums[idx] = (sn[0][o] + sn[1][o]) + (sn[2][o] + sn[3][o]);
+    sums[(size_t)B * count + idx] = (sd[0][o] + sd[1][o]) + (sd[2][o] + sd[3][o]);
+  }
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256) nmf_apply_sums_kernel(R* __restrict__ out, const R* __restrict__ sums, size_t total,
+                                                            R eps, PowSpec p) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const R num = sums[idx];
+  R den = sums[total + idx];
+  if (p.mode == POW_CAUCHY_ME) {
+    const R d2 = floor_eps<R>(den + sqrt(fma(den, den, (R)2 * num * den)), eps);
+    out[idx] = out[idx] * (num / d2);
+  } else {
+    den = floor_eps<R>(den, eps);
+    out[idx] = out[idx] * powspec<R>(num / den, p);
+  }
+}
+
 // loss partials: lpart[b][f*nblk_t + blk]
 template <typename R>
 __global__ void __launch_bounds__(256) nmf_loss_kernel(const R* __restrict__ X, const R* __restrict__ Tb,
@@ -526,6 +570,53 @@ int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, dou
   if (dtype == ASSX_F64) return nmf_update_impl<double>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
   if (dtype == ASSX_F32) return nmf_update_impl<float>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
   return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+}
+
+int assx_nmf_half_sums(assx_ctx* ctx, int kind, double domain, double param, double eps, int half, const void* X,
+                       const void* Tb, const void* V, void* sums, void* ws, int B, int F, int T, int K, int dtype,
+                       void* stream) {
+  ASSX_REQUIRE_CTX(ctx);
+  ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1 && K >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d K=%d", B, F, T, K);
+  ASSX_REQUIRE(ctx, X && Tb && V && sums && ws, ASSX_E_NULL, "assx_nmf_half_sums: NULL array");
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_T_RAW, ASSX_E_ARG, "bad NMF kind %d", kind);
+  ASSX_REQUIRE(ctx, half == 0 || half == 1, ASSX_E_ARG, "half must be 0 (basis) or 1 (activation), got %d", half);
+  ASSX_REQUIRE(ctx, domain >= 1.0 && domain <= 2.0, ASSX_E_ARG, "1 <= domain <= 2 is not satisfied (%g)", domain);
+  ASSX_REQUIRE(ctx, kind < ASSX_NMF_T || domain == 2.0, ASSX_E_ARG, "Only domain = 2 is supported (tNMF, CauchyNMF).");
+  hipStream_t st = (hipStream_t)stream;
+  const void* part = nullptr;
+  int slabs = 0;
+  int rc = nmf_half_partials(ctx, kind, domain, param, eps, half, X, Tb, V, ws, B, F, T, K, dtype, st, &part, &slabs);
+  if (rc) return rc;
+  const size_t count = half == NMF_HALF_BASIS ? (size_t)F * K : (size_t)K * T;
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((nmf_sum_slabs_kernel<double>), dim3(nblocks((size_t)B * count, 64)), dim3(256), 0, st,
+                       (const double*)part, (double*)sums, B, count, slabs);
+  else
+    hipLaunchKernelGGL((nmf_sum_slabs_kernel<float>), dim3(nblocks((size_t)B * count, 64)), dim3(256), 0, st,
+                       (const float*)part, (float*)sums, B, count, slabs);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_sum_slabs_kernel");
+  return 0;
+}
+
+int assx_nmf_apply_sums(assx_ctx* ctx, int kind, double domain, double eps, void* A, const void* sums, int B,
+                        long long count, int dtype, void* stream) {
+  ASSX_REQUIRE_CTX(ctx);
+  ASSX_REQUIRE(ctx, B >= 1 && count >= 1, ASSX_E_ARG, "invalid sizes B=%d count=%lld", B, count);
+  ASSX_REQUIRE(ctx, A && sums, ASSX_E_NULL, "assx_nmf_apply_sums: NULL array");
+  ASSX_REQUIRE(ctx, kind >= ASSX_NMF_EUC && kind <= ASSX_NMF_T_RAW, ASSX_E_ARG, "bad NMF kind %d", kind);
+  hipStream_t st = (hipStream_t)stream;
+  const PowSpec pe = update_exponent(kind, domain);
+  const size_t total = (size_t)B * (size_t)count;
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((nmf_apply_sums_kernel<double>), dim3(nblocks(total, 256)), dim3(256), 0, st, (double*)A,
+                       (const double*)sums, total, eps, pe);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((nmf_apply_sums_kernel<float>), dim3(nblocks(total, 256)), dim3(256), 0, st, (float*)A,
+                       (const float*)sums, total, (float)eps, pe);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_apply_sums_kernel");
+  return 0;
 }
 
 int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V, void* ws,

@@ -352,6 +352,13 @@ int demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* 
   });
 }
 
+int power_map(assx_ctx* ctx, const void* X, const void* W, void* P, int B, int M, int F, int T, int dtype,
+              hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);
+  });
+}
+
 int cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U, void* ws, int B, int M,
                    int N, int F, int T, int dtype, hipStream_t st) {
   (void)ws;

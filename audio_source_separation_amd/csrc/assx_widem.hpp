@@ -24,6 +24,8 @@ size_t workspace_bytes(int B, int M, int F, int T, int K, int dtype);
 
 int demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y, int B, int M, int F, int T, int dtype,
           hipStream_t st);                                                                    // assx_demix
+int power_map(assx_ctx* ctx, const void* X, const void* W, void* P, int B, int M, int F, int T, int dtype,
+              hipStream_t st);                                                                // assx_ilrma_power_map
 int cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U, void* ws, int B, int M,
                    int N, int F, int T, int dtype, hipStream_t st);                           // assx_cov_accumulate
 int ip_update(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int B, int M, int F, int dtype,

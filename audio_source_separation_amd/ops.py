@@ -334,6 +334,36 @@ class Engine:
                                                       self.prec.code, self._st()), "assx_compute_demix_filter")
         return W
 
+    # ------------------------------------------------------------------ pieces for the F-sharded mode (row f2)
+    def ilrma_power_map(self, X, W, out=None):
+        """P (B,N,F,T) real = |W x|^2."""
+        B, M, F, T = self._dims(X)
+        P = out if out is not None else self.empty((B, M, F, T))
+        self._check(self._L.assx_ilrma_power_map(self.ctx, ptr(X), ptr(W), ptr(P), B, M, F, T, self.prec.code, self._st()),
+                    "assx_ilrma_power_map")
+        return P
+
+    def nmf_half_sums(self, kind, half, X, Tb, V, domain=2, eps=1e-12, param=0.0, out=None):
+        """(2, B, F*K) [half 0: basis] or (2, B, K*T) [half 1: activation] numerators / denominators of one half of a
+        multiplicative update on X (B,F,T), not applied."""
+        B, F, T = (int(s) for s in X.shape)
+        K = int(Tb.shape[-1])
+        count = F * K if int(half) == 0 else K * T
+        sums = out if out is not None else self.empty((2, B, count))
+        ws = self._nmf_scratch(B, F, T, K)
+        self._check(self._L.assx_nmf_half_sums(self.ctx, int(kind), float(domain), float(param), float(eps), int(half),
+                                               ptr(X), ptr(Tb), ptr(V), ptr(sums), ptr(ws), B, F, T, K, self.prec.code,
+                                               self._st()), "assx_nmf_half_sums")
+        return sums
+
+    def nmf_apply_sums(self, kind, A, sums, domain=2, eps=1e-12):
+        """A (B, ...) *= (num / max(den, eps)) ** exponent(kind, domain), sums (2, B, count)."""
+        B = int(sums.shape[1])
+        count = int(sums.shape[2])
+        self._check(self._L.assx_nmf_apply_sums(self.ctx, int(kind), float(domain), float(eps), ptr(A), ptr(sums), B,
+                                                count, self.prec.code, self._st()), "assx_nmf_apply_sums")
+        return A
+
     # ------------------------------------------------------------------ NMF
     def _nmf_scratch(self, B, F, T, K):
         return self._ws.get(self._L.assx_nmf_workspace_bytes(B, F, T, K, self.prec.code))

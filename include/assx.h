@@ -286,6 +286,26 @@ int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, dou
 int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* Tb,
                      const void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
 
+/* ---- (f2) pieces of an iteration for the F-SHARDED single-utterance mode ------------------------------------------
+ * Bins are independent in every step of GaussILRMA.update_once except the activation update, which reduces over f
+ * (src/bss/ilrma.py:421-428), and the power / loss statistics, which reduce over (f, t) (ilrma.py:304-307, 648-677).
+ * A rank that owns a contiguous block of bins runs the ordinary entry points on its block (X, W, Tb sliced to the
+ * block; V whole) and needs only these extra pieces; the host all-reduces `sums` of the activation half (2 N K T
+ * reals) and N power scalars per iteration (audio_source_separation_amd/bss/ilrma_fshard.py).
+ *   assx_ilrma_power_map: P (B,N,F,T) real = |W x|^2 (ilrma.py:356-366) -- the target of the source-model NMF.
+ *   assx_nmf_half_sums:   one half of a multiplicative update stopped before it is applied: half 0 = basis (reduce
+ *                         over t), sums (2, B, F*K); half 1 = activation (reduce over f, with the CURRENT Tb), sums
+ *                         (2, B, K*T); sums[0] numerators, sums[1] denominators (not floored).  n_basis <= 64.
+ *   assx_nmf_apply_sums:  A[b][i] *= (num / max(den, eps))^e with the kind's exponent (nmf.py:317,325 etc.).
+ * X (B,F,T) as for assx_nmf_update; for the ILRMA source model B = utterances x sources and X = P. */
+int assx_ilrma_power_map(assx_ctx* ctx, const void* X, const void* W, void* P, int B, int M, int F, int T, int dtype,
+                         void* stream);
+int assx_nmf_half_sums(assx_ctx* ctx, int kind, double domain, double param, double eps, int half, const void* X,
+                       const void* Tb, const void* V, void* sums, void* ws, int B, int F, int T, int K, int dtype,
+                       void* stream);
+int assx_nmf_apply_sums(assx_ctx* ctx, int kind, double domain, double eps, void* A, const void* sums, int B,
+                        long long count, int dtype, void* stream);
+
 /* ---- (f3) STFT / iSTFT either side of the loop ---------------------------------------------- */
 /* stft / istft of src/transform/stft.py:4-17, i.e. scipy.signal.stft / istft with nperseg = fft_size,
  * noverlap = fft_size - hop, boundary='zeros', padded=True, detrend=False, scaling='spectrum', one-sided:

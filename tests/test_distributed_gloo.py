@@ -121,3 +121,126 @@ def test_two_process_scatter_separate_gather(n_items):
     # rank-ordered sum: the same bits on both ranks, equal to adding the partials in rank order
     expect = np.array([0.1, 1e-17]) + np.array([0.2, 2e-17])
     assert np.array_equal(s, expect) and np.array_equal(other[2], expect)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# F-sharded single utterance (bss/ilrma_fshard.py): the real driver + reductions, NumPy stand-in for the shard steps
+# ---------------------------------------------------------------------------------------------------------------
+class OracleShardOps:
+    """The per-shard steps of FrequencyShardedGaussILRMA restated with the oracle (CPU tensors, float64)."""
+    device = torch.device("cpu")
+    real, cplx = torch.float64, torch.complex128
+
+    def cov(self, X):
+        x = X[0].numpy()
+        A = x.transpose(1, 0, 2)
+        return torch.from_numpy((A @ A.conj().transpose(0, 2, 1) / x.shape[2])[None])
+
+    def power_map(self, X, W):
+        return torch.from_numpy(np.abs(orc.separate(X[0].numpy(), W[0].numpy()))[None] ** 2)
+
+    def half_sums(self, half, P, Tb, V, domain, eps):
+        P, T, Vv = P[0].numpy(), Tb[0].numpy(), V[0].numpy()
+        TV = T @ Vv
+        TV[TV < eps] = eps
+        division, TVinv = P / TV ** ((domain + 2) / domain), 1 / TV
+        if half == 0:
+            Vt = Vv.transpose(0, 2, 1)
+            num, den = division @ Vt, TVinv @ Vt
+        else:
+            Tt = T.transpose(0, 2, 1)
+            num, den = Tt @ division, Tt @ TVinv
+        N = P.shape[0]
+        return torch.from_numpy(np.stack([num.reshape(N, -1), den.reshape(N, -1)]))
+
+    def apply_sums(self, A, sums, domain, eps):
+        num, den = sums[0].numpy().reshape(A.shape), sums[1].numpy().reshape(A.shape).copy()
+        den[den < eps] = eps
+        A.mul_(torch.from_numpy((num / den) ** (domain / (domain + 2))))
+
+    def spatial(self, X, W, Tb, V, C, domain, eps, threshold, status):
+        Wn, _, _ = orc.ilrma_spatial_update_ip(X[0].numpy(), W[0].numpy().copy(), Tb[0].numpy(), V[0].numpy(), domain, eps,
+                                               threshold)
+        W[0].copy_(torch.from_numpy(Wn))
+
+    def shard_power_sum(self, C, W, n_frames):
+        Wn, Cn = W[0].numpy(), C[0].numpy()
+        return torch.from_numpy(np.einsum("fnm,fml,fnl->n", Wn, Cn, Wn.conj()).real.copy())
+
+    def normalize(self, W, Tb, power, domain, eps):
+        a = np.sqrt(power[0].numpy())
+        a[a < eps] = eps
+        W[0].div_(torch.from_numpy(a)[None, :, None])
+        Tb[0].div_(torch.from_numpy(a ** domain)[:, None, None])
+
+    def loss(self, X, W, Tb, V, domain, eps):
+        return torch.tensor(orc.ilrma_loss(X[0].numpy(), W[0].numpy(), Tb[0].numpy(), V[0].numpy(), domain, eps))
+
+    def output(self, X, W, ref, status):
+        Y = orc.separate(X[0].numpy(), W[0].numpy())
+        return torch.from_numpy((Y * orc.projection_back(Y, X[0].numpy()[ref])[..., None])[None])
+
+    def new_status(self):
+        return torch.zeros(1, dtype=torch.int32)
+
+    def check(self, status):
+        pass
+
+
+FS_M, FS_F, FS_T, FS_K = 3, 11, 40, 2
+
+
+def _fs_problem():
+    rng = np.random.default_rng(21)
+    S = (rng.standard_normal((FS_M, FS_F, FS_T)) + 1j * rng.standard_normal((FS_M, FS_F, FS_T))) * \
+        rng.random((FS_M, 1, FS_T)) ** 2
+    A = rng.standard_normal((FS_F, FS_M, FS_M)) + 1j * rng.standard_normal((FS_F, FS_M, FS_M))
+    X = np.einsum("fmn,nft->mft", A, S)
+    st = np.random.RandomState(3)
+    return X, st.rand(FS_M, FS_F, FS_K), st.rand(FS_M, FS_K, FS_T)
+
+
+def _fs_run(n_shards, ops):
+    from audio_source_separation_amd.bss.ilrma_fshard import FrequencyShardedGaussILRMA
+    X, T0, V0 = _fs_problem()
+    m = FrequencyShardedGaussILRMA(n_basis=FS_K, n_shards=n_shards, ops=ops, comm_device="cpu")
+    Y = m(X, iteration=3, basis=T0, activation=V0)
+    return Y, np.asarray(m.loss), m.demix_filter, m.basis, m.activation
+
+
+def _fs_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    D.init_from_env(backend="gloo")
+    out = _fs_run(world, OracleShardOps())
+    D.barrier()
+    q.put((rank,) + out)
+    torch.distributed.destroy_process_group()
+
+
+def test_frequency_sharded_ilrma_two_ranks_equal_two_shards_bitwise():
+    """bins split over 2 gloo ranks == the same 2 shards on one process, bit for bit (Y, loss, W, basis, activation);
+    and both agree with the unsharded oracle up to the rounding of the f-reduction's association."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=180) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    single = _fs_run(2, OracleShardOps())
+    for res in results:  # every rank returns the whole result
+        for a, b in zip(res[1:], single):
+            assert np.array_equal(a, b)
+    X, T0, V0 = _fs_problem()
+    ref = orc.gauss_ilrma(X, 3, T0, V0)
+    one = _fs_run(1, OracleShardOps())
+    for got in (single, one, _fs_run(3, OracleShardOps())):
+        assert np.linalg.norm(got[0] - ref["Y"]) / np.linalg.norm(ref["Y"]) < 1e-10
+        np.testing.assert_allclose(got[1], ref["loss"], rtol=1e-12)
+        assert np.linalg.norm(got[2] - ref["W"]) / np.linalg.norm(ref["W"]) < 1e-10
+        assert np.linalg.norm(got[3] - ref["T"]) / np.linalg.norm(ref["T"]) < 1e-11

@@ -118,3 +118,84 @@ def test_rccl_single_rank_group_and_bench_under_launcher():
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["roofline"]["frac"] > 0
     assert out["roofline_b8"]["utterances_per_launch"] == 2
     assert out["config5"]["utterances"] == 3 and out["config5"]["outputs_finite"] and out["config5"]["value"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# F-sharded single utterance with the HIP shard ops (bss/ilrma_fshard.py)
+# ---------------------------------------------------------------------------------------------------------------
+def _fs_problem(Mx, Fx, Tx, Kx, seed=31):
+    rng = np.random.default_rng(seed)
+    S = (rng.standard_normal((Mx, Fx, Tx)) + 1j * rng.standard_normal((Mx, Fx, Tx))) * (0.1 + rng.random((Mx, 1, Tx)) ** 2)
+    A = rng.standard_normal((Fx, Mx, Mx)) + 1j * rng.standard_normal((Fx, Mx, Mx))
+    st = np.random.RandomState(seed)
+    return np.einsum("fmn,nft->mft", A, S), st.rand(Mx, Fx, Kx), st.rand(Mx, Kx, Tx)
+
+
+@pytest.mark.parametrize("Mx,Kx,domain,normalize,dtype", [(4, 4, 2, "power", "float64"), (3, 10, 1, "power", "float64"),
+                                                          (2, 3, 2, False, "float64"), (5, 3, 2, "power", "float64"),
+                                                          (4, 4, 2, "power", "float32")])
+def test_frequency_sharded_ilrma_matches_oracle_and_class(Mx, Kx, domain, normalize, dtype):
+    """1, 2 and 3 bin shards on one process: each equals the oracle's (and the GaussILRMA class's) unsharded result
+    up to the rounding of the f-reduction; ragged shards (F = 23); the loss list has iteration + 1 entries."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    from audio_source_separation_amd.bss.ilrma_fshard import FrequencyShardedGaussILRMA
+    from oracle import oracle_np as orc
+    Fx, Tx = 23, 200
+    X, T0, V0 = _fs_problem(Mx, Fx, Tx, Kx)
+    ref = orc.gauss_ilrma(X, 4, T0, V0, domain=domain, normalize=normalize)
+    tolW, tolL = (1e-8, 1e-10) if dtype == "float64" else (2e-2, 1e-4)
+    for S in (1, 2, 3):
+        m = FrequencyShardedGaussILRMA(n_basis=Kx, domain=domain, normalize=normalize, n_shards=S, dtype=dtype)
+        Y = m(X, iteration=4, basis=T0, activation=V0)
+        assert Y.shape == X.shape and Y.dtype == np.complex128 and len(m.loss) == 5
+        assert np.linalg.norm(m.demix_filter - ref["W"]) / np.linalg.norm(ref["W"]) < tolW
+        assert np.linalg.norm(Y - ref["Y"]) / np.linalg.norm(ref["Y"]) < tolW
+        assert np.linalg.norm(m.basis - ref["T"]) / np.linalg.norm(ref["T"]) < tolW
+        assert np.linalg.norm(m.activation - ref["V"]) / np.linalg.norm(ref["V"]) < tolW
+        np.testing.assert_allclose(m.loss, ref["loss"], rtol=tolL)
+    if dtype == "float64":
+        g = GaussILRMA(n_basis=Kx, domain=domain, normalize=normalize)
+        g.basis, g.activation = T0, V0
+        Yg = g(X, iteration=4)
+        assert np.linalg.norm(Y - Yg) / np.linalg.norm(Yg) < 1e-8
+
+
+def _fs_worker(rank, world, port, backend, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == "nccl" else 0),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    from audio_source_separation_amd import distributed as D
+    from audio_source_separation_amd.bss.ilrma_fshard import FrequencyShardedGaussILRMA
+    D.init_from_env(backend=backend)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    X, T0, V0 = _fs_problem(4, 23, 200, 4)
+    m = FrequencyShardedGaussILRMA(n_basis=4, n_shards=4, device=dev, comm_device=dev if backend == "nccl" else "cpu")
+    Y = m(X, iteration=3, basis=T0, activation=V0)
+    out = (rank, Y, np.asarray(m.loss), m.demix_filter, m.basis, m.activation)
+    D.barrier(dev)
+    q.put(out)
+    torch.distributed.destroy_process_group()
+
+
+def test_frequency_sharded_ilrma_two_ranks_bitwise():
+    """4 bin shards over 2 ranks (2 shards each) == the same 4 shards on one process, bit for bit on every rank."""
+    from audio_source_separation_amd.bss.ilrma_fshard import FrequencyShardedGaussILRMA
+    backend = "nccl" if torch.cuda.device_count() >= 2 else "gloo"
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fs_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=600) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    X, T0, V0 = _fs_problem(4, 23, 200, 4)
+    m = FrequencyShardedGaussILRMA(n_basis=4, n_shards=4)
+    Y = m(X, iteration=3, basis=T0, activation=V0)
+    single = (Y, np.asarray(m.loss), m.demix_filter, m.basis, m.activation)
+    for res in results:
+        for a, b in zip(res[1:], single):
+            assert np.array_equal(a, b)
