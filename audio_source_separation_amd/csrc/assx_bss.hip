@@ -794,8 +794,19 @@ inline FlatPart flat_act(int B, int F, int T) {    // act_stream_kernel: ACT_NH 
   return make_flat(B, (long long)tblocks(T) * F, F, g_target(8 / ACT_NH));
 }
 
-inline FlatPart flat_cov_wide(int B, int F, int T) {  // cov_wide_kernel: COVW_BINS waves per workgroup, one workgroup per CU
-  return make_flat(B, (long long)((F + COVW_BINS - 1) / COVW_BINS) * tblocks(T), tblocks(T), g_target(1));
+// cov_wide_kernel: COVW_BINS waves per workgroup, one workgroup per CU; items of 64 * sb frames
+inline FlatPart flat_cov_wide(int B, int F, int T, int sb = 1) {
+  const int tbk = (T + WAVE * sb - 1) / (WAVE * sb);
+  return make_flat(B, (long long)((F + COVW_BINS - 1) / COVW_BINS) * tbk, tbk, g_target(1));
+}
+// sub-blocks per item of cov_wide_kernel.  1 is what is measured fastest; ASSX_COVW_SB=2 (one barrier per 128
+// frames, loads a whole item ahead) is kept for A/B runs: the kernel is instruction-issue bound, not latency bound
+// (SQ counters), and the second X block in registers spills at float64 -- 124 us instead of 92.
+template <typename R>
+inline int cov_wide_sb(int NK) {
+  static const int forced = env_int("ASSX_COVW_SB", 0);
+  if (forced == 2 && CovWideGeom<R, 2>::lds_bytes(NK) <= 144 * 1024) return 2;
+  return 1;
 }
 
 inline FlatPart flat_loss(int F, int T) {  // loss_stream_kernel: the utterance index is grid.y
@@ -817,9 +828,11 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   size_t p_aux = (size_t)B * FS * M * T;
   size_t pmax = p_cov;
   if (K > KU) {  // cov_wide_kernel records: [g][slot][COVW_BINS][N][M*M]
-    const FlatPart fw = flat_cov_wide(B, F, T);
-    const size_t p_wide = (size_t)fw.G * fw.S * COVW_BINS * (M * M * M);
-    if (p_wide > pmax) pmax = p_wide;
+    for (int sb = 1; sb <= 2; ++sb) {  // either item size may be chosen at launch (cov_wide_sb)
+      const FlatPart fw = flat_cov_wide(B, F, T, sb);
+      const size_t p_wide = (size_t)fw.G * fw.S * COVW_BINS * (M * M * M);
+      if (p_wide > pmax) pmax = p_wide;
+    }
     const size_t p_adapt = (size_t)B * tblocks(T) * M * 2 * Kc * WAVE;  // part_adapt_act_kernel records
     if (p_adapt > pmax) pmax = p_adapt;
   }
@@ -1090,27 +1103,29 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
   if (K <= KU || !wide) return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, fp_out);
   const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
   const PowSpec p2d = make_pow(2.0 / domain);
-  const size_t lds = CovWideGeom<R>::lds_bytes(MM * K);
+  const int sb = cov_wide_sb<R>(MM * K);
+  const size_t lds = sb == 2 ? CovWideGeom<R, 2>::lds_bytes(MM * K) : CovWideGeom<R, 1>::lds_bytes(MM * K);
   if (fused && U_dense && lds <= 144 * 1024 && (size_t)B * MM * K * T * sizeof(R) < 0xffffffffull) {
-    const FlatPart fw = flat_cov_wide(B, F, T);
+    const FlatPart fw = flat_cov_wide(B, F, T, sb);
     const Dims d{B, F, T, K};
+#define COVW_LAUNCH(D2V, SBV)                                                                                        \
+  do {                                                                                                               \
+    if (lds > 64 * 1024) {                                                                                           \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, D2V, SBV>),            \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                      \
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(cov_wide_kernel)");                          \
+    }                                                                                                                \
+    hipLaunchKernelGGL((cov_wide_kernel<R, MM, D2V, SBV>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st,              \
+                       (const Cx<R>*)X, (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);                      \
+  } while (0)
     if (p2d.mode == POW_ID) {
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, true>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(cov_wide_kernel)");
-      }
-      hipLaunchKernelGGL((cov_wide_kernel<R, MM, true>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st, (const Cx<R>*)X,
-                         (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);
+      if (sb == 2) COVW_LAUNCH(true, 2);
+      else COVW_LAUNCH(true, 1);
     } else {
-      if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_wide_kernel<R, MM, false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(cov_wide_kernel)");
-      }
-      hipLaunchKernelGGL((cov_wide_kernel<R, MM, false>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st, (const Cx<R>*)X,
-                         (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);
+      if (sb == 2) COVW_LAUNCH(false, 2);
+      else COVW_LAUNCH(false, 1);
     }
+#undef COVW_LAUNCH
     ASSX_LAUNCH_CHECK(ctx, "cov_wide_kernel");
     hipLaunchKernelGGL((cov_wide_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)), dim3(256),
                        0, st, (const R*)ws, (Cx<R>*)U_dense, B, F, fw, (R)(1.0 / (double)T));

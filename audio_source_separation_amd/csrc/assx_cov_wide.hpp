@@ -16,23 +16,29 @@ namespace assx {
 
 constexpr int COVW_BINS = 8;
 
-template <typename R>
+// SB = 64-frame sub-blocks per work item.  With SB = 2 a workgroup passes ONE barrier per 128 frames and the loads
+// of the next item are issued a whole item's arithmetic (~1.7 us) ahead -- about the HBM latency -- where SB = 1
+// waited ~2 us per 64-frame block for loads issued 0.8 us earlier (97 us per pass at config-4 size, K = 10).
+template <typename R, int SB = 1>
 struct CovWideGeom {
-  static constexpr int LPR = WAVE * (int)sizeof(R) / 16;  // lanes per 64-frame row (16 bytes per lane)
+  static constexpr int FBW = WAVE * SB;                    // frames per item
+  static constexpr int ROW_BYTES = FBW * (int)sizeof(R);
+  static constexpr int LPR = ROW_BYTES / 16;               // lanes per row (16 bytes per lane)
   static constexpr int RPI = WAVE / LPR;                   // rows per LDS-direct instruction
-  static constexpr int ROW_BYTES = WAVE * (int)sizeof(R);
+  static_assert(LPR >= 1 && LPR <= WAVE && WAVE % LPR == 0, "row geometry");
   static __host__ __device__ int rows_padded(int NK) { return (NK + RPI - 1) / RPI * RPI; }
   static __host__ __device__ size_t tile_bytes(int NK) { return (size_t)rows_padded(NK) * ROW_BYTES; }
   static __host__ __device__ size_t lds_bytes(int NK) { return 2 * tile_bytes(NK) + (size_t)COVW_BINS * NK * sizeof(R); }
 };
 
-template <typename R, int M, bool D2>
+template <typename R, int M, bool D2, int SB = 1>
 __global__ void __launch_bounds__(WAVE * COVW_BINS)
     cov_wide_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
                     Dims d, FlatPart fp, R eps, PowSpec p2d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int N = M, HM = M * M, WB = COVW_BINS, NACC = N * HM, NV = next_pow2_c(NACC);
-  using GEO = CovWideGeom<R>;
+  using GEO = CovWideGeom<R, SB>;
+  constexpr int FBW = GEO::FBW;
   const int F = d.F, T = d.T, K = d.K, NK = N * K, TBk = fp.len, FG = (F + WB - 1) / WB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned tile_bytes = (unsigned)GEO::tile_bytes(NK);
@@ -45,7 +51,7 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
   if (q0 >= q1) return;
   const int nblk = (int)(q1 - q0);
   const int jg_first = (int)(q0 / TBk);
-  Cursor cc;  // .f counts bin groups here
+  Cursor cc;  // .f counts bin groups here, .tb items of FBW frames
   cc.tb = (int)(q0 - (long long)jg_first * TBk);
   cc.b = jg_first / FG;
   cc.f = jg_first - cc.b * FG;
@@ -57,7 +63,7 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
     for (int ri = w; ri < NI; ri += WB) {
       int row = ri * GEO::RPI + lane / GEO::LPR;
       row = row < NK ? row : NK - 1;
-      const unsigned voff = (unsigned)(((size_t)(c.b * NK + row) * T + (size_t)c.tb * WAVE) * sizeof(R)) +
+      const unsigned voff = (unsigned)(((size_t)(c.b * NK + row) * T + (size_t)c.tb * FBW) * sizeof(R)) +
                             (unsigned)(lane % GEO::LPR) * 16u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(
           rv, (__attribute__((address_space(3))) void*)(smem + (unsigned)buf * tile_bytes + (unsigned)ri * GEO::RPI * GEO::ROW_BYTES),
@@ -71,18 +77,21 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
       Tl[i] = Tb[(((size_t)c.b * N + n) * F + ff) * K + k];
     }
   };
-  auto load_x = [&](const Cursor& c, Cx<R> (&x)[M]) {
+  auto load_x = [&](const Cursor& c, Cx<R> (&x)[SB][M]) {
     const int ff = min(c.f * WB + w, F - 1);
-    const int t = min(c.tb * WAVE + lane, T - 1);
-    const Cx<R>* xb = X + (size_t)c.b * M * FT + (size_t)ff * T + t;
 #pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = xb[m * FT];
+    for (int sb = 0; sb < SB; ++sb) {
+      const int t = min(c.tb * FBW + sb * WAVE + lane, T - 1);
+      const Cx<R>* xb = X + (size_t)c.b * M * FT + (size_t)ff * T + t;
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[sb][m] = xb[m * FT];
+    }
   };
 
   R acc[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) acc[q] = 0;
-  Cx<R> xn[M];
+  Cx<R> xn[SB][M];
   load_rows(cc);
   issue_tile(cc, 0);
   load_x(cc, xn);
@@ -90,44 +99,72 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
     const Cursor cur = cc;
     advance(cc, TBk, FG);
     const bool more = it + 1 < nblk;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile `it` (and its X block) has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile `it` (and its X item) has landed
     __syncthreads();                                  // ... everyone's has; tile it-1 and the old rows are no longer read
-    Cx<R> x[M];
+    Cx<R> x[SB][M];
 #pragma unroll
-    for (int m = 0; m < M; ++m) x[m] = xn[m];
+    for (int sb = 0; sb < SB; ++sb)
+#pragma unroll
+      for (int m = 0; m < M; ++m) x[sb][m] = xn[sb][m];
     if (more) {
       issue_tile(cc, (it + 1) & 1);
       load_x(cc, xn);
     }
-    const R* vl = reinterpret_cast<const R*>(smem + (unsigned)(it & 1) * tile_bytes) + lane;
     const R* tl = Tl + w * NK;
-    const bool live = (cur.f * WB + w < F) && (cur.tb * WAVE + lane < T);
-    R wgt[N];
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-      R tv = 0;
-      for (int k = 0; k < K; ++k) tv = fma(tl[n * K + k], vl[(n * K + k) * WAVE], tv);
-      const R r = floor_eps<R>(D2 ? tv : powspec<R>(tv, p2d), eps);  // floored AFTER the power (ilrma.py:499-509)
-      wgt[n] = live ? fast_rcp(r) : (R)0;
-    }
+    for (int sb = 0; sb < SB; ++sb) {
+      const R* vl = reinterpret_cast<const R*>(smem + (unsigned)(it & 1) * tile_bytes) + sb * WAVE + lane;
+      const bool live = (cur.f * WB + w < F) && (cur.tb * FBW + sb * WAVE + lane < T);
+      // r_n = sum_k T[n,f,k] V[n,k,t], k ascending per source.  The N sources advance together and k in pairs, so
+      // 4N LDS reads are in flight per wait instead of 2.
+      R tvv[N];
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const R pd = cabs2(x[m]);
-#pragma unroll
-      for (int n = 0; n < N; ++n) acc[n * HM + m] = fma(wgt[n], pd, acc[n * HM + m]);
-    }
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-#pragma unroll
-      for (int l = m + 1; l < M; ++l) {
-        const Cx<R> pr = cmulc(x[m], x[l]);
-        const int hb = herm_pair_base<M>(m, l);
+      for (int n = 0; n < N; ++n) tvv[n] = 0;
+      int k = 0;
+      for (; k + 2 <= K; k += 2) {
+        R t0[N], t1[N], v0[N], v1[N];
 #pragma unroll
         for (int n = 0; n < N; ++n) {
-          acc[n * HM + hb] = fma(wgt[n], pr.x, acc[n * HM + hb]);
-          acc[n * HM + hb + 1] = fma(wgt[n], pr.y, acc[n * HM + hb + 1]);
+          t0[n] = tl[n * K + k];
+          t1[n] = tl[n * K + k + 1];
+          v0[n] = vl[(n * K + k) * FBW];
+          v1[n] = vl[(n * K + k + 1) * FBW];
+        }
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          tvv[n] = fma(t0[n], v0[n], tvv[n]);
+          tvv[n] = fma(t1[n], v1[n], tvv[n]);
         }
       }
+      if (k < K) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) tvv[n] = fma(tl[n * K + k], vl[(n * K + k) * FBW], tvv[n]);
+      }
+      R wgt[N];
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        const R r = floor_eps<R>(D2 ? tvv[n] : powspec<R>(tvv[n], p2d), eps);  // floored AFTER the power (ilrma.py:499-509)
+        wgt[n] = live ? fast_rcp(r) : (R)0;
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const R pd = cabs2(x[sb][m]);
+#pragma unroll
+        for (int n = 0; n < N; ++n) acc[n * HM + m] = fma(wgt[n], pd, acc[n * HM + m]);
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+#pragma unroll
+        for (int l = m + 1; l < M; ++l) {
+          const Cx<R> pr = cmulc(x[sb][m], x[sb][l]);
+          const int hb = herm_pair_base<M>(m, l);
+#pragma unroll
+          for (int n = 0; n < N; ++n) {
+            acc[n * HM + hb] = fma(wgt[n], pr.x, acc[n * HM + hb]);
+            acc[n * HM + hb + 1] = fma(wgt[n], pr.y, acc[n * HM + hb + 1]);
+          }
+        }
+    }
     if (cc.tb == 0 || !more) {  // the bin group is complete (or the range ends): flush, take the next group's rows
       const R tot = wave_reduce_scatter<R, NV>(acc);
       const int i = scatter_index<NV>();

@@ -1,18 +1,35 @@
 #!/bin/bash
-# Collect the evidence committed under profiles/ (run on the GPU box through gpurun):
-#   bash tools/collect_profiles.sh TAG      -> gpurun_out/TAG/*
-set -u
-TAG="${1:-r01}"
+# Everything profiles/<tag>_* is made of, in one run on the GPU box:  bash tools/collect_profiles.sh r02_a
+# (bench lines, rocprofv3 kernel tables, SQ / traffic PMC passes -- PMC only ever with --kernel-trace, as gpurun wants)
+TAG="${1:-r02}"
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
-cd $ROOT
-python bench.py --with-loss > $OUT/bench_f64.json 2> $OUT/bench_f64.err
-python bench.py --dtype float32 --cpu-iters 0 > $OUT/bench_f32.json 2> $OUT/bench_f32.err
-python tools/bench_configs.py > $OUT/bench_configs.json 2> $OUT/bench_configs.err
-python bench.py --steps 30 --warmup 5 --utterances-per-gpu 8 --cpu-iters 0 > $OUT/bench_f64_b8.json 2> $OUT/bench_f64_b8.err
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $OUT/prof -o p -- python $ROOT/bench.py --steps 20 --warmup 3 --cpu-iters 0 > $OUT/prof_bench.log 2>&1)
-python tools/pmc_traffic.py collect
-python tools/pmc_traffic.py report > $OUT/cov_traffic.log 2>&1
-cp profiles/cov_traffic.json $OUT/cov_traffic.json
-tail -n 1 $OUT/bench_f64.json | cut -c1-300
+cd /tmp && export TMPDIR=/tmp
+py() { python "$@"; }
+B="$ROOT/bench.py"
+py $B > $OUT/bench_f64.json 2> $OUT/bench_f64.err
+py $B --dtype float32 --cpu-iters 0 > $OUT/bench_f32.json 2>/dev/null
+py $B --cpu-iters 0 --utterances-per-gpu 8 --steps 100 --warmup 10 --roofline-b8 0 > $OUT/bench_f64_8utt.json 2>/dev/null
+py $B --cpu-iters 0 --basis 10 --steps 200 --warmup 20 > $OUT/bench_f64_k10.json 2>/dev/null
+py $B --cpu-iters 0 --basis 10 --utterances-per-gpu 8 --steps 50 --warmup 5 --roofline-b8 0 > $OUT/bench_f64_k10_8utt.json 2>/dev/null
+py $B --cpu-iters 0 --with-loss --roofline-b8 0 > $OUT/bench_f64_with_loss.json 2>/dev/null
+py $B --cpu-iters 0 --config5 on --config5-utterances 16 --config5-iterations 100 --roofline-b8 0 > $OUT/bench_f64_config5_1gpu_16utt.json 2>/dev/null
+py $ROOT/tools/bench_configs.py > $OUT/bench_configs.json 2>/dev/null
+py $ROOT/tools/nmf_bench.py float64 > $OUT/nmf_bench_f64.txt 2>/dev/null
+py $ROOT/tools/nmf_bench.py float32 > $OUT/nmf_bench_f32.txt 2>/dev/null
+# rocprofv3 kernel tables: the driver's own command line, the K=10 line, NMF config 2
+rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg4 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_k10 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --basis 10 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_nmf -o p -- python $ROOT/tools/nmf_bench.py float64 > /dev/null 2>&1
+for t in cfg4 k10 nmf; do py $ROOT/tools/rocprof_summary.py $OUT/prof_$t > $OUT/${t}_kernel_stats.md 2>&1; done
+# SQ counters
+bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_stream $TAG/sq_cov_k4 > $OUT/sq_cov_k4.txt 2>&1
+bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_wide $TAG/sq_cov_k10 --K 10 > $OUT/sq_cov_k10.txt 2>&1
+# HBM traffic
+py $ROOT/tools/pmc_traffic.py collect > /dev/null 2>&1
+py $ROOT/tools/pmc_traffic.py report > $OUT/cov_traffic.json 2>&1
+cp $ROOT/profiles/cov_traffic.json $OUT/cov_traffic.json 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/mfma_f64_rate_probe.hip -o /tmp/mfma_rate && /tmp/mfma_rate > $OUT/mfma_rate_probe.txt
+rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] 2>/dev/null
+ls -la $OUT

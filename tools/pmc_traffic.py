@@ -23,15 +23,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
+CASES = (("k4", 4, "cov_stream_kernel"), ("k10", 10, "cov_wide_kernel"))  # (tag, n_basis, kernel-name substring)
+
+
 def collect():
     env = dict(os.environ, TMPDIR="/tmp")
-    for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        for dtype in ("float64", "float32"):
-            d = os.path.join(OUT, name + "_" + dtype)
-            cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                   sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "--only", "cov TV", "--reps", "5",
-                   "--dtype", dtype]
-            subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for tag, K, _ in CASES:
+        for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+            for dtype in ("float64", "float32"):
+                d = os.path.join(OUT, "%s_%s_%s" % (name, tag, dtype))
+                cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+                       sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "--only", "cov TV", "--reps", "5",
+                       "--dtype", dtype, "--K", str(K)]
+                subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
 def _mean_counter(d, counter, kernel_substr):
@@ -44,27 +48,34 @@ def _mean_counter(d, counter, kernel_substr):
 
 
 def report():
+    import datetime
     out = {}
-    for dtype in ("float64", "float32"):
-        f, nf = _mean_counter(os.path.join(OUT, "pmc_fetch_" + dtype), "FETCH_SIZE", "cov_stream_kernel")
-        w, nw = _mean_counter(os.path.join(OUT, "pmc_write_" + dtype), "WRITE_SIZE", "cov_stream_kernel")
-        if f is None or w is None:
-            continue
-        fetch_raw, write_raw = f * 1024.0, w * 1024.0
-        # float64: 16 B/lane loads -> the guide's x2.  float32: 8 B/lane loads, "uncalibrated" in the guide, so it is
-        # calibrated here against a known byte count: the kernel must read every byte of X (134.3 MB) exactly once
-        # and raw FETCH_SIZE reports 69 MB = 0.51x -> the same x2 applies to this access pattern.
-        corr = 2.0
-        out[dtype] = {
-            "workload": "cov_stream_kernel (TV weights), M=4 F=1025 T=4096 K=4, one launch",
-            "fetch_size_kib": f, "write_size_kib": w, "launches_averaged": [nf, nw],
-            "fetch_bytes_raw": fetch_raw, "write_bytes_raw": write_raw,
-            "fetch_correction": corr,
-            "traffic_bytes": fetch_raw * corr + write_raw,
-            "note": "FETCH_SIZE x1024 x%g (gfx950 counts 128 B requests as 64 B on coalesced streaming reads; x2 from "
-                    "MI355X_MICROARCH.md for 16 B/lane, re-calibrated on the known X byte count for 8 B/lane) + "
-                    "WRITE_SIZE x1024 (uncalibrated, <1%% of the total)" % corr,
-        }
+    for tag, K, ksub in CASES:
+        for dtype in ("float64", "float32"):
+            f, nf = _mean_counter(os.path.join(OUT, "pmc_fetch_%s_%s" % (tag, dtype)), "FETCH_SIZE", ksub)
+            w, nw = _mean_counter(os.path.join(OUT, "pmc_write_%s_%s" % (tag, dtype)), "WRITE_SIZE", ksub)
+            if f is None or w is None:
+                continue
+            fetch_raw, write_raw = f * 1024.0, w * 1024.0
+            # float64: 16 B/lane loads -> the guide's x2.  float32: 8 B/lane loads, "uncalibrated" in the guide, so it
+            # is calibrated here against a known byte count: the kernel must read every byte of X (134.3 MB) exactly
+            # once and raw FETCH_SIZE reports 69 MB = 0.51x -> the same x2 applies to this access pattern.
+            corr = 2.0
+            rec = {
+                "workload": "%s (TV weights rebuilt in-kernel), M=4 F=1025 T=4096 K=%d, one launch" % (ksub, K),
+                "fetch_size_kib": f, "write_size_kib": w, "launches_averaged": [nf, nw],
+                "fetch_bytes_raw": fetch_raw, "write_bytes_raw": write_raw,
+                "fetch_correction": corr,
+                "traffic_bytes": fetch_raw * corr + write_raw,
+                "collected": "round 2, %s" % datetime.date.today().isoformat(),
+                "note": "FETCH_SIZE x1024 x%g (gfx950 counts 128 B requests as 64 B on coalesced streaming reads; x2 "
+                        "from MI355X_MICROARCH.md for 16 B/lane, re-calibrated on the known X byte count for 8 B/lane) "
+                        "+ WRITE_SIZE x1024 (uncalibrated, <1%% of the total)" % corr,
+            }
+            if K <= 4:
+                out[dtype] = rec
+            else:
+                out.setdefault("wide_k%d" % K, {})[dtype] = rec
     path = os.path.join(ROOT, "profiles", "cov_traffic.json")
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
