@@ -70,24 +70,48 @@ __device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singula
   return a;
 }
 
+// Largest singular value of the M x M matrix whose element (i, j) lives in lane (i, j) of the group: lambda_max of
+// the Gram matrix by repeated squaring with trace normalisation, every product made of in-group shuffles.  Same
+// arithmetic as spectral_norm_slow (assx_small_linalg.hpp) but with NO per-lane arrays: the single-thread form keeps
+// three M x M complex matrices in scratch, and although this is a rare path its 3.6 KB per lane are reserved for
+// every wave of the kernel -- at 8 utterances per launch the scratch ceiling throttled the waves in flight and the IP
+// sweep took 405 us instead of 67.
+template <int M, int GW>
+__device__ __forceinline__ double group_spectral_norm(Cd a, int i, int j, bool active) {
+  Cd g = cmake<double>(0.0, 0.0);
+#pragma unroll
+  for (int k = 0; k < M; ++k) cfma(g, cconj(group_shfl<GW>(a, k * M + i)), group_shfl<GW>(a, k * M + j));  // (A^H A)[i][j]
+  const double tr = group_sum<GW>((active && i == j) ? g.x : 0.0);
+  if (!(tr > 0.0) || !isfinite(tr)) return tr > 0.0 ? tr : 0.0;
+  g = cscale(g, 1.0 / tr);
+  const Cd g0 = g;
+  for (int it = 0; it < 24; ++it) {
+    Cd h = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) cfma(h, group_shfl<GW>(g, i * M + k), group_shfl<GW>(g, k * M + j));
+    const double t2 = group_sum<GW>((active && i == j) ? h.x : 0.0);
+    g = cscale(h, 1.0 / t2);
+  }
+  // Rayleigh quotient tr(G0 Gk) / tr(Gk), tr(Gk) = 1
+  const Cd gt = group_shfl<GW>(g, j * M + i);
+  const double lam = group_sum<GW>(active ? (g0.x * gt.x - g0.y * gt.y) : 0.0);
+  return sqrt(lam * tr);
+}
+
 // cond_2(A) < thr from A (a0) and its inverse (ainv), element (i, j) per lane: Frobenius bounds, exact spectral
-// norms only inside the factor-M band (every lane gathers both matrices; rare).
+// norms only inside the factor-M band (rare; whole groups take the slow path together).
 template <int M, int GW>
 __device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bool singular, double thr) {
-  constexpr int MM = M * M;
   const double nA2 = group_sum<GW>(active ? cabs2(a0) : 0.0);
   const double nI2 = group_sum<GW>(active ? cabs2(ainv) : 0.0);
   const double condF = sqrt(nA2) * sqrt(nI2);
   const bool amb = !singular && (condF == condF) && condF >= thr && condF < thr * (double)M;
   bool ok = !singular && (condF == condF) && condF < thr;
   if (__any(amb)) {
-    Cd ma[MM], mi[MM];
-#pragma unroll
-    for (int q = 0; q < MM; ++q) {
-      ma[q] = group_shfl<GW>(a0, q);
-      mi[q] = group_shfl<GW>(ainv, q);
-    }
-    if (amb) ok = spectral_norm_slow(ma, M) * spectral_norm_slow(mi, M) < thr;
+    const int lane = threadIdx.x & (GW - 1);
+    const int i = active ? lane / M : 0, j = active ? lane % M : 0;
+    const double s = group_spectral_norm<M, GW>(a0, i, j, active) * group_spectral_norm<M, GW>(ainv, i, j, active);
+    if (amb) ok = s < thr;
   }
   return ok;
 }
