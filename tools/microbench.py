@@ -68,3 +68,10 @@ timeit("demix (read X, write Y)", lambda: eng.demix(X, W, out=Y), 2 * xbytes)
 U = eng.cov_accumulate(X, r_nt)
 W2 = W.clone()
 timeit("ip_update", lambda: eng.ip_update(U, W2, 1e12, st), U.numel() * U.element_size())
+# BASELINE config 2 (IS-NMF F x T, n_basis 32) through the same harness, for the PMC scripts
+if a.only.startswith("nmf"):
+    Kn = a.K if a.K > 4 else 32
+    Xn = (torch.rand((1, F, T), dtype=torch.float64, device=eng.dev, generator=g) ** 2).to(eng.prec.real)
+    Tn = torch.rand((1, F, Kn), dtype=torch.float64, device=eng.dev, generator=g).to(eng.prec.real)
+    Vn = torch.rand((1, Kn, T), dtype=torch.float64, device=eng.dev, generator=g).to(eng.prec.real)
+    timeit("nmf_update IS", lambda: eng.nmf_update(_lib.NMF_IS_MM, Xn, Tn, Vn), 2 * F * T * Xn.element_size())
