@@ -20,9 +20,10 @@ py $ROOT/tools/nmf_bench.py float64 > $OUT/nmf_bench_f64.txt 2>/dev/null
 py $ROOT/tools/nmf_bench.py float32 > $OUT/nmf_bench_f32.txt 2>/dev/null
 # rocprofv3 kernel tables: the driver's own command line, the K=10 line, NMF config 2
 rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg4 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_f32 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --dtype float32 --roofline-b8 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_k10 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --basis 10 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_nmf -o p -- python $ROOT/tools/nmf_bench.py float64 > /dev/null 2>&1
-for t in cfg4 k10 nmf; do py $ROOT/tools/rocprof_summary.py $OUT/prof_$t > $OUT/${t}_kernel_stats.md 2>&1; done
+for t in cfg4 f32 k10 nmf; do py $ROOT/tools/rocprof_summary.py $OUT/prof_$t > $OUT/${t}_kernel_stats.md 2>&1; done
 # SQ counters
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_stream $TAG/sq_cov_k4 > $OUT/sq_cov_k4.txt 2>&1
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_wide $TAG/sq_cov_k10 --K 10 > $OUT/sq_cov_k10.txt 2>&1
