@@ -118,13 +118,21 @@ def gather_utterances(y_local, n_items, dst=0):
     return out
 
 
+def _is_nccl():
+    return dist.is_initialized() and dist.get_backend() == "nccl"
+
+
 def barrier(device=None):
+    """Every rank's queued GPU work is finished, then every rank has arrived (timing bracket of bench.py)."""
+    cuda = device is not None and torch.device(device).type == "cuda"
+    if cuda:
+        torch.cuda.synchronize(device)
     if dist.is_initialized():
-        if device is not None and torch.device(device).type == "cuda":
+        if cuda and _is_nccl():
             dist.barrier(device_ids=[torch.device(device).index])
         else:
             dist.barrier()
-    if device is not None and torch.device(device).type == "cuda":
+    if cuda:
         torch.cuda.synchronize(device)
 
 
@@ -132,9 +140,28 @@ def max_over_ranks(value, device="cpu"):
     """MAX of a Python float over all ranks (the per-rank elapsed time of a timed region)."""
     if not dist.is_initialized():
         return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if _is_nccl() else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def warm_up_edges(device, src=0):
+    """One tiny grouped send/recv root <-> every peer: RCCL builds its point-to-point channels on first use (seconds),
+    which must not be billed to the first timed scatter."""
+    rank, world = _world()
+    if world == 1:
+        return
+    t = torch.zeros(8, dtype=torch.float32, device=device)
+    for direction in (0, 1):
+        ops = []
+        if rank == src:
+            for r in range(world):
+                if r != src:
+                    ops.append(dist.P2POp(dist.isend if direction == 0 else dist.irecv, t.clone(), r))
+        else:
+            ops.append(dist.P2POp(dist.irecv if direction == 0 else dist.isend, t.clone(), src))
+        _run_p2p(ops)
+    barrier(device if torch.device(device).type == "cuda" else None)
 
 
 def run_sharded(process_fn, x_all, n_items, item_shape, dtype, device, gather=True):

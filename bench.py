@@ -64,6 +64,10 @@ def parse():
                    help="config-5 leg (64 utterances sharded over the ranks); auto = only when N > 1")
     p.add_argument("--config5-utterances", type=int, default=64)
     p.add_argument("--config5-iterations", type=int, default=100)
+    # test scaffolding (tests/test_gpu_multi.py): N ranks on ONE GPU with gloo-staged edges, so that the whole N > 1
+    # flow of this file runs on a 1-GPU box.  Never used for a reported number.
+    p.add_argument("--comm-backend", default="nccl", choices=["nccl", "gloo"])
+    p.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (only with --comm-backend gloo)")
     return p.parse_args()
 
 
@@ -71,7 +75,7 @@ def self_launch(args):
     """`python bench.py --gpus N` without a launcher: spawn the N ranks (one per GPU) and relay their output."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (args.share_gpu and args.comm_backend == "gloo" and have >= 1):
         sys.stderr.write("bench.py: --gpus %d requested but only %d GPU(s) are visible; refusing to run fewer ranks "
                          "than asked for.\n" % (args.gpus, have))
         sys.exit(2)
@@ -190,7 +194,7 @@ def cpu_baseline_leg(args, Xh, M, F, T, K):
     return out
 
 
-def config5_leg(args, torch, D, dev, rank, world, M, F, T, K):
+def config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K):
     """64 seeded utterances -> shard_range blocks -> one batched GaussILRMA call per rank -> gather."""
     from audio_source_separation_amd.bss.ilrma import GaussILRMA
     U, iters = args.config5_utterances, args.config5_iterations
@@ -220,9 +224,12 @@ def config5_leg(args, torch, D, dev, rank, world, M, F, T, K):
                                                else torch.float32, device=dev, generator=gen))
         warm(xw, iteration=2)
         del warm, xw
+    if rank == 0 and comm_dev != dev:
+        x_all = x_all.to(comm_dev)  # gloo-staged test mode: the edges travel through host memory
+    D.warm_up_edges(comm_dev)
     D.barrier(dev)
     t0 = time.perf_counter()
-    x_local = D.scatter_utterances(x_all, U, (M, F, T), cplx, dev)
+    x_local = D.scatter_utterances(x_all, U, (M, F, T), cplx, comm_dev).to(dev)
     D.barrier(dev)
     t1 = time.perf_counter()
     model = factory()
@@ -233,7 +240,7 @@ def config5_leg(args, torch, D, dev, rank, world, M, F, T, K):
         y_local = torch.empty((0, M, F, T), dtype=cplx, device=dev)
     D.barrier(dev)
     t2 = time.perf_counter()
-    y_all = D.gather_utterances(y_local, U)
+    y_all = D.gather_utterances(y_local.to(comm_dev), U)
     D.barrier(dev)
     t3 = time.perf_counter()
     compute = D.max_over_ranks(t2 - t1, device=dev)
@@ -265,9 +272,13 @@ def main():
     import torch.distributed as dist
 
     from audio_source_separation_amd import distributed as D
-    rank, world, local_rank = D.init_from_env(backend="nccl" if args.gpus > 1 else None)
+    if args.share_gpu and args.comm_backend != "gloo":
+        sys.stderr.write("bench.py: --share-gpu needs --comm-backend gloo (RCCL cannot put two ranks on one GPU).\n")
+        sys.exit(2)
+    rank, world, local_rank = D.init_from_env(backend=args.comm_backend if args.gpus > 1 else None)
     n_gpus = world
-    dev = torch.device("cuda", local_rank if world > 1 else torch.cuda.current_device())
+    dev = torch.device("cuda", 0 if args.share_gpu else (local_rank if world > 1 else torch.cuda.current_device()))
+    comm_dev = dev if (world == 1 or args.comm_backend == "nccl") else torch.device("cpu")
     comm = {"backend": (dist.get_backend() if dist.is_initialized() else None),
             "world_size": (dist.get_world_size() if dist.is_initialized() else 1)}
 
@@ -363,7 +374,7 @@ def main():
         del model
         torch.cuda.empty_cache()
         try:
-            config5 = config5_leg(args, torch, D, dev, rank, world, M, F, T, K)
+            config5 = config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K)
         except Exception as exc:  # the headline line must survive a failure of this leg
             config5 = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
@@ -400,7 +411,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     if world > 1:
-        dist.barrier(device_ids=[dev.index])
+        D.barrier(dev)
         dist.destroy_process_group()
 
 

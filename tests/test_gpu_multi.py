@@ -199,3 +199,26 @@ def test_frequency_sharded_ilrma_two_ranks_bitwise():
     for res in results:
         for a, b in zip(res[1:], single):
             assert np.array_equal(a, b)
+
+
+def test_bench_two_ranks_whole_flow_on_one_gpu():
+    """`python bench.py --gpus 2` end to end -- self-launch under torch.distributed.run, the weak-scaling headline
+    line, the config-5 leg with a ragged 5-utterance batch and real scatter / gather edges -- with both ranks on
+    cuda:0 and the edges staged over gloo (the test-only --comm-backend gloo --share-gpu mode; RCCL needs one GPU per
+    rank).  Everything but the transport is what the driver's 8-GPU run executes."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--comm-backend", "gloo", "--share-gpu",
+           "--steps", "3", "--warmup", "1", "--bins", "129", "--frames", "512", "--cpu-iters", "0", "--kernel-reps", "3",
+           "--roofline-b8", "2", "--config5-utterances", "5", "--config5-iterations", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["comm"] == {"backend": "gloo", "world_size": 2}
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["cpu_baseline"] is None
+    c5 = out["config5"]
+    assert c5["utterances"] == 5 and c5["utterances_per_gpu"] == [3, 2] and c5["outputs_finite"]
+    assert c5["value"] >= c5["value_incl_edges"] > 0 and c5["seconds_scatter"] > 0 and c5["seconds_gather"] > 0
