@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Wide-channel path (5 <= M <= 8): GaussILRMA.update_once rate and per-stage times at config-4 bins / frames."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from audio_source_separation_amd.bss.ilrma import GaussILRMA
+
+F, T = 1025, 4096
+dev = torch.device("cuda", 0)
+for M, K in ((4, 4), (5, 4), (6, 4), (8, 4), (8, 10)):
+    g = torch.Generator(device=dev).manual_seed(M)
+    X = torch.view_as_complex(torch.randn((M, F, T, 2), dtype=torch.float64, device=dev, generator=g)).contiguous()
+    np.random.seed(1)
+    m = GaussILRMA(n_basis=K, recordable_loss=False)
+    m.input = X
+    m._reset()
+    for _ in range(3):
+        m.update_once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        m.update_once()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    e = []
+    for name, fn in (("source", m.update_source_model), ("spatial", m.update_spatial_model)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            fn()
+        e1.record(); e1.synchronize()
+        e.append("%s %.0f us" % (name, e0.elapsed_time(e1) / 5 * 1e3))
+    print("M=%d K=%d: %.3f ms/iteration = %.0f it/s  (X = %.0f MB; %s)" % (M, K, dt * 1e3, 1 / dt, X.numel() * 16 / 1e6, ", ".join(e)))
