@@ -60,6 +60,9 @@ def parse():
     p.add_argument("--cpu-reference-form", default="quarter", choices=["quarter", "full", "off"],
                    help="reference-form (materialising XX/R) CPU leg: on T/4 frames (default), the full shape, or not")
     p.add_argument("--with-loss", action="store_true", help="also report it/s with recordable_loss=True")
+    p.add_argument("--prewarm-ms", type=float, default=150.0,
+                   help="untimed load before the W warm-up steps: the clocks take ~100 ms of work to settle "
+                        "(20 timed steps after 5 / 50 / 500 warm-up steps: 0.2025 / 0.1986 / 0.1945 ms per step)")
     p.add_argument("--config5", default="auto", choices=["auto", "on", "off"],
                    help="config-5 leg (64 utterances sharded over the ranks); auto = only when N > 1")
     p.add_argument("--config5-utterances", type=int, default=64)
@@ -300,7 +303,18 @@ def main():
     def barrier():
         D.barrier(dev)
 
+    def prewarm(model):
+        """Bring the GPU to its steady state with the same work, before the contract's W warm-up steps."""
+        if args.prewarm_ms <= 0:
+            return
+        t_end = time.perf_counter() + args.prewarm_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(20):
+                model.update_once()
+            torch.cuda.synchronize(dev)
+
     def timed_steps(model, steps, warmup, with_loss=False):
+        prewarm(model)
         for _ in range(warmup):
             model.update_once()
             if with_loss:
@@ -391,6 +405,7 @@ def main():
             "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
+            "prewarm_ms": args.prewarm_ms,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
             "scaling": "weak",
