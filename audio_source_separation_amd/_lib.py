@@ -70,6 +70,7 @@ SIGNATURES = {
     "assx_ilrma_power_map": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_half_sums": (_i, [_vp, _i, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_apply_sums": (_i, [_vp, _i, _d, _d, _vp, _vp, _i, _ll, _i, _vp]),
+    "assx_ordered_sum": (_i, [_vp, _vp, _vp, _vp, _i, _ll, _i, _vp]),
     "assx_stft_num_frames": (_ll, [_ll, _i, _i]),
     "assx_istft_num_samples": (_ll, [_i, _i, _i]),
     "assx_stft_workspace_bytes": (_sz, [_i, _i, _i, _i]),

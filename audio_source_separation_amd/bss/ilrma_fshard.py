@@ -58,10 +58,15 @@ class HipShardOps:
         self.eng.ilrma_spatial_update(X, W, Tb, V, domain=domain, eps=eps, threshold=threshold, status=status, C=C,
                                       power_bins=pb)
 
-    def shard_power_sum(self, C, W, n_frames):
-        """sum over the shard's bins of w_n^H C_f w_n = F_shard * mean: (N,) float64."""
-        F = W.shape[1]
-        return self.eng.power_from_cov(C, W, n_frames)[0].to(torch.float64) * float(F)
+    def shard_power_mean(self, C, W, n_frames):
+        """mean over the shard's bins of w_n^H C_f w_n: (N,) in the compute dtype (weighted by the shard's bin count
+        when the shards are combined)."""
+        return self.eng.power_from_cov(C, W, n_frames)[0]
+
+    def ordered_sum(self, parts, weights=None):
+        """(S, ...) -> (...): fixed ascending order, in a kernel (no torch arithmetic on the data path)."""
+        w = None if weights is None else torch.tensor(weights, dtype=torch.float64, device=self.device)
+        return self.eng.ordered_sum(parts, w)
 
     def normalize(self, W, Tb, power, domain, eps):
         self.eng.ilrma_normalize_power(W, Tb, power, domain=domain, eps=eps)
@@ -113,17 +118,14 @@ class FrequencyShardedGaussILRMA:
         self.comm_device = comm_device if comm_device is not None else self.ops.device
 
     # ------------------------------------------------------------------ deterministic reductions over shards
-    def _ordered_sum(self, local_parts):
-        """Sum of one partial per shard, added in GLOBAL shard order on every rank."""
+    def _ordered_sum(self, local_parts, weights=None):
+        """Sum of one partial per shard (optionally weighted per shard), added in GLOBAL shard order on every rank."""
         t = torch.stack(local_parts).to(self.comm_device)
         if self.world > 1:
             parts = [torch.empty_like(t) for _ in range(self.world)]
             dist.all_gather(parts, t.contiguous())
             t = torch.cat(parts, dim=0)
-        acc = t[0].clone()
-        for s in range(1, t.shape[0]):
-            acc += t[s]
-        return acc.to(self.ops.device)
+        return self.ops.ordered_sum(t.to(self.ops.device), weights)
 
     # ------------------------------------------------------------------ driver
     def __call__(self, input, iteration=100, basis=None, activation=None):
@@ -195,13 +197,15 @@ class FrequencyShardedGaussILRMA:
             ops.spatial(Xs[i], Ws[i], Ts[i], V, self._Cs[i], d, eps, self.threshold, self._status)
         # ---- power normalisation: N scalars
         if self.normalize == 'power':
-            psum = self._ordered_sum([ops.shard_power_sum(self._Cs[i], Ws[i], self.n_frames) for i in range(len(Xs))])
-            power = (psum / float(self.n_bins)).to(ops.real).reshape(1, -1).contiguous()
+            # mean over all bins = sum_s (F_s / F) * mean over shard s
+            wts = [(hi - lo) / float(self.n_bins) for lo, hi in self._ranges]
+            power = self._ordered_sum([ops.shard_power_mean(self._Cs[i], Ws[i], self.n_frames) for i in range(len(Xs))],
+                                      weights=wts).reshape(1, -1).contiguous()
             for i in range(len(Xs)):
                 ops.normalize(Ws[i], Ts[i], power, d, eps)
 
     def compute_negative_loglikelihood(self):
-        parts = [self.ops.loss(self._Xs[i], self._Ws[i], self._Ts[i], self._V, self.domain, self.eps).reshape(())
+        parts = [self.ops.loss(self._Xs[i], self._Ws[i], self._Ts[i], self._V, self.domain, self.eps).reshape(1)
                  for i in range(len(self._Xs))]
         return float(self._ordered_sum(parts).item())
 

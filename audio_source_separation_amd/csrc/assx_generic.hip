@@ -168,6 +168,37 @@ int stack_gram_solve(assx_ctx* ctx, const void* A, size_t a_batch_stride, int na
 
 using namespace assx;
 
+// out[i] = sum_s w[s] * parts[s][i], s ascending (w == NULL: all ones).  The fixed-order combination of per-shard
+// partial sums after an all-gather (F-sharded mode): a ring / tree all-reduce may associate differently per rank.
+template <typename R>
+__global__ void __launch_bounds__(256) ordered_sum_kernel(const R* __restrict__ parts, const double* __restrict__ w,
+                                                         R* __restrict__ out, int S, size_t count) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  R acc = w ? (R)w[0] * parts[i] : parts[i];
+  for (int s = 1; s < S; ++s) acc += w ? (R)w[s] * parts[(size_t)s * count + i] : parts[(size_t)s * count + i];
+  out[i] = acc;
+}
+
+extern "C" int assx_ordered_sum(assx_ctx* ctx, const void* parts, const double* weights, void* out, int S,
+                                long long count, int dtype, void* stream) {
+  ASSX_REQUIRE_CTX(ctx);
+  ASSX_REQUIRE(ctx, S >= 1 && count >= 1, ASSX_E_ARG, "invalid sizes S=%d count=%lld", S, count);
+  ASSX_REQUIRE(ctx, parts && out, ASSX_E_NULL, "assx_ordered_sum: NULL array");
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned nb = (unsigned)(((size_t)count + 255) / 256);
+  if (dtype == ASSX_F64)
+    hipLaunchKernelGGL((ordered_sum_kernel<double>), dim3(nb), dim3(256), 0, st, (const double*)parts, weights,
+                       (double*)out, S, (size_t)count);
+  else if (dtype == ASSX_F32)
+    hipLaunchKernelGGL((ordered_sum_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)parts, weights,
+                       (float*)out, S, (size_t)count);
+  else
+    return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+  ASSX_LAUNCH_CHECK(ctx, "ordered_sum_kernel");
+  return 0;
+}
+
 extern "C" int assx_compute_demix_filter(assx_ctx* ctx, const void* Y, const void* X, void* W, int32_t* status, int B,
                                          int M, int F, int T, int dtype, void* stream) {
   ASSX_REQUIRE_CTX(ctx);

@@ -364,6 +364,18 @@ class Engine:
                                                 count, self.prec.code, self._st()), "assx_nmf_apply_sums")
         return A
 
+    def ordered_sum(self, parts, weights=None):
+        """sum over the leading axis of `parts` (S, ...) in ascending order, optionally weighted (float64 (S,))."""
+        S = int(parts.shape[0])
+        count = int(parts[0].numel())
+        if parts.dtype not in (torch.float64, torch.float32):
+            raise ValueError("ordered_sum: float64 / float32 only")
+        code = _lib.F64 if parts.dtype == torch.float64 else _lib.F32
+        out = torch.empty(parts.shape[1:], dtype=parts.dtype, device=self.dev)
+        self._check(self._L.assx_ordered_sum(self.ctx, ptr(parts.contiguous()), ptr(weights), ptr(out), S, count, code,
+                                             self._st()), "assx_ordered_sum")
+        return out
+
     # ------------------------------------------------------------------ NMF
     def _nmf_scratch(self, B, F, T, K):
         return self._ws.get(self._L.assx_nmf_workspace_bytes(B, F, T, K, self.prec.code))

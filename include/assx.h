@@ -305,6 +305,11 @@ int assx_nmf_half_sums(assx_ctx* ctx, int kind, double domain, double param, dou
                        void* stream);
 int assx_nmf_apply_sums(assx_ctx* ctx, int kind, double domain, double eps, void* A, const void* sums, int B,
                         long long count, int dtype, void* stream);
+/* out[i] = sum_{s=0}^{S-1} weights[s] * parts[s][i], added in ascending s (weights: device float64[S] or NULL = ones;
+ * parts (S, count), out (count) of `dtype`).  The combination step after an all-gather of per-shard partials: every
+ * rank gets the same bits, and the same bits as one process that holds all the shards. */
+int assx_ordered_sum(assx_ctx* ctx, const void* parts, const double* weights, void* out, int S, long long count,
+                     int dtype, void* stream);
 
 /* ---- (f3) STFT / iSTFT either side of the loop ---------------------------------------------- */
 /* stft / istft of src/transform/stft.py:4-17, i.e. scipy.signal.stft / istft with nperseg = fft_size,

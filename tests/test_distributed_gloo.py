@@ -163,9 +163,15 @@ class OracleShardOps:
                                                threshold)
         W[0].copy_(torch.from_numpy(Wn))
 
-    def shard_power_sum(self, C, W, n_frames):
+    def shard_power_mean(self, C, W, n_frames):
         Wn, Cn = W[0].numpy(), C[0].numpy()
-        return torch.from_numpy(np.einsum("fnm,fml,fnl->n", Wn, Cn, Wn.conj()).real.copy())
+        return torch.from_numpy(np.einsum("fnm,fml,fnl->n", Wn, Cn, Wn.conj()).real.copy() / Wn.shape[0])
+
+    def ordered_sum(self, parts, weights=None):
+        acc = parts[0].clone() * (1.0 if weights is None else weights[0])
+        for s in range(1, parts.shape[0]):
+            acc += parts[s] * (1.0 if weights is None else weights[s])
+        return acc
 
     def normalize(self, W, Tb, power, domain, eps):
         a = np.sqrt(power[0].numpy())
@@ -174,7 +180,7 @@ class OracleShardOps:
         Tb[0].div_(torch.from_numpy(a ** domain)[:, None, None])
 
     def loss(self, X, W, Tb, V, domain, eps):
-        return torch.tensor(orc.ilrma_loss(X[0].numpy(), W[0].numpy(), Tb[0].numpy(), V[0].numpy(), domain, eps))
+        return torch.tensor([orc.ilrma_loss(X[0].numpy(), W[0].numpy(), Tb[0].numpy(), V[0].numpy(), domain, eps)])
 
     def output(self, X, W, ref, status):
         Y = orc.separate(X[0].numpy(), W[0].numpy())
