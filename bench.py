@@ -67,6 +67,7 @@ def parse():
                    help="config-5 leg (64 utterances sharded over the ranks); auto = only when N > 1")
     p.add_argument("--config5-utterances", type=int, default=64)
     p.add_argument("--config5-iterations", type=int, default=100)
+    p.add_argument("--config5-timeout", type=int, default=420, help="seconds before the config-5 leg is abandoned")
     # test scaffolding (tests/test_gpu_multi.py): N ranks on ONE GPU with gloo-staged edges, so that the whole N > 1
     # flow of this file runs on a 1-GPU box.  Never used for a reported number.
     p.add_argument("--comm-backend", default="nccl", choices=["nccl", "gloo"])
@@ -382,21 +383,12 @@ def main():
         extra["value_with_loss"] = n_gpus * B * args.steps / dt
         del ml
 
-    # ---------------- config 5: sharded batch of utterances with and without the RCCL edges
-    config5 = None
-    if args.config5 == "on" or (args.config5 == "auto" and n_gpus > 1):
-        del model
-        torch.cuda.empty_cache()
-        try:
-            config5 = config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K)
-        except Exception as exc:  # the headline line must survive a failure of this leg
-            config5 = {"error": "%s: %s" % (type(exc).__name__, exc)}
-
     # ---------------- CPU baseline: the NumPy oracle on the same workload (rank 0, N=1 only)
     cpu_baseline = None
     if rank == 0 and n_gpus == 1 and args.cpu_iters > 0:
         cpu_baseline = cpu_baseline_leg(args, X[0].cpu().numpy(), M, F, T, K)
 
+    out = None
     if rank == 0:
         out = {
             "metric": "ILRMA iterations/sec (4ch, F=1025, T=4096)",
@@ -420,9 +412,38 @@ def main():
             "roofline_b8": roofline_b8,
             "cpu_baseline": cpu_baseline,
         }
-        if config5 is not None:
-            out["config5"] = config5
         out.update(extra)
+
+    # ---------------- config 5: sharded batch of utterances with and without the RCCL edges.  The headline
+    # measurement above is complete at this point; a watchdog makes sure its line is printed even if a point-to-point
+    # edge of this leg were to hang (rank 0 prints the line with config5.error, every rank leaves).
+    if args.config5 == "on" or (args.config5 == "auto" and n_gpus > 1):
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["config5"] = {"error": "timeout after %d s (the headline measurement is unaffected)" % args.config5_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.config5_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        del model
+        torch.cuda.empty_cache()
+        try:
+            config5 = config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K)
+        except Exception as exc:  # the headline line must survive a failure of this leg
+            config5 = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        dog.cancel()
+        if rank == 0:
+            out["config5"] = config5
+        if config5 is not None and "error" in config5:  # peers may be stuck in a collective: no farewell barrier
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+    if rank == 0:
         print(json.dumps(out), flush=True)
 
     if world > 1:
