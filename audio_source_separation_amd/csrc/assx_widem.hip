@@ -67,32 +67,49 @@ __global__ void __launch_bounds__(256) demix_map_kernel(const Cx<R>* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Weighted covariance of one bin per workgroup.  Wave w accumulates sources n = w, w + 4, ... one after the other
-// (a source's packed Hermitian sums fill the wave's registers: 36 complex at M = 8), lanes own frames; X_f is re-read
-// from L2 per source.  U[b,n,f] = (1/T) sum_t x x^H / max(r_n, eps), dense output.
+// Weighted covariance of one bin per workgroup, one wave per source (a source's packed Hermitian sums fill the wave's
+// registers: 36 complex at M = 8), lanes own frames; the N waves walk X_f together (HBM once, L1 for the others: with
+// 4 waves taking two sources each the bin's rows were streamed from HBM twice -- 461 us at M = 8, the traffic floor).  U[b,n,f] = (1/T) sum_t x x^H / max(r_n, eps), dense output.
 // ------------------------------------------------------------------------------------------------------------------
 enum { RK_NONE = 0, RK_NT = 1, RK_NFT = 2 };
 
 template <typename R, int M>
-__global__ void __launch_bounds__(256) cov_bin_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ r, int r_kind,
+__global__ void __launch_bounds__(512) cov_bin_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ r, int r_kind,
                                                      int N, R eps, Cx<R>* __restrict__ U, int F, int T, R inv_T) {
   constexpr int NH = M * (M + 1) / 2;
   const int f = blockIdx.x, b = blockIdx.y;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const size_t FT = (size_t)F * T;
   const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * T;
-  for (int n = wave; n < N; n += 4) {
+  const int nwaves = blockDim.x >> 6;  // = N for the weighted forms: every source's wave walks X_f at the same time, so
+                                       // the bin's rows come from HBM once and from L1 for the other N - 1 waves
+  for (int n = wave; n < N; n += nwaves) {
     const R* rn = nullptr;
     if (r_kind == RK_NT) rn = r + ((size_t)b * N + n) * T;
     else if (r_kind == RK_NFT) rn = r + ((size_t)b * N + n) * FT + (size_t)f * T;
     R ar[NH], ai[NH];
 #pragma unroll
     for (int q = 0; q < NH; ++q) ar[q] = ai[q] = 0;
+    // one block of register prefetch: the loads of frame t + 64 travel while frame t is accumulated (without it the
+    // 2 waves per SIMD exposed an L2 round trip per block: 461 us at M = 8, config-4 bins / frames)
+    Cx<R> xn[M];
+    R rnext = (R)1;
+    if (lane < T) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) xn[m] = xb[m * FT + lane];
+      if (rn) rnext = rn[lane];
+    }
     for (int t = lane; t < T; t += WAVE) {
       Cx<R> x[M];
 #pragma unroll
-      for (int m = 0; m < M; ++m) x[m] = xb[m * FT + t];
-      const R wgt = rn ? fast_rcp(floor_eps<R>(rn[t], eps)) : (R)1;
+      for (int m = 0; m < M; ++m) x[m] = xn[m];
+      const R rcur = rnext;
+      if (t + WAVE < T) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) xn[m] = xb[m * FT + t + WAVE];
+        if (rn) rnext = rn[t + WAVE];
+      }
+      const R wgt = rn ? fast_rcp(floor_eps<R>(rcur, eps)) : (R)1;
       int q = 0;
 #pragma unroll
       for (int i = 0; i < M; ++i) {
@@ -289,7 +306,7 @@ static int launch_demix(assx_ctx* ctx, const void* X, const void* W, const void*
 template <typename R, int M>
 static int launch_cov(assx_ctx* ctx, const void* X, const void* r, int r_kind, int N, double eps, void* U, int B, int F,
                       int T, hipStream_t st) {
-  hipLaunchKernelGGL((cov_bin_kernel<R, M>), dim3(F, B), dim3(256), 0, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
+  hipLaunchKernelGGL((cov_bin_kernel<R, M>), dim3(F, B), dim3(64 * (N > 1 ? N : 4)), 0, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
                      (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T));
   ASSX_LAUNCH_CHECK(ctx, "widem::cov_bin_kernel");
   return 0;
