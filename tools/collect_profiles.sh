@@ -32,5 +32,7 @@ py $ROOT/tools/pmc_traffic.py collect > /dev/null 2>&1
 py $ROOT/tools/pmc_traffic.py report > $OUT/cov_traffic.json 2>&1
 cp $ROOT/profiles/cov_traffic.json $OUT/cov_traffic.json 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/mfma_f64_rate_probe.hip -o /tmp/mfma_rate && /tmp/mfma_rate > $OUT/mfma_rate_probe.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/valu_f64_rate_probe.hip -o /tmp/valu_rate && /tmp/valu_rate > $OUT/valu_f64_rate_probe.txt
+py $ROOT/tools/widem_bench.py > $OUT/widem_bench.txt 2>/dev/null
 rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] 2>/dev/null
 ls -la $OUT
