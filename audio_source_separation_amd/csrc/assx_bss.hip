@@ -1385,6 +1385,8 @@ int assx_ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const voi
                "assx_ilrma_source_update_partitioned: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M))
+    return widem::ilrma_source_update_partitioned(ctx, X, W, Z, Tb, V, Teff, Veff, eps, ws, B, M, F, T, K, dtype, st);
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
@@ -1475,6 +1477,8 @@ int assx_ilrma_normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z,
                "assx_ilrma_normalize_power_bins_partitioned: NULL array");
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M))
+    return widem::normalize_power_bins_partitioned(ctx, W, Z, Tb, power_bins, eps, ws, B, M, F, K, dtype, st);
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
@@ -1654,9 +1658,8 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
   ASSX_REQUIRE(ctx, X && W && Tb && V && loss && ws, ASSX_E_NULL, "%s: NULL array", who);
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   if (widem::handles(M)) {
-    ASSX_REQUIRE(ctx, nu < 0.0, ASSX_E_UNSUPPORTED, "%s: t-ILRMA is not on the wide-channel path (M = %d > 4)", who, M);
     if (wrote_P) *wrote_P = false;
-    return widem::ilrma_loss(ctx, X, W, Tb, V, domain, eps, loss, ws, B, M, F, T, K, dtype, (hipStream_t)stream);
+    return widem::ilrma_loss(ctx, X, W, Tb, V, domain, eps, loss, ws, B, M, F, T, K, dtype, (hipStream_t)stream, nu);
   }
   hipStream_t st = (hipStream_t)stream;
   const WsLayout L = ws_layout(B, M, F, T, K, dtype);
@@ -1750,6 +1753,7 @@ int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void*
   ASSX_REQUIRE(ctx, K >= 1, ASSX_E_ARG, "n_basis must be >= 1, got %d", K);
   ASSX_REQUIRE(ctx, nu >= 0.0, ASSX_E_ARG, "nu must be >= 0, got %g", nu);
   hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M)) return widem::tilrma_source_update(ctx, X, W, Tb, V, nu, eps, ws, B, M, F, T, K, dtype, st);
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
@@ -1790,6 +1794,8 @@ int assx_tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void
   ASSX_REQUIRE(ctx, (C == nullptr) == (power_bins == nullptr), ASSX_E_ARG,
                "assx_tilrma_spatial_update: C and power_bins must be given together");
   hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M))
+    return widem::tilrma_spatial_update(ctx, X, W, Tb, V, nu, eps, Xi, C, power_bins, status, ws, B, M, F, T, K, dtype, st);
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;

@@ -2,6 +2,8 @@
 // points in include/assx.h; the arithmetic contract (floors, exponents, Gauss-Seidel order) is the M <= 4 path's.
 #include "assx_widem.hpp"
 #include "assx_group_linalg.hpp"
+#include "assx_nmf_internal.hpp"
+#include "assx_partition.hpp"
 
 namespace assx {
 namespace widem {
@@ -155,6 +157,16 @@ __global__ void __launch_bounds__(256) variance_map_kernel(const R* __restrict__
   Rm[((size_t)bn * F + f) * T + t] = powspec<R>(tv, p2d);
 }
 
+// t-ILRMA: Xi = (nu R + 2 P) / (nu + 2) in place of R (R floored first, Xi itself is not: ilrma.py:945-966)
+template <typename R>
+__global__ void __launch_bounds__(256) xi_map_kernel(const R* __restrict__ P, R* __restrict__ Rm, size_t count, R nu,
+                                                    R eps) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const R r = floor_eps<R>(Rm[i], eps);
+  Rm[i] = fma(nu, r, (R)2 * P[i]) / (nu + (R)2);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // deterministic reductions over the maps
 // ------------------------------------------------------------------------------------------------------------------
@@ -168,11 +180,12 @@ __device__ __forceinline__ double block_sum(double s, double* sm) {
   return sm[0];
 }
 
-// out[row * ostride + blockIdx.x] = sum over this block's chunk of a[row][.]  (TERM: P/R + log R of two maps)
-template <typename R, bool TERM>
+// out[row * ostride + blockIdx.x] = sum over this block's chunk of a[row][.]
+//   TERM 1: P/R + log R of two maps (ilrma.py:648-677);  TERM 2: (1 + nu/2) log(1 + (2/nu) P/R) + log R (ilrma.py:991-1018)
+template <typename R, int TERM>
 __global__ void __launch_bounds__(RED_THREADS) map_sum_kernel(const R* __restrict__ a, const R* __restrict__ rm,
                                                              double* __restrict__ out, size_t elems, int ostride,
-                                                             R eps) {
+                                                             R eps, R nu) {
   __shared__ double sm[RED_THREADS];
   const size_t row = blockIdx.y;
   const size_t chunk = (elems + gridDim.x - 1) / gridDim.x;
@@ -181,9 +194,12 @@ __global__ void __launch_bounds__(RED_THREADS) map_sum_kernel(const R* __restric
   const R* pr = TERM ? rm + row * elems : nullptr;
   double s = 0.0;
   for (size_t i = i0 + threadIdx.x; i < i1; i += RED_THREADS) {
-    if (TERM) {
+    if (TERM == 1) {
       const R rr = floor_eps<R>(pr[i], eps);
       s += (double)(pa[i] / rr) + log((double)rr);
+    } else if (TERM == 2) {
+      const R rr = floor_eps<R>(pr[i], eps);
+      s += (1.0 + 0.5 * (double)nu) * log1p((2.0 / (double)nu) * (double)(pa[i] / rr)) + log((double)rr);
     } else {
       s += (double)pa[i];
     }
@@ -314,12 +330,12 @@ static int launch_cov(assx_ctx* ctx, const void* X, const void* r, int r_kind, i
 
 template <typename R, int M>
 static int launch_sweep(assx_ctx* ctx, int spatial, int pm, int pn, const void* U, void* W, const void* C, double* pw,
-                        double thr, int32_t* status, int B, int F, int T, hipStream_t st) {
+                        double thr, int32_t* status, int B, int F, int T, hipStream_t st, double den_floor = 0.0) {
   const dim3 grid((unsigned)((size_t)B * F)), block(64);  // 64 lanes = one bin (GW = 64 for M >= 5)
   const FlatPart fp{};
   if (spatial == ASSX_SPATIAL_IP)
     hipLaunchKernelGGL((ip_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
-                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, 0.0);
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor);
   else if (spatial == ASSX_SPATIAL_ISS)
     hipLaunchKernelGGL((iss_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
                        (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, B, F);
@@ -344,11 +360,15 @@ static int launch_variance(assx_ctx* ctx, const void* Tb, const void* V, void* R
 // loss[b] = sum_{n,f,t} P/R + log R  -  2 T sum_f log|det W_f|, from the maps already in ws
 template <typename R, int M>
 static int loss_from_maps(assx_ctx* ctx, const Ws& L, const void* W, double eps, double* loss, void* ws, int B, int F,
-                          int T, hipStream_t st) {
+                          int T, hipStream_t st, double nu = -1.0) {
   double* lpart = (double*)((char*)ws + L.lpart);
   const int lstride = RB + F;
-  hipLaunchKernelGGL((map_sum_kernel<R, true>), dim3(RB, B), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
-                     (const R*)((char*)ws + L.map1), lpart, (size_t)M * F * T, lstride, (R)eps);
+  if (nu >= 0.0)  // Student-t term (t-ILRMA)
+    hipLaunchKernelGGL((map_sum_kernel<R, 2>), dim3(RB, B), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
+                       (const R*)((char*)ws + L.map1), lpart, (size_t)M * F * T, lstride, (R)eps, (R)nu);
+  else
+    hipLaunchKernelGGL((map_sum_kernel<R, 1>), dim3(RB, B), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
+                       (const R*)((char*)ws + L.map1), lpart, (size_t)M * F * T, lstride, (R)eps, (R)0);
   ASSX_LAUNCH_CHECK(ctx, "widem::map_sum_kernel(loss)");
   hipLaunchKernelGGL((logdet_kernel<R, M>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B, F,
                      T, lstride, RB);
@@ -407,7 +427,7 @@ int ip2_update(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* statu
 }
 
 int ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain, double eps,
-               double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st) {
+               double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st, double nu) {
   const Ws L = layout(B, M, F, T, K, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
@@ -415,7 +435,45 @@ int ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, cons
     int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
     if (rc) return rc;
     if ((rc = launch_variance<R>(ctx, Tb, V, (char*)ws + L.map1, domain, B * MM, F, T, K, st))) return rc;
-    return loss_from_maps<R, MM>(ctx, L, W, eps, loss, ws, B, F, T, st);
+    return loss_from_maps<R, MM>(ctx, L, W, eps, loss, ws, B, F, T, st, nu);
+  });
+}
+
+// t-ILRMA (ilrma.py:899-983) on the maps: the tNMF-type update with the raw power map as target, and IP on the
+// covariance weighted by Xi = (nu R + 2 P) / (nu + 2)
+int tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double nu, double eps, void* ws,
+                         int B, int M, int F, int T, int K, int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, K, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    void* P = (char*)ws + L.map0;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);
+    if (rc) return rc;
+    NmfGroupScope grp(ctx, MM);
+    return assx_nmf_update_ex(ctx, ASSX_NMF_T_RAW, 2.0, nu, eps, P, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype, st);
+  });
+}
+
+int tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double nu, double eps,
+                          void* Xi, const void* C, double* power_bins, int32_t* status, void* ws, int B, int M, int F,
+                          int T, int K, int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, K, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    void* P = (char*)ws + L.map0;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // with the filters BEFORE the sweep
+    if (rc) return rc;
+    if ((rc = launch_variance<R>(ctx, Tb, V, Xi, 2.0, B * MM, F, T, K, st))) return rc;
+    const size_t count = (size_t)B * MM * F * T;
+    hipLaunchKernelGGL((xi_map_kernel<R>), dim3(nblk(count, 256)), dim3(256), 0, st, (const R*)P, (R*)Xi, count, (R)nu,
+                       (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "widem::xi_map_kernel");
+    void* U = (char*)ws + L.u;
+    // Xi is used as is (the reference does not floor it); no condition-number guard, normaliser floored at eps
+    if ((rc = launch_cov<R, MM>(ctx, X, Xi, RK_NFT, MM, 0.0, U, B, F, T, st))) return rc;
+    return launch_sweep<R, MM>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, C, power_bins, INFINITY, status, B, F, T, st, eps);
   });
 }
 
@@ -471,6 +529,83 @@ int ilrma_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void*
   });
 }
 
+// Partitioning function (ilrma.py:368-408) on the maps: the route the M <= 4 path takes for n_basis > 4 -- the three
+// sets of per-source sums come from the NMF half kernels on P = |W x|^2 with the effective model (batch B*N), the
+// adapters lay them out as one record per bin / per frame block, the combination kernels of assx_partition.hpp fold
+// them.  The adapter records live in the (idle) variance-map region.
+int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W, void* Z, void* Tb, void* V, void* Teff,
+                                    void* Veff, double eps, void* ws, int B, int M, int F, int T, int K, int dtype,
+                                    hipStream_t st) {
+  const Ws L = layout(B, M, F, T, K, dtype);
+  if (K > 64) return fail(ctx, ASSX_E_UNSUPPORTED, "partitioning with M = %d > 4 needs n_basis <= 64, got %d", M, K);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const size_t nT = (size_t)B * MM * F * K, nV = (size_t)B * MM * K * T;
+    auto expand = [&](bool with_v) -> int {
+      hipLaunchKernelGGL((part_expand_kernel<R>), dim3(nblk(with_v ? nT + nV : nT, 256)), dim3(256), 0, st, (const R*)Z,
+                         (const R*)Tb, (const R*)V, (R*)Teff, with_v ? (R*)Veff : (R*)nullptr, B, MM, F, K, T);
+      ASSX_LAUNCH_CHECK(ctx, "part_expand_kernel");
+      return 0;
+    };
+    void* P = (char*)ws + L.map0;
+    R* rec = (R*)((char*)ws + L.map1);
+    void* nws = (char*)ws + L.nmf;
+    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // W does not move here: P once
+    if (rc) return rc;
+    const int TBk = (T + WAVE - 1) / WAVE;
+    const FlatPart fpb{(long long)F * TBk, TBk, TBk, B * F, 1, F, F};      // one record per bin
+    const FlatPart fpa{(long long)TBk * F, F, F, B * TBk, 1, TBk, TBk};    // one record per frame block
+    auto sums = [&](int half) -> int {
+      const void* np = nullptr;
+      int slabs = 0;
+      NmfGroupScope grp(ctx, MM);
+      int r2 = nmf_half_partials(ctx, ASSX_NMF_IS_MM, 2.0, 0.0, eps, half, P, Teff, Veff, nws, B * MM, F, T, K, dtype, st,
+                                 &np, &slabs);
+      if (r2) return r2;
+      if (half == NMF_HALF_BASIS)
+        hipLaunchKernelGGL((part_adapt_basis_kernel<R>), dim3(nblk((size_t)B * F * MM * 2 * K, 256)), dim3(256), 0, st,
+                           (const R*)np, rec, B, MM, F, K, slabs);
+      else
+        hipLaunchKernelGGL((part_adapt_act_kernel<R>), dim3(nblk((size_t)B * TBk * MM * 2 * K * WAVE, 256)), dim3(256), 0,
+                           st, (const R*)np, rec, B, MM, K, T, slabs);
+      ASSX_LAUNCH_CHECK(ctx, "part_adapt_kernel");
+      return 0;
+    };
+    if ((rc = expand(true))) return rc;
+    if ((rc = sums(NMF_HALF_BASIS))) return rc;
+    hipLaunchKernelGGL((part_latent_kernel<R, MM>), dim3(K, B), dim3(256), 0, st, (const R*)rec, (const R*)Tb, (R*)Z, F, K,
+                       fpb, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_latent_kernel");
+    if ((rc = expand(false))) return rc;
+    if ((rc = sums(NMF_HALF_BASIS))) return rc;
+    hipLaunchKernelGGL((part_basis_kernel<R>), dim3(nblk((size_t)B * F * K, 256)), dim3(256), 0, st, (const R*)rec,
+                       (const R*)Z, (R*)Tb, B, MM, F, K, fpb, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_basis_kernel");
+    if ((rc = expand(false))) return rc;
+    if ((rc = sums(NMF_HALF_ACT))) return rc;
+    hipLaunchKernelGGL((part_act_kernel<R>), dim3(nblk((size_t)B * K * T, 256)), dim3(256), 0, st, (const R*)rec, (R*)V, B,
+                       MM, F, K, T, fpa, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_act_kernel");
+    return expand(true);  // leave (Teff, Veff) consistent with the updated (Z, T, V)
+  });
+}
+
+int normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins, double eps,
+                                     void* ws, int B, int M, int F, int K, int dtype, hipStream_t st) {
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    const size_t per_b = (size_t)F * MM * MM + (size_t)F * K;
+    hipLaunchKernelGGL((part_normalize_power_kernel<R, MM>), dim3(nblk(per_b, 256), B), dim3(256), (size_t)K * sizeof(R),
+                       st, (Cx<R>*)W, (R*)ws, (const R*)Z, (R*)Tb, power_bins, F, K, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "part_normalize_power_kernel");
+    hipError_t e = hipMemcpyAsync(Z, ws, (size_t)B * MM * K * sizeof(R), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return fail(ctx, (int)e, "hipMemcpyAsync(Z): %s", hipGetErrorString(e));
+    return 0;
+  });
+}
+
 int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* ws, int B, int M, int F, int T,
                 int dtype, hipStream_t st) {
   const Ws L = layout(B, M, F, T, 1, dtype);
@@ -480,8 +615,8 @@ int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* 
     int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
     if (rc) return rc;
     double* part = (double*)((char*)ws + L.lpart);
-    hipLaunchKernelGGL((map_sum_kernel<R, false>), dim3(RB, B * MM), dim3(RED_THREADS), 0, st,
-                       (const R*)((char*)ws + L.map0), (const R*)nullptr, part, (size_t)F * T, RB, (R)0);
+    hipLaunchKernelGGL((map_sum_kernel<R, 0>), dim3(RB, B * MM), dim3(RED_THREADS), 0, st,
+                       (const R*)((char*)ws + L.map0), (const R*)nullptr, part, (size_t)F * T, RB, (R)0, (R)0);
     ASSX_LAUNCH_CHECK(ctx, "widem::map_sum_kernel(power)");
     hipLaunchKernelGGL((row_sum_kernel<R>), dim3(B * MM), dim3(RED_THREADS), 0, st, (const double*)part, (R*)power, RB,
                        RB, 1.0 / ((double)F * (double)T));

@@ -40,12 +40,24 @@ int ilrma_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void*
                          const void* V, double domain, double eps, double thr, void* U_out, const void* C,
                          double* power_bins, int32_t* status, void* ws, int B, int M, int F, int T, int K, int dtype,
                          hipStream_t st);                                                     // assx_ilrma_spatial_update
+int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W, void* Z, void* Tb, void* V, void* Teff,
+                                    void* Veff, double eps, void* ws, int B, int M, int F, int T, int K, int dtype,
+                                    hipStream_t st);                          // assx_ilrma_source_update_partitioned
+int normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins, double eps,
+                                     void* ws, int B, int M, int F, int K, int dtype,
+                                     hipStream_t st);                         // assx_ilrma_normalize_power_bins_partitioned
 int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* ws, int B, int M, int F, int T,
                 int dtype, hipStream_t st);                                                   // assx_demix_power
 int power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power, void* ws, int B, int M, int F, int dtype,
                    hipStream_t st);                                                           // assx_power_from_cov
 int ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, const void* V, double domain, double eps,
-               double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st);  // assx_ilrma_loss
+               double* loss, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st,
+               double nu = -1.0);                          // assx_ilrma_loss; nu >= 0: assx_tilrma_loss
+int tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, void* V, double nu, double eps, void* ws,
+                         int B, int M, int F, int T, int K, int dtype, hipStream_t st);       // assx_tilrma_source_update
+int tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb, const void* V, double nu, double eps,
+                          void* Xi, const void* C, double* power_bins, int32_t* status, void* ws, int B, int M, int F,
+                          int T, int K, int dtype, hipStream_t st);                           // assx_tilrma_spatial_update
 int auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, double eps, void* r, double* loss, void* ws,
                    int B, int M, int F, int T, int dtype, hipStream_t st);                     // assx_auxiva_weights
 int auxiva_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void* X, void* W, const void* r, double eps,

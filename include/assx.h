@@ -26,8 +26,8 @@
  *     complex = interleaved (re, im) of the real type selected by `dtype`.
  *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 8 -- M <= 4 on the streaming
  *     kernels (every entry point), 5 <= M <= 8 on the wide-channel path (csrc/assx_widem.hpp: materialised |W x|^2 /
- *     variance maps, one workgroup per bin; every Gauss-ILRMA / AuxIVA / projection-back entry point, IP, ISS and
- *     IP2; t-ILRMA and the partitioning function return ASSX_E_UNSUPPORTED there).  One utterance must stay below
+ *     variance maps, one workgroup per bin; every Gauss-ILRMA / AuxIVA / t-ILRMA / projection-back entry point, IP,
+ *     ISS and IP2, the partitioning function with n_basis <= 64).  One utterance must stay below
  *     4 GiB in complex128 (M*F*T < 2^28: in-kernel buffer offsets are 32-bit), any number of utterances.
  *   - dtype: ASSX_F32 (float / complex64) or ASSX_F64 (double / complex128 = the reference's).
  *   - `ws` is caller-owned device scratch of at least assx_workspace_bytes() bytes.

@@ -369,10 +369,11 @@ def gen_ip2():
 # ----------------------------------------------------------------------------
 # G6c: partitioning function (shared bases + latent Z)   (ilrma.py:79-95, 368-408, 313-320)
 # ----------------------------------------------------------------------------
-def gen_part(cases=((2, 3, "power", "IP"), (3, 4, "power", "IP"), (4, 4, False, "IP"), (3, 3, "power", "ISS")), seed=800):
+def gen_part(cases=((2, 3, "power", "IP"), (3, 4, "power", "IP"), (4, 4, False, "IP"), (3, 3, "power", "ISS")), seed=800,
+             shape=(17, 48)):
     for M, K, normalize, alg in cases:
         seed += 1
-        F, T = 17, 48
+        F, T = shape
         X = convolutive_mixture(M, F, T, seed=seed)
         np.random.seed(seed)
         state = np.random.get_state()
@@ -402,11 +403,11 @@ def gen_part(cases=((2, 3, "power", "IP"), (3, 4, "power", "IP"), (4, 4, False, 
 # ----------------------------------------------------------------------------
 # G6d: t-ILRMA (ilrma.py:713-1020)
 # ----------------------------------------------------------------------------
-def gen_tilrma():
-    seed = 900
-    for M, K, nu, normalize in [(2, 2, 1, "power"), (3, 4, 5, "power"), (4, 4, 100, "power"), (4, 6, 2.5, False)]:
+def gen_tilrma(cases=((2, 2, 1, "power"), (3, 4, 5, "power"), (4, 4, 100, "power"), (4, 6, 2.5, False)), seed=900,
+               shape=(17, 72)):
+    for M, K, nu, normalize in cases:
         seed += 1
-        F, T = 17, 72
+        F, T = shape
         X = convolutive_mixture(M, F, T, seed=seed)
         np.random.seed(seed)
         state = np.random.get_state()
@@ -687,6 +688,12 @@ def gen_wide_m():
          update_pair=np.asarray(model.update_pair), **snap.data)
 
 
+def gen_wide_variants():
+    """partitioning=True and tILRMA beyond 4 channels (the wide-channel path; same file formats as the M <= 4 groups)."""
+    gen_part(cases=((5, 3, "power", "IP"), (6, 10, "power", "ISS")), seed=1600, shape=(13, 256))
+    gen_tilrma(cases=((5, 3, 5, "power"), (6, 10, 1, "power")), seed=1700, shape=(13, 256))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
         for name in sys.argv[1:]:
@@ -709,3 +716,4 @@ if __name__ == "__main__":
     gen_part_k10()
     gen_f4()
     gen_wide_m()
+    gen_wide_variants()

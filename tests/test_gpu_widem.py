@@ -1,7 +1,7 @@
 """Wide-channel path (5 <= M <= 8, csrc/assx_widem.hip): every C-ABI entry point it serves against the oracle on
 seeded inputs, float64 and float32, ragged sizes, batched == single.  The reference is generic in M
 (src/bss/ilrma.py:61-62); model-level parity on the reference's own outputs is in test_gpu_models.py
-(fixtures ilrma_m5 / m6 / m8, auxiva_*_m5 / m6, iss_*_m5, ip2_*_m5 / m6)."""
+(fixtures ilrma_m5 / m6 / m8, auxiva_*_m5 / m6, iss_*_m5, ip2_*_m5 / m6, part_ilrma_m5 / m6, tilrma_m5 / m6)."""
 import numpy as np
 import pytest
 
@@ -147,6 +147,59 @@ def test_auxiva_stages(eng, kind, M):
     assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-9, 2e-3)
 
 
+@pytest.mark.parametrize("M,K,nu", [(5, 3, 5.0), (7, 10, 1.0)])
+def test_tilrma_stages(eng, M, K, nu):
+    """t-ILRMA beyond 4 channels (ilrma.py:899-1018): source update, spatial update (returns Xi), loss -- each against
+    the oracle from the same state; two utterances in one call == one at a time."""
+    F, T = 6, 260
+    rng = np.random.default_rng(70 + M)
+    Xs = np.stack([mixture(M, F, T, 71 + M), mixture(M, F, T, 72 + M)])
+    W = np.stack([rand_filters(M, F, 73), rand_filters(M, F, 74)])
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Xb, Wb, Tbd, Vbd = dev_c(eng, Xs), dev_c(eng, W), dev_r(eng, Tb), dev_r(eng, V)
+    loss = host(eng.tilrma_loss(Xb, Wb, Tbd, Vbd, nu))
+    eng.tilrma_source_update(Xb, Wb, Tbd, Vbd, nu)
+    Xi = eng.empty((2, M, F, T))
+    st = eng.new_status(2)
+    Wn = eng.tilrma_spatial_update(Xb, Wb.clone(), Tbd, Vbd, nu, Xi, status=st)
+    assert int(st.sum().item()) == 0
+    for b in range(2):
+        assert abs(loss[b] - orc.tilrma_loss(Xs[b], W[b], Tb[b], V[b], nu)) < tol(eng, 1e-10, 1e-4) * abs(loss[b])
+        P = np.abs(orc.separate(Xs[b], W[b])) ** 2
+        Tr, Vr = orc.tilrma_source_update(P, Tb[b], V[b], nu)
+        assert rel_err(host(Tbd)[b], Tr) < tol(eng, 1e-10, 2e-4)
+        assert rel_err(host(Vbd)[b], Vr) < tol(eng, 1e-10, 2e-4)
+        Wr, _ = orc.tilrma_spatial_update(Xs[b], W[b], host(Tbd)[b], host(Vbd)[b], nu)
+        assert rel_err(host(Wn)[b], Wr) < tol(eng, 1e-9, 5e-3)
+        # one at a time: bit-identical
+        W1, T1, V1 = dev_c(eng, W[b:b + 1]), dev_r(eng, Tb[b:b + 1]), dev_r(eng, V[b:b + 1])
+        eng.tilrma_source_update(Xb[b:b + 1], W1, T1, V1, nu)
+        W1n = eng.tilrma_spatial_update(Xb[b:b + 1], W1, T1, V1, nu, eng.empty((1, M, F, T)), status=eng.new_status(1))
+        assert torch.equal(T1[0], Tbd[b]) and torch.equal(V1[0], Vbd[b]) and torch.equal(W1n[0], Wn[b])
+
+
+@pytest.mark.parametrize("M,K", [(5, 3), (8, 10)])
+def test_partitioned_source_update(eng, M, K):
+    """partitioning=True beyond 4 channels (ilrma.py:368-408): Z, T, V after one source update against the oracle."""
+    F, T = 7, 200
+    rng = np.random.default_rng(80 + M)
+    X = mixture(M, F, T, 81 + M)
+    W = rand_filters(M, F, 82)
+    Z = rng.random((M, K)) * 1e-2 + 1 / M
+    Z = Z / Z.sum(axis=0)
+    Tb, V = rng.random((F, K)) + 0.05, rng.random((K, T)) + 0.05
+    Zd, Td, Vd = dev_r(eng, Z[None]), dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    Teff, Veff = eng.empty((1, M, F, K)), eng.empty((1, M, K, T))
+    eng.ilrma_source_update_partitioned(dev_c(eng, X[None]), dev_c(eng, W[None]), Zd, Td, Vd, Teff, Veff)
+    P = np.abs(orc.separate(X, W)) ** 2
+    Zr, Tr, Vr = orc.part_source_update(P, Z, Tb, V)
+    assert rel_err(host(Zd)[0], Zr) < tol(eng, 1e-10, 2e-4)
+    assert rel_err(host(Td)[0], Tr) < tol(eng, 1e-10, 2e-4)
+    assert rel_err(host(Vd)[0], Vr) < tol(eng, 1e-10, 2e-4)
+    assert rel_err(host(Teff)[0], Zr[:, None, :] * Tr[None]) < tol(eng, 1e-10, 2e-4)
+    assert rel_err(host(Veff)[0], np.broadcast_to(Vr, (M, K, T))) < tol(eng, 1e-10, 2e-4)
+
+
 def test_batched_equals_single_and_unsupported_entry_points(eng):
     from audio_source_separation_amd._lib import AssxError
     M, F, T, K = 6, 7, 200, 3
@@ -164,9 +217,6 @@ def test_batched_equals_single_and_unsupported_entry_points(eng):
         eng.ilrma_source_update(X1, W1, T1, V1)
         eng.ilrma_spatial_update(X1, W1, T1, V1, status=eng.new_status(1))
         assert torch.equal(W1[0], Wb[b]) and torch.equal(T1[0], Tbd[b]) and torch.equal(V1[0], Vbd[b])
-    # t-ILRMA is not on the wide path: refused with a message, never a fallback
-    with pytest.raises(AssxError, match="2 <= M <= 4"):
-        eng.tilrma_source_update(Xb, Wb, Tbd, Vbd, 1.0)
     with pytest.raises(AssxError):
         eng.demix(dev_c(eng, np.zeros((1, 9, 3, 70), dtype=np.complex128)),
                   dev_c(eng, np.zeros((1, 3, 9, 9), dtype=np.complex128)))  # M = 9
