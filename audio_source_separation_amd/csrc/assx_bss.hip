@@ -888,8 +888,8 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
     return fail(ctx, ASSX_E_ARG, "dtype must be ASSX_F32 or ASSX_F64, got %d", dtype);
   }
   return fail(ctx, ASSX_E_UNSUPPORTED,
-              "this entry point supports 2 <= M <= 4 channels, got M=%d (5 <= M <= 8 is available for the Gauss-ILRMA / "
-              "AuxIVA / projection-back entry points, not for t-ILRMA or the partitioning function)", M);
+              "this entry point supports 2 <= M <= 4 channels, got M=%d (5 <= M <= 8 runs on the wide-channel path of the "
+              "model entry points; more than 8 channels are not supported)", M);
 }
 
 #define CHECK_COMMON(ctx, B, M, F, T)                                                        \
@@ -1826,6 +1826,23 @@ int assx_idlma_space_update(assx_ctx* ctx, const void* X, void* W, const void* d
   ASSX_REQUIRE(ctx, domain > 0.0, ASSX_E_ARG, "domain must be > 0, got %g", domain);
   ASSX_REQUIRE(ctx, domain == 2.0 || R_scratch, ASSX_E_NULL, "assx_idlma_space_update: R_scratch is needed for domain != 2");
   hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M)) {  // the same two steps on the wide-channel kernels
+    const void* r = dnn_output;
+    if (domain != 2.0) {
+      const size_t n = (size_t)B * M * F * T;
+      if (dtype == ASSX_F64)
+        hipLaunchKernelGGL((pow_map_kernel<double>), dim3(blocks_for(n, 256)), dim3(256), 0, st, (const double*)dnn_output,
+                           (double*)R_scratch, n, make_pow(2.0 / domain));
+      else if (dtype == ASSX_F32)
+        hipLaunchKernelGGL((pow_map_kernel<float>), dim3(blocks_for(n, 256)), dim3(256), 0, st, (const float*)dnn_output,
+                           (float*)R_scratch, n, make_pow(2.0 / domain));
+      else
+        return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+      ASSX_LAUNCH_CHECK(ctx, "pow_map_kernel");
+      r = R_scratch;
+    }
+    return widem::weighted_ip(ctx, X, r, eps, threshold, 0.0, W, status, ws, B, M, F, T, dtype, st);
+  }
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
@@ -1851,6 +1868,18 @@ int assx_fastmnmf_update_diagonalizer(assx_ctx* ctx, const void* X, void* Q, con
   ASSX_REQUIRE(ctx, X && Q && Lambda && g && R_scratch && ws, ASSX_E_NULL, "assx_fastmnmf_update_diagonalizer: NULL array");
   ASSX_REQUIRE(ctx, N >= 1, ASSX_E_ARG, "n_sources must be >= 1, got %d", N);
   hipStream_t st = (hipStream_t)stream;
+  if (widem::handles(M)) {
+    if (dtype == ASSX_F64)
+      hipLaunchKernelGGL((mix_variance_kernel<double>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                         (const double*)Lambda, (const double*)g, (double*)R_scratch, M, N, F, T);
+    else if (dtype == ASSX_F32)
+      hipLaunchKernelGGL((mix_variance_kernel<float>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
+                         (const float*)Lambda, (const float*)g, (float*)R_scratch, M, N, F, T);
+    else
+      return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
+    ASSX_LAUNCH_CHECK(ctx, "mix_variance_kernel");
+    return widem::weighted_ip(ctx, X, R_scratch, eps, threshold, eps, Q, status, ws, B, M, F, T, dtype, st);
+  }
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;

@@ -606,6 +606,20 @@ int normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, 
   });
 }
 
+// covariance weighted by a given (B,N,F,T) map, then the IP sweep: the other callers of the pair (IDLMA, FastMNMF)
+int weighted_ip(assx_ctx* ctx, const void* X, const void* r, double eps, double thr, double den_floor, void* W,
+                int32_t* status, void* ws, int B, int M, int F, int T, int dtype, hipStream_t st) {
+  const Ws L = layout(B, M, F, T, 1, dtype);
+  return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
+    void* U = (char*)ws + L.u;
+    int rc = launch_cov<R, MM>(ctx, X, r, RK_NFT, MM, eps, U, B, F, T, st);
+    if (rc) return rc;
+    return launch_sweep<R, MM>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status, B, F, T, st, den_floor);
+  });
+}
+
 int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* ws, int B, int M, int F, int T,
                 int dtype, hipStream_t st) {
   const Ws L = layout(B, M, F, T, 1, dtype);

@@ -46,6 +46,9 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
 int normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins, double eps,
                                      void* ws, int B, int M, int F, int K, int dtype,
                                      hipStream_t st);                         // assx_ilrma_normalize_power_bins_partitioned
+int weighted_ip(assx_ctx* ctx, const void* X, const void* r, double eps, double thr, double den_floor, void* W,
+                int32_t* status, void* ws, int B, int M, int F, int T, int dtype,
+                hipStream_t st);                              // assx_idlma_space_update / assx_fastmnmf_update_diagonalizer
 int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* ws, int B, int M, int F, int T,
                 int dtype, hipStream_t st);                                                   // assx_demix_power
 int power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power, void* ws, int B, int M, int F, int dtype,

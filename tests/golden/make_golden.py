@@ -572,17 +572,18 @@ def gen_stft():
     save("stft", cases=np.array([(L, N, hop, wf == "hamming") for L, N, hop, wf in cases]), **out)
 
 
-def gen_f4():
+def gen_f4(idlma_cases=((2, 2), (3, 1), (4, 2), (4, 1.5)),
+           mnmf_cases=((2, 2, 3, False), (3, 2, 4, False), (4, 3, 3, False), (4, 5, 2, True)), shape=(17, 96)):
     """Other callers of the covariance + IP kernels: the reference's own methods on seeded state."""
     from sss.idlma import GaussIDLMA
     from bss.mnmf import FastMultichannelISNMF
-    F, T = 17, 96
-    for M, domain in ((2, 2), (3, 1), (4, 2), (4, 1.5)):
+    F, T = shape
+    for M, domain in idlma_cases:
         rng = np.random.default_rng(900 + M)
         X = convolutive_mixture(M, F, T, 901 + M)
         W0 = np.eye(M)[None] + 0.3 * (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M)))
         dnn = rng.random((M, F, T)) ** 2 + 1e-3
-        dnn[0, 3, :5] = 0.0  # hits the eps floor (idlma.py:189)
+        dnn[0, 3, :max(5, M + 2)] = 0.0  # hits the eps floor (idlma.py:189); >= M frames keep the bin well conditioned
         m = object.__new__(GaussIDLMA)
         m.input, m.demix_filter, m.dnn_output = X, W0.copy(), dnn.copy()
         m.domain, m.eps, m.threshold = domain, 1e-12, 1e12
@@ -591,7 +592,7 @@ def gen_f4():
         m.update_space_model()
         save("f4_idlma_m%d_d%s" % (M, str(domain).replace(".", "")), X=X, W0=W0, dnn_output=dnn, domain=float(domain),
              W1=m.demix_filter)
-    for M, N, K, part in ((2, 2, 3, False), (3, 2, 4, False), (4, 3, 3, False), (4, 5, 2, True)):
+    for M, N, K, part in mnmf_cases:
         rng = np.random.default_rng(950 + M + N)
         X = convolutive_mixture(M, F, T, 951 + M)
         Q0 = np.eye(M)[None] + 0.3 * (rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M)))
@@ -692,6 +693,7 @@ def gen_wide_variants():
     """partitioning=True and tILRMA beyond 4 channels (the wide-channel path; same file formats as the M <= 4 groups)."""
     gen_part(cases=((5, 3, "power", "IP"), (6, 10, "power", "ISS")), seed=1600, shape=(13, 256))
     gen_tilrma(cases=((5, 3, 5, "power"), (6, 10, 1, "power")), seed=1700, shape=(13, 256))
+    gen_f4(idlma_cases=((5, 1.5), (6, 2)), mnmf_cases=((5, 3, 3, False), (6, 4, 2, True)), shape=(13, 256))
 
 
 if __name__ == "__main__":

@@ -599,8 +599,10 @@ def test_oversize_utterance_is_rejected(eng):
     assert b"4 GiB" in L.lib.assx_last_error(eng.ctx)
 
 
-F4_IDLMA = ["f4_idlma_m2_d2", "f4_idlma_m3_d1", "f4_idlma_m4_d2", "f4_idlma_m4_d15"]
-F4_FASTMNMF = ["f4_fastmnmf_m2_n2", "f4_fastmnmf_m3_n2", "f4_fastmnmf_m4_n3", "f4_fastmnmf_m4_n5_part"]
+F4_IDLMA = ["f4_idlma_m2_d2", "f4_idlma_m3_d1", "f4_idlma_m4_d2", "f4_idlma_m4_d15", "f4_idlma_m5_d15",
+            "f4_idlma_m6_d2"]
+F4_FASTMNMF = ["f4_fastmnmf_m2_n2", "f4_fastmnmf_m3_n2", "f4_fastmnmf_m4_n3", "f4_fastmnmf_m4_n5_part",
+               "f4_fastmnmf_m5_n3", "f4_fastmnmf_m6_n4_part"]
 
 
 @pytest.mark.parametrize("name", F4_IDLMA)
