@@ -183,7 +183,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 4; ++r) tv[r] = 0;
 #pragma unroll
-    for (int j = 0; j < KS; ++j) tv = MM::mma(vt[wv][4 * j + lk][li], tb[j], tv);  // A operand: V^T[t = li][k]
+    for (int j = 0; j < KS; ++j)
+      if (4 * j < K) tv = MM::mma(vt[wv][4 * j + lk][li], tb[j], tv);  // A operand: V^T[t = li][k]; all-padding k-slices skipped
     // (2) elementwise in the accumulator layout
     R a[4], bm[4];
 #pragma unroll
@@ -298,7 +299,8 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 4; ++r) tv[r] = 0;
 #pragma unroll
-    for (int j = 0; j < KS; ++j) tv = MM::mma(tt_[wv][li][4 * j + lk], vbr[j], tv);  // A operand: Tb[f = li][k]
+    for (int j = 0; j < KS; ++j)
+      if (4 * j < K) tv = MM::mma(tt_[wv][li][4 * j + lk], vbr[j], tv);  // A operand: Tb[f = li][k]; padding slices skipped
     // (2)
     R a[4], bm[4];
 #pragma unroll
@@ -408,6 +410,7 @@ __global__ void __launch_bounds__(256)
     const int fA = min(f0 + li, F - 1);
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
+      if (4 * j >= K) break;  // all-padding k-slice
       const int k = 4 * j + lk;
       const R ta = (k < K) ? tbb[(size_t)fA * K + k] : (R)0;
       tv = MM::mma(ta, vbr[j], tv);
