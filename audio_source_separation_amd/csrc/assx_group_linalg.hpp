@@ -50,7 +50,7 @@ __device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singula
     const int src_i = (i == c) ? p : ((i == p) ? c : i);
     a = group_shfl<GW>(a, src_i * M + j);  // row interchange c <-> p
     const Cd pv = group_shfl<GW>(a, c * M + c);
-    const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
+    const Cd ipv = crcp_fast(pv);
     const Cd acj = group_shfl<GW>(a, c * M + j);
     const Cd rcj = cmul((j == c) ? cmake<double>(1.0, 0.0) : acj, ipv);
     const Cd fic = group_shfl<GW>(a, i * M + c);
@@ -61,13 +61,15 @@ __device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singula
       a = cmake<double>(base.x - (fic.x * rcj.x - fic.y * rcj.y), base.y - (fic.x * rcj.y + fic.y * rcj.x));
     }
   }
+  // undo the row interchanges as column interchanges (c = M-1 .. 0): composed on the column index first (integer
+  // selects), then ONE shuffle instead of M dependent ones
+  int jj = j;
 #pragma unroll
-  for (int c = M - 1; c >= 0; --c) {  // undo the row interchanges as column interchanges
+  for (int c = 0; c < M; ++c) {
     const int p = piv[c];
-    const int src_j = (j == c) ? p : ((j == p) ? c : j);
-    a = group_shfl<GW>(a, i * M + src_j);
+    jj = (jj == c) ? p : ((jj == p) ? c : jj);
   }
-  return a;
+  return group_shfl<GW>(a, i * M + jj);
 }
 
 // Largest singular value of the M x M matrix whose element (i, j) lives in lane (i, j) of the group: lambda_max of
@@ -104,9 +106,16 @@ template <int M, int GW>
 __device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bool singular, double thr) {
   const double nA2 = group_sum<GW>(active ? cabs2(a0) : 0.0);
   const double nI2 = group_sum<GW>(active ? cabs2(ainv) : 0.0);
-  const double condF = sqrt(nA2) * sqrt(nI2);
-  const bool amb = !singular && (condF == condF) && condF >= thr && condF < thr * (double)M;
-  bool ok = !singular && (condF == condF) && condF < thr;
+  // compared as squares: the two square roots would sit in the middle of the sweep's dependent chain
+  // (outside the range where the product of the squared norms is a normal number: the square-root form)
+  double c2 = nA2 * nI2, thr2 = thr * thr, m2 = (double)(M * M);
+  if (!(c2 > 1e-290 && c2 < 1e290 && thr2 < 1e290)) {
+    c2 = sqrt(nA2) * sqrt(nI2);
+    thr2 = thr;
+    m2 = (double)M;
+  }
+  const bool amb = !singular && (c2 == c2) && c2 >= thr2 && c2 < thr2 * m2;
+  bool ok = !singular && (c2 == c2) && c2 < thr2;
   if (__any(amb)) {
     const int lane = threadIdx.x & (GW - 1);
     const int i = active ? lane / M : 0, j = active ? lane % M : 0;
@@ -139,6 +148,10 @@ __global__ void __launch_bounds__(64)
     const Cx<R> v = W[(size_t)bf * MM + i * M + j];
     w = cmake<double>((double)v.x, (double)v.y);
   }
+  // the mixture covariance of the power statistic is only needed after the sweep: requested here, its round trip
+  // hides behind the sweep instead of following it
+  Cx<R> cv = cmake<R>((R)0, (R)0);
+  if (pw) cv = C[(size_t)bf * MM + i * M + j];
   int flags = 0;
   // partial records covering this bin (FROM_PART): computed once, 32-bit arithmetic (NB < 2^31 is checked on the host)
   int g_lo = 0, g_hi = -1, base = 0;
@@ -155,14 +168,31 @@ __global__ void __launch_bounds__(64)
   if (FROM_PART) {
 #pragma unroll
     for (int n = 0; n < N; ++n) uall[n] = cmake<double>(0.0, 0.0);
-    for (int g = g_lo; g <= g_hi; ++g) {
-      const int slot = flat_slot(fp, bf, g);
-      const R* p = part + ((size_t)g * fp.S + slot) * N * MM;
+    // records in chunks of RC with every load of a chunk issued before the first add (a bin is covered by 2-3
+    // workgroups at benchmark size: one round trip instead of one per record); same summation order
+    constexpr int RC = 4;
+    for (int g0 = g_lo; g0 <= g_hi; g0 += RC) {
+      R vx[RC][N], vy[RC][N];
 #pragma unroll
-      for (int n = 0; n < N; ++n) {
-        uall[n].x += (double)p[n * MM + base];
-        if (i != j) uall[n].y += (double)p[n * MM + base + 1];
+      for (int c = 0; c < RC; ++c) {
+        const int g = min(g0 + c, g_hi);
+        const int slot = flat_slot(fp, bf, g);
+        const R* p = part + ((size_t)g * fp.S + slot) * N * MM;
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          vx[c][n] = p[n * MM + base];
+          vy[c][n] = (i != j) ? p[n * MM + base + 1] : (R)0;
+        }
       }
+#pragma unroll
+      for (int c = 0; c < RC; ++c)
+        if (g0 + c <= g_hi) {
+#pragma unroll
+          for (int n = 0; n < N; ++n) {
+            uall[n].x += (double)vx[c][n];
+            if (i != j) uall[n].y += (double)vy[c][n];
+          }
+        }
     }
 #pragma unroll
     for (int n = 0; n < N; ++n) {
@@ -200,14 +230,13 @@ __global__ void __launch_bounds__(64)
     Cd term = cmul(cmul(cconj(wi), u), wj);
     if (!active) term = cmake<double>(0.0, 0.0);
     const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
-    Cd den = csqrt_principal(q);
+    Cd den = csqrt_fast(q);
     if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
-    if (ok && !singular && i == n) w = cdiv(cconj(wj), den);
+    if (ok && !singular && i == n) w = cdiv_fast(cconj(wj), den);
   }
 
   if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
   if (pw) {  // per-bin share of mean|y_n|^2 = mean_f w_n^H C_f w_n
-    const Cx<R> cv = C[(size_t)bf * MM + i * M + j];
     const Cd c = cmake<double>((double)cv.x, (double)cv.y);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
