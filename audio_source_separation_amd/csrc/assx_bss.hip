@@ -358,26 +358,37 @@ __global__ void __launch_bounds__(256) normalize_power_bins_kernel(Cx<R>* __rest
   __shared__ R anorm[8];
   const int b = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  // this thread's element of W / Tb is requested first: its round trip overlaps the reduction instead of following it
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nW = (size_t)F * M * M, nT = (size_t)M * F * K;
+  Cx<R>* w = W + (size_t)b * nW + (idx < nW ? idx : 0);
+  R* t = Tb + (size_t)b * nT + ((idx >= nW && idx < nW + nT) ? idx - nW : 0);
+  const Cx<R> wold = *w;
+  const R told = *t;
   for (int n = wv; n < M; n += 4) {  // one wave per source: fixed-order strided sum + butterfly
     const double* p = pbins + ((size_t)b * M + n) * F;
     double s = 0.0;
-    for (int f = lane; f < F; f += WAVE) s += p[f];
+    constexpr int RC = 8;  // loads of a chunk in flight together (the plain loop was one L2 round trip per 64 bins)
+    for (int f0 = lane; f0 < F; f0 += WAVE * RC) {
+      double v[RC];
+#pragma unroll
+      for (int c = 0; c < RC; ++c) v[c] = p[min(f0 + WAVE * c, F - 1)];
+#pragma unroll
+      for (int c = 0; c < RC; ++c)
+        if (f0 + WAVE * c < F) s += v[c];
+    }
     s = wave_allreduce_sum<double>(s);
     if (lane == 0) anorm[n] = floor_eps<R>(sqrt((R)(s / (double)F)), eps);
   }
   __syncthreads();
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const size_t nW = (size_t)F * M * M, nT = (size_t)M * F * K;
   if (idx < nW) {
     const int n = (idx / M) % M;
-    Cx<R>* w = W + (size_t)b * nW + idx;
     const R a = anorm[n];
-    *w = cmake<R>(w->x / a, w->y / a);
+    *w = cmake<R>(wold.x / a, wold.y / a);
   } else if (idx < nW + nT) {
     const size_t j = idx - nW;
     const int n = j / ((size_t)F * K);
-    R* t = Tb + (size_t)b * nT + j;
-    *t = *t / powspec<R>(anorm[n], pd);
+    *t = told / powspec<R>(anorm[n], pd);
   }
 }
 

@@ -1001,15 +1001,28 @@ __global__ void __launch_bounds__(256) basis_stream_finalize_kernel(const R* __r
   const long long j = (long long)b * F + f;
   int g_lo, g_hi;
   flat_cover(fp, j, g_lo, g_hi);
+  const R told = Tb[idx];  // requested with the records: one round trip for the whole kernel instead of one per load
   R num = 0, den = 0;
-  for (int g = g_lo; g <= g_hi; ++g) {
-    const int slot = flat_slot(fp, j, g);
-    const R* p = part + (((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2;
-    num += p[0];
-    den += p[1];
+  constexpr int RC = 4;  // a bin is covered by 2-3 workgroups at benchmark size; same summation order
+  for (int g0 = g_lo; g0 <= g_hi; g0 += RC) {
+    R vn[RC], vd[RC];
+#pragma unroll
+    for (int c = 0; c < RC; ++c) {
+      const int g = min(g0 + c, g_hi);
+      const int slot = flat_slot(fp, j, g);
+      const R* p = part + (((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2;
+      vn[c] = p[0];
+      vd[c] = p[1];
+    }
+#pragma unroll
+    for (int c = 0; c < RC; ++c)
+      if (g0 + c <= g_hi) {
+        num += vn[c];
+        den += vd[c];
+      }
   }
   den = floor_eps<R>(den, eps);
-  Tb[idx] = Tb[idx] * powspec<R>(num / den, p2);
+  Tb[idx] = told * powspec<R>(num / den, p2);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1645,13 +1658,27 @@ __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __res
   const long long j = (long long)b * TBk + tb;
   int g_lo, g_hi;
   flat_cover(fp, j, g_lo, g_hi);
+  R* v = V + (((size_t)b * N + n) * K + k) * T + (t < T ? t : T - 1);
+  const R vold = (q == 0 && upd) ? *v : (R)0;  // requested with the records, not after the barrier
   R num = 0, den = 0;
   if (upd) {
-    for (int g = g_lo + q; g <= g_hi; g += 4) {
-      const int slot = flat_slot(fp, j, g);
-      const R* p = part + ((((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2) * WAVE + lane;
-      num += p[0];
-      den += p[WAVE];
+    constexpr int RC = 4;  // records of a strand in chunks whose loads are all in flight together; same order
+    for (int g0 = g_lo + q; g0 <= g_hi; g0 += 4 * RC) {
+      R vn[RC], vd[RC];
+#pragma unroll
+      for (int c = 0; c < RC; ++c) {
+        const int g = min(g0 + 4 * c, g_hi);
+        const int slot = flat_slot(fp, j, g);
+        const R* p = part + ((((size_t)g * fp.S + slot) * N + n) * (size_t)(2 * K) + k * 2) * WAVE + lane;
+        vn[c] = p[0];
+        vd[c] = p[WAVE];
+      }
+#pragma unroll
+      for (int c = 0; c < RC; ++c)
+        if (g0 + 4 * c <= g_hi) {
+          num += vn[c];
+          den += vd[c];
+        }
     }
   }
   sn[q][lane] = num;
@@ -1661,8 +1688,7 @@ __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __res
     num = (sn[0][lane] + sn[1][lane]) + (sn[2][lane] + sn[3][lane]);
     den = (sd[0][lane] + sd[1][lane]) + (sd[2][lane] + sd[3][lane]);
     den = floor_eps<R>(den, eps);
-    R* v = V + (((size_t)b * N + n) * K + k) * T + t;
-    *v = *v * powspec<R>(num / den, p2);
+    *v = vold * powspec<R>(num / den, p2);
   }
 }
 
