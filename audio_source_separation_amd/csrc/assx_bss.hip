@@ -973,15 +973,15 @@ int run_cov(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb,
 
 template <typename R, int M>
 int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
-           double thr, int32_t* status, int B, int F, hipStream_t st, double den_floor = 0.0) {
+           double thr, int32_t* status, int B, int F, hipStream_t st, double den_floor = 0.0, int wb = 1) {
   constexpr int GPW = WAVE / next_pow2_c(M * M);
   const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
   if (part)
     hipLaunchKernelGGL((ip_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
-                       1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor);
+                       1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor, wb);
   else
     hipLaunchKernelGGL((ip_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
-                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor);
+                       (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor, 1);
   ASSX_LAUNCH_CHECK(ctx, "ip_group_kernel");
   return 0;
 }
@@ -1107,10 +1107,12 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
 template <typename R, int MM>
 int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int K, double domain, double eps,
                        void* ws, void* U_dense, int B, int F, int T, int dtype, hipStream_t st, FlatPart* fp_out,
-                       bool* dense) {
+                       bool* dense, int* records_wb = nullptr /* non-null: the caller's sweep reads cov_wide_kernel's
+                       records itself (ip_group_kernel, wb = COVW_BINS); the dense finalize is skipped */) {
   static const int wide = env_int("ASSX_WIDE_K", 1);
   static const int fused = env_int("ASSX_COV_WIDE", 1);
   *dense = false;
+  if (records_wb) *records_wb = 1;
   if (K <= KU || !wide) return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, fp_out);
   const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
   const PowSpec p2d = make_pow(2.0 / domain);
@@ -1138,6 +1140,11 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
     }
 #undef COVW_LAUNCH
     ASSX_LAUNCH_CHECK(ctx, "cov_wide_kernel");
+    if (records_wb) {
+      *records_wb = COVW_BINS;
+      *fp_out = fw;
+      return 0;
+    }
     hipLaunchKernelGGL((cov_wide_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)), dim3(256),
                        0, st, (const R*)ws, (Cx<R>*)U_dense, B, F, fw, (R)(1.0 / (double)T));
     ASSX_LAUNCH_CHECK(ctx, "cov_wide_finalize_kernel");
@@ -1529,7 +1536,10 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n
     FlatPart fp;
     bool dense = false;
     void* Ud = U_out ? U_out : (void*)((char*)ws + ws_layout(B, MM, F, T, K, dtype).u);
-    int rc = run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, Ud, B, F, T, dtype, st, &fp, &dense);
+    int wb = 1;  // IP without a dense-U request: the sweep reduces the covariance records itself, whichever kernel made them
+    const bool direct = spatial == ASSX_SPATIAL_IP && !U_out;
+    int rc = run_cov_partial_tv<R, MM>(ctx, X, Tb, V, K, domain, eps, ws, Ud, B, F, T, dtype, st, &fp, &dense,
+                                       direct ? &wb : nullptr);
     if (rc) return rc;
     if (U_out && !dense) {  // dense covariance on request only; the IP sweep reduces the partial records itself
       hipLaunchKernelGGL((cov_stream_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)),
@@ -1541,7 +1551,7 @@ int assx_ilrma_spatial_update(assx_ctx* ctx, int spatial, int pair_m, int pair_n
     if (spatial == ASSX_SPATIAL_ISS) return run_iss<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, B, F, st);
     if (spatial == ASSX_SPATIAL_IP2)
       return run_ip2<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, threshold, status, B, F, pair_m, pair_n, st);
-    return run_ip<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, threshold, status, B, F, st);
+    return run_ip<R, MM>(ctx, Uin, pin, fp, T, W, C, power_bins, threshold, status, B, F, st, 0.0, wb);
   });
 }
 

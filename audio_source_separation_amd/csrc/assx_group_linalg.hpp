@@ -129,7 +129,9 @@ template <typename R, int M, bool FROM_PART>
 __global__ void __launch_bounds__(64)
     ip_group_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
                     Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
-                    int32_t* __restrict__ status, int B, int F, double den_floor) {
+                    int32_t* __restrict__ status, int B, int F, double den_floor, int wb = 1) {
+  // wb (FROM_PART): bins per record group -- 1 for cov_stream_kernel's records [g][slot][n][HM], COVW_BINS for
+  // cov_wide_kernel's [g][slot][bin in group][n][HM] (same packed-Hermitian layout inside)
   constexpr int N = M;
   constexpr int MM = M * M;
   constexpr int GW = next_pow2_c(MM);
@@ -155,8 +157,14 @@ __global__ void __launch_bounds__(64)
   int flags = 0;
   // partial records covering this bin (FROM_PART): computed once, 32-bit arithmetic (NB < 2^31 is checked on the host)
   int g_lo = 0, g_hi = -1, base = 0;
+  long long jrec = bf;
+  int sub = 0;
   if (FROM_PART) {
-    flat_cover(fp, bf, g_lo, g_hi);
+    if (wb > 1) {
+      jrec = (long long)b * ((F + wb - 1) / wb) + f / wb;
+      sub = f % wb;
+    }
+    flat_cover(fp, jrec, g_lo, g_hi);
     const int lo = i < j ? i : j, hi = i < j ? j : i;
     base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
   }
@@ -176,8 +184,8 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
       for (int c = 0; c < RC; ++c) {
         const int g = min(g0 + c, g_hi);
-        const int slot = flat_slot(fp, bf, g);
-        const R* p = part + ((size_t)g * fp.S + slot) * N * MM;
+        const int slot = flat_slot(fp, jrec, g);
+        const R* p = part + (((size_t)g * fp.S + slot) * wb + sub) * N * MM;
 #pragma unroll
         for (int n = 0; n < N; ++n) {
           vx[c][n] = p[n * MM + base];

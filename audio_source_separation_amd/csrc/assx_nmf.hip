@@ -182,6 +182,7 @@ __global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__
   const size_t idx = (size_t)blockIdx.x * 64 + o;
   const bool ok = idx < (size_t)B * count;
   const size_t b = ok ? idx / count : 0, i = ok ? idx % count : 0;
+  const R old = (q == 0 && ok) ? out[idx] : (R)0;  // requested with the slabs, not after the barrier
   R num = 0, den = 0;
   if (ok) {
 #pragma unroll 4
@@ -199,10 +200,10 @@ __global__ void __launch_bounds__(256) nmf_finalize_kernel(const R* __restrict__
     den = (sd[0][o] + sd[1][o]) + (sd[2][o] + sd[3][o]);
     if (p.mode == POW_CAUCHY_ME) {  // num = B, den = A
       const R d2 = floor_eps<R>(den + sqrt(fma(den, den, (R)2 * num * den)), eps);
-      out[idx] = out[idx] * (num / d2);
+      out[idx] = old * (num / d2);
     } else {
       den = floor_eps<R>(den, eps);
-      out[idx] = out[idx] * powspec<R>(num / den, p);
+      out[idx] = old * powspec<R>(num / den, p);
     }
   }
 }
