@@ -400,6 +400,39 @@ constexpr int next_pow2_c(int n) { return n <= 1 ? 1 : 2 * next_pow2_c((n + 1) >
 // WIDTH lanes (WIDTH = 64: the whole wave).  On return v[0] of lane l holds the group-wide total of value index
 // (l % WIDTH) >> (log2 WIDTH - log2 NV) (every lane sharing that index holds the same total).
 // NV-1 + (log2 WIDTH - log2 NV) shuffles instead of NV * log2 WIDTH.
+// The two cross-row stages of the butterfly (partner lane ^ 32, lane ^ 16) as gfx950 half-wave / row swaps:
+// v_permlane32_swap(a, b) exchanges lanes 32-63 of a with lanes 0-31 of b (v_permlane16_swap: odd rows of a with even
+// rows of b), after which a + b is, in every lane, exactly the sum the select + ds_bpermute form produces (the same
+// two numbers, so the same bits) -- 2 swaps + 1 add per exchange instead of 4 selects + 2 LDS permutes + 1 add, and
+// these two stages are 3/4 of all exchanges.  The flush of a streaming kernel's accumulators ran 2.2-4.8 us per bin
+// boundary (in-kernel timestamps), on the critical path of the workgroups that cross one.
+template <bool HALF_WAVE>
+__device__ __forceinline__ void lane_block_swap(unsigned& a, unsigned& b) {
+  if (HALF_WAVE) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+  }
+}
+template <bool HALF_WAVE>
+__device__ __forceinline__ double swap_add(double a, double b) {
+  unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  lane_block_swap<HALF_WAVE>(alo, blo);
+  lane_block_swap<HALF_WAVE>(ahi, bhi);
+  return __hiloint2double((int)ahi, (int)alo) + __hiloint2double((int)bhi, (int)blo);
+}
+template <bool HALF_WAVE>
+__device__ __forceinline__ float swap_add(float a, float b) {
+  unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+  lane_block_swap<HALF_WAVE>(ua, ub);
+  return __uint_as_float(ua) + __uint_as_float(ub);
+}
+
 template <typename R, int NV, int WIDTH = WAVE>
 __device__ __forceinline__ R wave_reduce_scatter(R (&v)[NV]) {
   static_assert(NV >= 1 && NV <= WIDTH && (NV & (NV - 1)) == 0, "NV must be a power of two <= WIDTH");
@@ -407,13 +440,18 @@ __device__ __forceinline__ R wave_reduce_scatter(R (&v)[NV]) {
   int off = WIDTH / 2;
 #pragma unroll
   for (int h = NV / 2; h >= 1; h >>= 1) {
-    const bool up = (lane & off) != 0;
+    if (off == 32 || off == 16) {  // (compile-time after unrolling)
 #pragma unroll
-    for (int i = 0; i < h; ++i) {
-      R a = v[i], b = v[i + h];
-      R send = up ? a : b;
-      R keep = up ? b : a;
-      v[i] = keep + __shfl_xor(send, off, WAVE);
+      for (int i = 0; i < h; ++i) v[i] = off == 32 ? swap_add<true>(v[i], v[i + h]) : swap_add<false>(v[i], v[i + h]);
+    } else {
+      const bool up = (lane & off) != 0;
+#pragma unroll
+      for (int i = 0; i < h; ++i) {
+        R a = v[i], b = v[i + h];
+        R send = up ? a : b;
+        R keep = up ? b : a;
+        v[i] = keep + __shfl_xor(send, off, WAVE);
+      }
     }
     off >>= 1;
   }
