@@ -65,6 +65,20 @@ __host__ __device__ __forceinline__ void flat_range(const FlatPart& fp, int g, l
   q0 = (long long)b * fp.NB + lo;
   q1 = (long long)b * fp.NB + hi;
 }
+// the same start as (utterance, group in the utterance, item in the group, item count), in 32-bit arithmetic: an
+// utterance's NB items fit an int (checked on the host), so the 64-bit division a global item index needs -- ~150
+// instructions at the head of every streaming kernel, before its first load is issued -- is not needed
+__device__ __forceinline__ bool flat_start(const FlatPart& fp, int g, int& b, int& grp, int& item, int& n) {
+  b = g / fp.Gu;
+  const unsigned gl = (unsigned)(g - b * fp.Gu);
+  const unsigned nb = (unsigned)fp.NB, lo = gl * (unsigned)fp.L;
+  if (lo >= nb) return false;
+  const unsigned hi = lo + (unsigned)fp.L < nb ? lo + (unsigned)fp.L : nb;
+  n = (int)(hi - lo);
+  grp = (int)(lo / (unsigned)fp.len);
+  item = (int)(lo - (unsigned)grp * (unsigned)fp.len);
+  return true;
+}
 // consumer side: the workgroups g_lo..g_hi whose records cover GLOBAL group j (= utterance * Ju + group), and the
 // slot of that group inside workgroup g's block of records
 __host__ __device__ __forceinline__ void flat_cover(const FlatPart& fp, long long j, int& g_lo, int& g_hi) {
@@ -278,15 +292,10 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  long long q0, q1;
-  flat_range(a.fp, g, q0, q1);
-  if (q0 >= q1) return;
-  const int nblk = (int)(q1 - q0);
-  const int bf_first = (int)(q0 / TBk);  // the only divisions: once per workgroup
   Cursor cc;                             // consume cursor
-  cc.tb = (int)(q0 - (long long)bf_first * TBk);
-  cc.b = bf_first / F;
-  cc.f = bf_first - cc.b * F;
+  int nblk;
+  if (!flat_start(a.fp, g, cc.b, cc.f, cc.tb, nblk)) return;
+  const int bf_first = cc.b * F + cc.f;
   Cursor px = cc, pw = cc;               // prefetch cursors (X ring, weight ring)
   const bool ragged = (T % FB) != 0;     // only then can a lane fall beyond the last frame
 
@@ -624,15 +633,10 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  long long q0, q1;
-  flat_range(a.fp, g, q0, q1);
-  if (q0 >= q1) return;
-  const int nblk = (int)(q1 - q0);
-  const int bf_first = (int)(q0 / TBk);  // the only divisions: once per workgroup
   Cursor c0;
-  c0.tb = (int)(q0 - (long long)bf_first * TBk);
-  c0.b = bf_first / F;
-  c0.f = bf_first - c0.b * F;
+  int nblk;
+  if (!flat_start(a.fp, g, c0.b, c0.f, c0.tb, nblk)) return;
+  const int bf_first = c0.b * F + c0.f;
   const int nchunks = K4 ? 1 : (K + KU - 1) / KU;
   const bool ragged = (T % WAVE) != 0;
 
@@ -796,15 +800,10 @@ __global__ void __launch_bounds__(64, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  long long q0, q1;
-  flat_range(a.fp, g, q0, q1);
-  if (q0 >= q1) return;
-  const int nblk = (int)(q1 - q0);
-  const int bf_first = (int)(q0 / TBk);
   Cursor cc;
-  cc.tb = (int)(q0 - (long long)bf_first * TBk);
-  cc.b = bf_first / F;
-  cc.f = bf_first - cc.b * F;
+  int nblk;
+  if (!flat_start(a.fp, g, cc.b, cc.f, cc.tb, nblk)) return;
+  const int bf_first = cc.b * F + cc.f;
   Cursor px = cc, pw = cc;
   const unsigned x_row = (unsigned)FT * (unsigned)sizeof(Cx<R>);
   const unsigned t_row = (unsigned)T * (unsigned)sizeof(R);
@@ -1532,12 +1531,6 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
           v[n][kk] = buf_ld<R>(rv, tc * (unsigned)sizeof(R),
                                (unsigned)(n * K + (kk < K ? kk : K - 1)) * (unsigned)T * (unsigned)sizeof(R));
     }
-    // the activation columns must have landed before the ring starts: the compiler would otherwise wait for them
-    // with vmcnt(0) inside the loop -- on every trip, since its model merges the loop entry with the back-edge --
-    // and drain the ring (whose loads it cannot see) each time
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int n = 0; n < N; ++n) value_fence(v[n]);
     R acc[NACC];
 #pragma unroll
     for (int i = 0; i < NACC; ++i) acc[i] = 0;
@@ -1568,6 +1561,13 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
         for (int m = 0; m < M; ++m) xq[j][m] = Vec2<R>{0, 0};
         issue_bin(fa + h + j * ACT_NH, j, xq[j]);
       }
+    // the activation columns must have landed before the loop starts: the compiler would otherwise wait for them
+    // with vmcnt(0) inside the loop -- on every trip, since its model merges the loop entry with the back-edge --
+    // and drain the ring (whose loads it cannot see) each time.  The wait sits AFTER the ring's first requests, so the
+    // columns and the first bins travel together: one memory round trip per segment instead of two in a row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int n = 0; n < N; ++n) value_fence(v[n]);
 
     auto block = [&](auto jc, auto steady, const int it) {
       constexpr int j = decltype(jc)::value;
