@@ -48,6 +48,28 @@ def main():
         if pct < 0.05:
             continue
         print("| `%s` | %d | %.1f | %.2f | %.2f |" % (short(name), calls, total, avg, pct))
+    if dbs and not csvs:
+        by_grid(dbs[0])
+
+
+def by_grid(path):
+    """The same kernel name is launched with different geometries (one utterance in the timed steps, 8 in the
+    beyond-cache roofline leg): average per (kernel, grid) for the kernels that have more than one."""
+    con = sqlite3.connect(path)
+    rows = list(con.execute("select name, grid_x, grid_y, grid_z, count(*), avg(end - start) from kernels "
+                            "group by name, grid_x, grid_y, grid_z"))
+    names = {}
+    for r in rows:
+        names.setdefault(r[0], []).append(r)
+    multi = {k: v for k, v in names.items() if len(v) > 1 and ("assx" in k or "_kernel" in k) and "at::" not in k}
+    if not multi:
+        return
+    print()
+    print("| kernel | grid | calls | avg us |")
+    print("|---|---|---:|---:|")
+    for k, v in sorted(multi.items(), key=lambda kv: -sum(r[4] * r[5] for r in kv[1])):
+        for r in sorted(v, key=lambda r: -r[4]):
+            print("| `%s` | %d x %d x %d | %d | %.2f |" % (short(k), r[1], r[2], r[3], r[4], r[5] / 1e3))
 
 
 if __name__ == "__main__":
