@@ -41,40 +41,73 @@ struct FlatPart {
   int S;         // partial-record slots per workgroup
   int Gu;        // workgroups per utterance
   int Ju;        // groups per utterance (NB / len)
+  int P;         // 0: flat ranges of L items (may cross groups).  > 0: ALIGNED -- every group is cut into P parts of
+                 // L items, workgroup gl = group * P + part; a range never crosses a group, so a workgroup has ONE
+                 // segment / flush and one record slot
 };
 
+// A workgroup whose range crosses a group boundary pays a second prologue / flush (3-5 us measured, on the critical
+// path: the kernel ends with its slowest workgroup).  When the workgroup budget is (almost) a whole number of parts
+// per group the partition is therefore aligned to the groups -- the activation pass at config 4: 64 frame blocks x 8
+// parts = the 512 resident workgroups exactly.  The covariance / basis passes (1025 bins, 2048 workgroups) cannot be.
 inline FlatPart make_flat(int B, long long NB, int len, long long G_target) {
   FlatPart p;
   p.NB = NB;
   p.len = len;
+  p.Ju = (int)(NB / len);
+  p.P = 0;
   long long G = G_target < NB ? G_target : NB;
   if (G < 1) G = 1;
+  const long long parts = G / p.Ju;
+  if (parts >= 1 && parts <= len && p.Ju * parts * 100 >= G * 97) {
+    p.P = (int)parts;
+    p.L = (int)((len + parts - 1) / parts);
+    p.Gu = (int)(p.Ju * parts);
+    p.G = B * p.Gu;
+    p.S = 1;
+    return p;
+  }
   p.L = (int)((NB + G - 1) / G);
   p.Gu = (int)((NB + p.L - 1) / p.L);
   p.G = B * p.Gu;
   p.S = (p.L + len - 2) / len + 1;
-  p.Ju = (int)(NB / len);
   return p;
+}
+
+// first item (within the utterance) and item count of local workgroup gl; false: nothing to do
+__host__ __device__ __forceinline__ bool flat_local(const FlatPart& fp, unsigned gl, unsigned& lo, unsigned& n) {
+  const unsigned L = (unsigned)fp.L;
+  if (fp.P > 0) {
+    const unsigned grp = gl / (unsigned)fp.P, part = gl - grp * (unsigned)fp.P, len = (unsigned)fp.len;
+    const unsigned off = part * L;
+    if (off >= len) return false;
+    lo = grp * len + off;
+    n = off + L < len ? L : len - off;
+    return true;
+  }
+  const unsigned nb = (unsigned)fp.NB;
+  lo = gl * L;
+  if (lo >= nb) return false;
+  n = lo + L < nb ? L : nb - lo;
+  return true;
 }
 
 // producer side: the GLOBAL item range [q0, q1) of workgroup g (global item = utterance * NB + item in utterance)
 __host__ __device__ __forceinline__ void flat_range(const FlatPart& fp, int g, long long& q0, long long& q1) {
-  const int b = g / fp.Gu, gl = g - b * fp.Gu;
-  const long long lo = (long long)gl * fp.L;
-  const long long hi = (lo + fp.L < fp.NB) ? lo + fp.L : fp.NB;
+  const int b = g / fp.Gu;
+  unsigned lo = 0, n = 0;
+  if (!flat_local(fp, (unsigned)(g - b * fp.Gu), lo, n)) n = 0;
   q0 = (long long)b * fp.NB + lo;
-  q1 = (long long)b * fp.NB + hi;
+  q1 = q0 + n;
 }
 // the same start as (utterance, group in the utterance, item in the group, item count), in 32-bit arithmetic: an
 // utterance's NB items fit an int (checked on the host), so the 64-bit division a global item index needs -- ~150
 // instructions at the head of every streaming kernel, before its first load is issued -- is not needed
 __device__ __forceinline__ bool flat_start(const FlatPart& fp, int g, int& b, int& grp, int& item, int& n) {
   b = g / fp.Gu;
-  const unsigned gl = (unsigned)(g - b * fp.Gu);
-  const unsigned nb = (unsigned)fp.NB, lo = gl * (unsigned)fp.L;
-  if (lo >= nb) return false;
-  const unsigned hi = lo + (unsigned)fp.L < nb ? lo + (unsigned)fp.L : nb;
-  n = (int)(hi - lo);
+  unsigned lo, cnt;
+  if (!flat_local(fp, (unsigned)(g - b * fp.Gu), lo, cnt)) return false;
+  n = (int)cnt;
   grp = (int)(lo / (unsigned)fp.len);
   item = (int)(lo - (unsigned)grp * (unsigned)fp.len);
   return true;
@@ -83,11 +116,18 @@ __device__ __forceinline__ bool flat_start(const FlatPart& fp, int g, int& b, in
 // slot of that group inside workgroup g's block of records
 __host__ __device__ __forceinline__ void flat_cover(const FlatPart& fp, long long j, int& g_lo, int& g_hi) {
   const int b = (int)(j / fp.Ju);
-  const unsigned lo = (unsigned)(j - (long long)b * fp.Ju) * (unsigned)fp.len;
+  const unsigned jl = (unsigned)(j - (long long)b * fp.Ju);
+  if (fp.P > 0) {
+    g_lo = b * fp.Gu + (int)(jl * (unsigned)fp.P);
+    g_hi = g_lo + (fp.len + fp.L - 1) / fp.L - 1;
+    return;
+  }
+  const unsigned lo = jl * (unsigned)fp.len;
   g_lo = b * fp.Gu + (int)(lo / (unsigned)fp.L);
   g_hi = b * fp.Gu + (int)((lo + (unsigned)fp.len - 1u) / (unsigned)fp.L);
 }
 __host__ __device__ __forceinline__ int flat_slot(const FlatPart& fp, long long j, int g) {
+  if (fp.P > 0) return 0;
   const int b = g / fp.Gu, gl = g - b * fp.Gu;
   return (int)(j - (long long)b * fp.Ju) - (int)(((unsigned)gl * (unsigned)fp.L) / (unsigned)fp.len);
 }
