@@ -15,6 +15,7 @@
 //   * REGISTER DOUBLE BUFFERING.  The loads of block q+1 (X row slices and the weight inputs) are issued
 //     before block q is consumed.
 #pragma once
+#include <cstdlib>
 #include "assx_common.hpp"
 
 namespace assx {
@@ -59,7 +60,8 @@ inline FlatPart make_flat(int B, long long NB, int len, long long G_target) {
   long long G = G_target < NB ? G_target : NB;
   if (G < 1) G = 1;
   const long long parts = G / p.Ju;
-  if (parts >= 1 && parts <= len && p.Ju * parts * 100 >= G * 97) {
+  static const bool align = getenv("ASSX_ALIGN") == nullptr || atoi(getenv("ASSX_ALIGN")) != 0;  // A/B switch
+  if (align && parts >= 1 && parts <= len && p.Ju * parts * 100 >= G * 97) {
     p.P = (int)parts;
     p.L = (int)((len + parts - 1) / parts);
     p.Gu = (int)(p.Ju * parts);
