@@ -1534,14 +1534,14 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int F = a.d.F, T = a.d.T, K = a.d.K;
-  const int TBk = (T + WAVE - 1) / WAVE;
   const size_t FT = (size_t)F * T;
   const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
-  long long q0, q1;
-  flat_range(a.fp, g, q0, q1);
-  if (q0 >= q1) return;
-  const long long bt_first = q0 / F;
-  const long long bt_last = (q1 - 1) / F;
+  // this workgroup's items (frame block, bin) in 32-bit arithmetic (flat_start): the 64-bit divisions of a global item
+  // index were ~2 us at the head of the kernel, before its first load (in-kernel timestamps)
+  int b, tb_first, f_first, nitems;
+  if (!flat_start(a.fp, g, b, tb_first, f_first, nitems)) return;
+  const int tb_last = tb_first + (f_first + nitems - 1) / F;
+  const int f_end = f_first + nitems - (tb_last - tb_first) * F;  // one past the last bin, in the last frame block
   const unsigned x_row = (unsigned)FT * (unsigned)sizeof(Cx<R>);
   unsigned char* myring = ring + h * (DXT * ACT_RING_SLOT);
   const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)myring;
@@ -1557,10 +1557,9 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
                                     (unsigned)(lane % DPV) * 4u
                               : 0xfffffff0u;
 
-  for (long long bt = bt_first; bt <= bt_last; ++bt) {  // segments of the range, one frame block each
-    const int b = (int)(bt / TBk), tb = (int)(bt - (long long)b * TBk);
-    const int fa = (int)((q0 > bt * F ? q0 : bt * F) - bt * F);
-    const int fb = (int)((q1 < (bt + 1) * F ? q1 : (bt + 1) * F) - bt * F);
+  for (int tb = tb_first; tb <= tb_last; ++tb) {  // segments of the range, one frame block each
+    const int fa = tb == tb_first ? f_first : 0;
+    const int fb = tb == tb_last ? f_end : F;
     const int t = tb * WAVE + lane;
     const unsigned tc = (unsigned)(t < T ? t : T - 1);
     R v[N][KU];
@@ -1665,7 +1664,7 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
     }
     __syncthreads();
     if (h == 0) {
-      const int slot = (int)(bt - bt_first);
+      const int slot = tb - tb_first;
       R* out = part + ((size_t)g * a.fp.S + slot) * (size_t)(N * 2 * K) * WAVE + lane;
 #pragma unroll
       for (int i = 0; i < NACC; ++i) {
