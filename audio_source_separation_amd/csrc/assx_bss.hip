@@ -881,17 +881,21 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
   // compile time while a kernel is being tuned.  Never shipped: the full build is what the tests run.
   if (dtype == ASSX_F64) {
     switch (M) {
-#if !defined(ASSX_DEV_ONLY_M4_F64)
+#if !defined(ASSX_DEV_ONLY_M4_F64) && !defined(ASSX_DEV_ONLY_M4_F32)
       case 2: return fn(double(), IntC<2>());
       case 3: return fn(double(), IntC<3>());
 #endif
+#if !defined(ASSX_DEV_ONLY_M4_F32)
       case 4: return fn(double(), IntC<4>());
+#endif
     }
   } else if (dtype == ASSX_F32) {
 #if !defined(ASSX_DEV_ONLY_M4_F64)
     switch (M) {
+#if !defined(ASSX_DEV_ONLY_M4_F32)
       case 2: return fn(float(), IntC<2>());
       case 3: return fn(float(), IntC<3>());
+#endif
       case 4: return fn(float(), IntC<4>());
     }
 #endif

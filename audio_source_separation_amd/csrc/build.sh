@@ -7,6 +7,12 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -Wall -Wno-unused
 # ASSX_DEV=1: kernel-tuning build (M = 4, float64 instantiations of the BSS kernels only; objects kept apart in dev/)
 OBJ=.
 if [ "${ASSX_DEV:-0}" = 1 ]; then FLAGS="$FLAGS -DASSX_DEV_ONLY_M4_F64"; OBJ=dev; mkdir -p dev; fi
+# ASSX_DEV=32: the same for the float32 instantiations
+if [ "${ASSX_DEV:-0}" = 32 ]; then FLAGS="$FLAGS -DASSX_DEV_ONLY_M4_F32"; OBJ=dev32; mkdir -p dev32; fi
+# ASSX_EXTRA_FLAGS / ASSX_OBJ / ASSX_OUT: A/B builds (e.g. -DASSX_PACKED_F32=0 into another object directory and library)
+FLAGS="$FLAGS ${ASSX_EXTRA_FLAGS:-}"
+OBJ=${ASSX_OBJ:-$OBJ}; mkdir -p "$OBJ"
+OUT=${ASSX_OUT:-libassx.so}
 pids=()
 for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem; do
   stale=0
@@ -20,5 +26,5 @@ for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libassx.so $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o
-echo "built $(pwd)/libassx.so"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o
+echo "built $(pwd)/$OUT"
