@@ -918,6 +918,21 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
 
 inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
+// Launch order of a streaming pass over X (assx_stream.hpp: workgroup_range): utterance-sequential with the direction
+// alternating from pass to pass when the launch holds more than one utterance; ASSX_UTT_ORDER=0 restores the legacy
+// order (A/B runs).  Returns the grid size.  The order decides WHEN a range runs, never what it computes.
+inline unsigned stream_grid(assx_ctx* ctx, FlatPart& fp, int B) {
+  static const int on = env_int("ASSX_UTT_ORDER", 1);
+  if (!on || B < 2) {
+    fp.Gp = 0;
+    fp.rev = 0;
+    return (unsigned)fp.G;
+  }
+  fp.Gp = (fp.Gu + N_XCD - 1) / N_XCD * N_XCD;
+  fp.rev = (int)(ctx->stream_pass++ & 1u);
+  return (unsigned)B * (unsigned)fp.Gp;
+}
+
 // covariance (any weight kind): streaming partials, then dense U; returns error code
 template <typename R, int M>
 int run_cov_partial(assx_ctx* ctx, int wk, const void* X, const void* r, const void* Tb, const void* V, int K,
@@ -928,7 +943,7 @@ int run_cov_partial(assx_ctx* ctx, int wk, const void* X, const void* r, const v
   a.eps = (R)eps;
   a.p2d = make_pow(2.0 / domain);
   *fp_out = a.fp;
-  dim3 grid((unsigned)a.fp.G);
+  dim3 grid(stream_grid(ctx, a.fp, B));
   const bool d2 = a.p2d.mode == POW_ID;
 #define COV_LAUNCH(WKV, K4V, D2V, LSV, DXV, DWV, MW) \
   hipLaunchKernelGGL((cov_stream_kernel<R, M, WKV, K4V, D2V, LSV, DXV, DWV, MW>), grid, dim3(64), 0, st, \
@@ -1034,7 +1049,7 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
   a.fp = flat_basis(B, F, T);
   *fp_out = a.fp;
   const bool d2 = a.p1.mode == POW_SQUARE, k4 = K <= KU;
-  const dim3 gb(a.fp.G), bb(64);
+  const dim3 gb(stream_grid(ctx, a.fp, B)), bb(64);
 #define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
   hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
@@ -1078,7 +1093,7 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
   a.fp = flat_act(B, F, T);
   *fp_out = a.fp;
   const bool d2 = a.p1.mode == POW_SQUARE, k4 = K <= KU;
-  const dim3 ga(a.fp.G), ba(64 * ACT_NH);
+  const dim3 ga(stream_grid(ctx, a.fp, B)), ba(64 * ACT_NH);
 #define ACT_LAUNCH(K4V, D2V, DXV, MW) \
   hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
                      (const R*)Tb, (const R*)V, (R*)ws, a)

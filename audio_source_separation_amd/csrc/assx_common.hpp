@@ -17,6 +17,9 @@ struct assx_ctx {
   // batch is B utterances x N sources).  The split-T / split-F slab counts are derived from ONE problem's geometry,
   // never from the batch size, so that a batched call sums in the same order as per-item calls (bit-identical).
   int nmf_group;
+  // streaming passes launched so far: consecutive passes walk the utterances of a batch in opposite directions (the
+  // one a pass ends with is what the Infinity Cache still holds when the next pass starts).  Never changes a result.
+  unsigned stream_pass;
 };
 
 namespace assx {

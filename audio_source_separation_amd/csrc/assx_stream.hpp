@@ -45,6 +45,12 @@ struct FlatPart {
   int P;         // 0: flat ranges of L items (may cross groups).  > 0: ALIGNED -- every group is cut into P parts of
                  // L items, workgroup gl = group * P + part; a range never crosses a group, so a workgroup has ONE
                  // segment / flush and one record slot
+  // ---- launch order (which workgroup of the grid takes which range; never changes what a range computes)
+  int Gp;        // 0: legacy order (grid = G workgroups, each XCD takes a contiguous eighth of ALL ranges).  > 0:
+                 // utterance-sequential order: grid = B * Gp workgroups, Gp = Gu rounded up to a multiple of the XCD
+                 // count; the utterances are walked one after the other and inside an utterance each XCD takes a
+                 // contiguous eighth of its ranges (launch slots beyond Gu exit at once)
+  int rev;       // utterance-sequential order only: walk the utterances last to first
 };
 
 // A workgroup whose range crosses a group boundary pays a second prologue / flush (3-5 us measured, on the critical
@@ -53,6 +59,8 @@ struct FlatPart {
 // parts = the 512 resident workgroups exactly.  The covariance / basis passes (1025 bins, 2048 workgroups) cannot be.
 inline FlatPart make_flat(int B, long long NB, int len, long long G_target) {
   FlatPart p;
+  p.Gp = 0;
+  p.rev = 0;
   p.NB = NB;
   p.len = len;
   p.Ju = (int)(NB / len);
@@ -158,6 +166,30 @@ __device__ __forceinline__ int xcd_local_range(int bid, int G) {
   const int x = bid % N_XCD, j = bid / N_XCD;
   const int q = G / N_XCD, r = G % N_XCD;
   return x * q + (x < r ? x : r) + j;
+}
+
+// Range of workgroup `bid` of the launch; < 0: a padding slot of the utterance-sequential order.
+// Utterance-sequential order (fp.Gp > 0): with more than one utterance per launch the workgroups run in rounds, and
+// X (B x 268.7 MB at config 4) streams through the 256 MiB Infinity Cache once per pass.  In the legacy order every
+// XCD works on a different utterance at the same time, so nothing of X survives from one pass to the next.  Here all
+// XCDs work on the same utterance (each on a contiguous eighth of its ranges, which keeps the per-bin rows and the
+// utterance's activation local to an XCD's L2 as before), utterance after utterance, and consecutive passes alternate
+// the direction: a pass starts with the utterance the previous pass ended with -- the one the cache still holds.
+__device__ __forceinline__ int workgroup_range(int bid, int grid, const FlatPart& fp) {
+  if (fp.Gp == 0) return xcd_local_range(bid, grid);
+  const int Gp = fp.Gp, B = grid / Gp;
+  int b = bid / Gp;
+  const int r = bid - b * Gp;
+  const int x = r % N_XCD, j = r / N_XCD;  // Gp is a multiple of N_XCD: x is the XCD this workgroup is dealt to
+  const int q = fp.Gu / N_XCD, rem = fp.Gu % N_XCD;
+  const int cnt = q + (x < rem ? 1 : 0);  // ranges of this XCD's eighth
+  if (j >= cnt) return -1;
+  const int first = x * q + (x < rem ? x : rem);
+  if (fp.rev) {  // everything backwards: the most recently streamed lines are read first (a forward re-read of a set
+    b = B - 1 - b;  // slightly larger than the cache evicts every line just before it is needed)
+    return b * fp.Gu + first + (cnt - 1 - j);
+  }
+  return b * fp.Gu + first + j;
 }
 
 constexpr int DX = 4;  // X prefetch depth in 64-frame blocks: keeps >= 4 KB of X in flight per wave (Little's law:
@@ -333,7 +365,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int s0 = (lane / FB) * SPL;            // first source of this lane group
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
+  const int g = workgroup_range((int)blockIdx.x, (int)gridDim.x, a.fp);
+  if (g < 0) return;
   Cursor cc;                             // consume cursor
   int nblk;
   if (!flat_start(a.fp, g, cc.b, cc.f, cc.tb, nblk)) return;
@@ -674,7 +707,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
+  const int g = workgroup_range((int)blockIdx.x, (int)gridDim.x, a.fp);
+  if (g < 0) return;
   Cursor c0;
   int nblk;
   if (!flat_start(a.fp, g, c0.b, c0.f, c0.tb, nblk)) return;
@@ -841,7 +875,8 @@ __global__ void __launch_bounds__(64, MINW)
   const int lane = threadIdx.x & (WAVE - 1);
   const int F = a.d.F, T = a.d.T, K = a.d.K, TBk = a.fp.len;
   const size_t FT = (size_t)F * T;
-  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
+  const int g = workgroup_range((int)blockIdx.x, (int)gridDim.x, a.fp);
+  if (g < 0) return;
   Cursor cc;
   int nblk;
   if (!flat_start(a.fp, g, cc.b, cc.f, cc.tb, nblk)) return;
@@ -1400,7 +1435,8 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int F = a.d.F, T = a.d.T, K = a.d.K;
   const int TBk = (T + WAVE - 1) / WAVE;
   const size_t FT = (size_t)F * T;
-  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
+  const int g = workgroup_range((int)blockIdx.x, (int)gridDim.x, a.fp);
+  if (g < 0) return;
   long long q0, q1;
   flat_range(a.fp, g, q0, q1);
   if (q0 >= q1) return;
@@ -1535,7 +1571,8 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
   const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int F = a.d.F, T = a.d.T, K = a.d.K;
   const size_t FT = (size_t)F * T;
-  const int g = xcd_local_range((int)blockIdx.x, (int)gridDim.x);
+  const int g = workgroup_range((int)blockIdx.x, (int)gridDim.x, a.fp);
+  if (g < 0) return;
   // this workgroup's items (frame block, bin) in 32-bit arithmetic (flat_start): the 64-bit divisions of a global item
   // index were ~2 us at the head of the kernel, before its first load (in-kernel timestamps)
   int b, tb_first, f_first, nitems;
