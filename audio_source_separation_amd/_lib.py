@@ -35,6 +35,7 @@ SIGNATURES = {
     "assx_last_error": (ctypes.c_char_p, [_vp]),
     "assx_version": (ctypes.c_char_p, []),
     "assx_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "assx_launch_order": (_i, [_i, _i, _i, _i, _vp, _i]),
     "assx_demix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_cov_accumulate": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),

@@ -1190,6 +1190,22 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
 // ==========================================================================================
 extern "C" {
 
+int assx_launch_order(int B, int F, int T, int reverse, int* ranges, int capacity) {
+  if (B < 1 || F < 1 || T < 1) return ASSX_E_ARG;
+  FlatPart fp = flat_cov(B, F, T, 1);
+  int grid = fp.G;
+  if (B >= 2) {
+    fp.Gp = (fp.Gu + N_XCD - 1) / N_XCD * N_XCD;
+    fp.rev = reverse ? 1 : 0;
+    grid = B * fp.Gp;
+  }
+  if (ranges) {
+    if (capacity < grid) return ASSX_E_ARG;
+    for (int bid = 0; bid < grid; ++bid) ranges[bid] = workgroup_range(bid, grid, fp);
+  }
+  return grid;
+}
+
 size_t assx_workspace_bytes(int B, int M, int F, int T, int K, int dtype) {
   if (B < 1 || M < 1 || F < 1 || T < 1) return 0;
   if (widem::handles(M)) return widem::workspace_bytes(B, M, F, T, K, dtype);

@@ -162,7 +162,7 @@ __device__ __forceinline__ void advance(Cursor& c, int TBk, int F) {
 // ranges keeps what is re-read from L2 -- the activation tiles, the per-bin rows -- local: with 8 utterances in
 // flight every XCD then sees one utterance's V (0.5 MB) instead of all eight (4.2 MB, more than its L2).
 constexpr int N_XCD = 8;
-__device__ __forceinline__ int xcd_local_range(int bid, int G) {
+__host__ __device__ __forceinline__ int xcd_local_range(int bid, int G) {
   const int x = bid % N_XCD, j = bid / N_XCD;
   const int q = G / N_XCD, r = G % N_XCD;
   return x * q + (x < r ? x : r) + j;
@@ -175,7 +175,7 @@ __device__ __forceinline__ int xcd_local_range(int bid, int G) {
 // XCDs work on the same utterance (each on a contiguous eighth of its ranges, which keeps the per-bin rows and the
 // utterance's activation local to an XCD's L2 as before), utterance after utterance, and consecutive passes alternate
 // the direction: a pass starts with the utterance the previous pass ended with -- the one the cache still holds.
-__device__ __forceinline__ int workgroup_range(int bid, int grid, const FlatPart& fp) {
+__host__ __device__ __forceinline__ int workgroup_range(int bid, int grid, const FlatPart& fp) {
   if (fp.Gp == 0) return xcd_local_range(bid, grid);
   const int Gp = fp.Gp, B = grid / Gp;
   int b = bid / Gp;

@@ -91,6 +91,14 @@ const char* assx_version(void);
 /* scratch bytes sufficient for any call below at these sizes (n_basis > 4 adds one (B,N,F,T) real array and the
  * scratch of the batched NMF update: the source model then runs on the matrix cores) */
 size_t assx_workspace_bytes(int B, int M, int F, int T, int K, int dtype);
+/* Host-side query (no GPU): the launch order of a batched streaming pass over X (covariance / basis partition of
+ * (B, F, T); csrc/assx_stream.hpp: workgroup_range).  ranges[w] = the range of the partition that workgroup w of the
+ * grid takes, -1 for a padding slot; returns the grid size (pass ranges = NULL to size the array), < 0 on bad
+ * arguments.  B == 1: the XCD-aware order over all ranges; B >= 2: utterance after utterance, each XCD (w % 8) on a
+ * contiguous eighth of an utterance's ranges, everything backwards when `reverse` != 0 -- consecutive passes alternate,
+ * so that a pass starts with what the previous one left in the Infinity Cache.  The order never changes a result;
+ * tests/test_cabi_and_host.py checks that it is a permutation.  No reference counterpart (the reference is NumPy). */
+int assx_launch_order(int B, int F, int T, int reverse, int* ranges, int capacity);
 
 /* ---- (a3) demixing  y = W x ----------------------------------------------------------- */
 /* ILRMAbase.separate / IVAbase.separate  (src/bss/ilrma.py:153-165, src/bss/iva.py:105-117).

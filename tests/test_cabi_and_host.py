@@ -39,6 +39,45 @@ def test_workspace_queries_need_no_gpu():
     assert _lib.lib.assx_nmf_workspace_bytes(1, 1025, 4096, 32, _lib.F64) > 2 * 1025 * 4096 * 8
 
 
+@pytest.mark.parametrize("forced_g", [0, 1, 3, 7, 8, 9, 100])
+@pytest.mark.parametrize("B,F,T", [(1, 1025, 4096), (2, 1025, 4096), (8, 1025, 4096), (3, 33, 200), (5, 7, 64), (2, 1, 1)])
+def test_launch_order_is_a_permutation(monkeypatch, forced_g, B, F, T):
+    """Every range of a batched streaming pass is taken by exactly one workgroup, in either direction; utterances
+    are walked one after the other and an XCD (workgroup index % 8) owns a contiguous run of an utterance's ranges."""
+    from audio_source_separation_amd import _lib
+    if forced_g:
+        monkeypatch.setenv("ASSX_G", str(forced_g))  # read on every call: shrinks the partition like the GPU tests do
+    else:
+        monkeypatch.delenv("ASSX_G", raising=False)
+    seen = {}
+    for rev in (0, 1):
+        grid = _lib.lib.assx_launch_order(B, F, T, rev, None, 0)
+        assert grid > 0
+        buf = (ctypes.c_int * grid)()
+        assert _lib.lib.assx_launch_order(B, F, T, rev, buf, grid) == grid
+        assert _lib.lib.assx_launch_order(B, F, T, rev, buf, grid - 1) < 0
+        r = np.asarray(buf[:], dtype=np.int64)
+        taken = r[r >= 0]
+        n = taken.size
+        assert n % B == 0 and sorted(taken.tolist()) == list(range(n)), "not a permutation of the ranges"
+        seen[rev] = r
+        if B >= 2:
+            gu, gp = n // B, grid // B
+            assert gp % 8 == 0 and gu <= gp < gu + 8
+            for b in range(B):  # launch slots b*gp .. (b+1)*gp - 1 hold exactly one utterance
+                blk = r[b * gp:(b + 1) * gp]
+                utt = set((blk[blk >= 0] // gu).tolist())
+                assert utt == {B - 1 - b if rev else b}
+                for x in range(8):  # an XCD's ranges inside the utterance: consecutive, ascending / descending
+                    mine = blk[x::8]
+                    mine = mine[mine >= 0]
+                    if mine.size > 1:
+                        assert np.all(np.diff(mine) == (-1 if rev else 1))
+    if B >= 2:
+        fwd, bwd = seen[0][seen[0] >= 0], seen[1][seen[1] >= 0]
+        assert fwd[0] // (fwd.size // B) == 0 and bwd[0] // (bwd.size // B) == B - 1
+
+
 def test_invalid_context_is_an_error_not_a_crash():
     from audio_source_separation_amd import _lib
     rc = _lib.lib.assx_demix(None, None, None, None, None, 1, 4, 8, 8, _lib.F64, None)
