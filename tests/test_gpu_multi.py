@@ -226,3 +226,45 @@ def test_bench_two_ranks_whole_flow_on_one_gpu():
     c5 = out["config5"]
     assert c5["utterances"] == 5 and c5["utterances_per_gpu"] == [3, 2] and c5["outputs_finite"]
     assert c5["value"] >= c5["value_incl_edges"] > 0 and c5["seconds_scatter"] > 0 and c5["seconds_gather"] > 0
+
+
+# ------------------------------------------------------------------------------------------
+# Launch order of a batched pass (csrc/assx_stream.hpp: workgroup_range): utterance-sequential with alternating
+# direction (default) against the first XCD-aware order (ASSX_UTT_ORDER=0).  The switch is read once per process,
+# so each order runs in its own interpreter; the order decides when a range runs, never what it computes.
+# ------------------------------------------------------------------------------------------
+_ORDER_CODE = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from audio_source_separation_amd.bss.ilrma import GaussILRMA
+from audio_source_separation_amd.bss.iva import AuxLaplaceIVA
+rng = np.random.default_rng(5)
+B, M, F, T, K = 3, 4, 37, 300, %(K)d
+X = rng.standard_normal((B, M, F, T)) + 1j * rng.standard_normal((B, M, F, T))
+h = hashlib.sha1()
+for cls, kw in ((GaussILRMA, dict(n_basis=K)), (AuxLaplaceIVA, {})):
+    np.random.seed(3)
+    m = cls(dtype=%(dtype)r, **kw)
+    Y = m(torch.from_numpy(X).to("cuda:0"), iteration=5)      # odd number of passes: both directions, both parities
+    h.update(np.ascontiguousarray(Y.cpu().numpy()).tobytes())
+    h.update(np.ascontiguousarray(np.asarray(m.demix_filter)).tobytes())
+    h.update(np.asarray(m.loss, dtype=np.float64).tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("dtype,K,forced_g", [("float64", 4, 0), ("float64", 4, 5), ("float32", 4, 11), ("float64", 10, 0)])
+def test_batched_launch_orders_give_the_same_bits(dtype, K, forced_g):
+    digests = []
+    for order in ("1", "0"):
+        env = dict(os.environ, ASSX_UTT_ORDER=order, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if forced_g:
+            env["ASSX_G"] = str(forced_g)  # a handful of long ranges per utterance: padding slots, ragged eighths
+        else:
+            env.pop("ASSX_G", None)
+        r = subprocess.run([sys.executable, "-c", _ORDER_CODE % dict(root=ROOT, dtype=dtype, K=K)], capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
