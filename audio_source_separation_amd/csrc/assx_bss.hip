@@ -921,7 +921,7 @@ inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / 
 // Launch order of a streaming pass over X (assx_stream.hpp: workgroup_range): utterance-sequential with the direction
 // alternating from pass to pass when the launch holds more than one utterance; ASSX_UTT_ORDER=0 restores the legacy
 // order (A/B runs).  Returns the grid size.  The order decides WHEN a range runs, never what it computes.
-inline unsigned stream_grid(assx_ctx* ctx, FlatPart& fp, int B) {
+inline unsigned set_launch_order(FlatPart& fp, int B, int rev) {
   static const int on = env_int("ASSX_UTT_ORDER", 1);
   if (!on || B < 2) {
     fp.Gp = 0;
@@ -929,8 +929,11 @@ inline unsigned stream_grid(assx_ctx* ctx, FlatPart& fp, int B) {
     return (unsigned)fp.G;
   }
   fp.Gp = (fp.Gu + N_XCD - 1) / N_XCD * N_XCD;
-  fp.rev = (int)(ctx->stream_pass++ & 1u);
+  fp.rev = rev ? 1 : 0;
   return (unsigned)B * (unsigned)fp.Gp;
+}
+inline unsigned stream_grid(assx_ctx* ctx, FlatPart& fp, int B) {
+  return set_launch_order(fp, B, B >= 2 ? (int)(ctx->stream_pass++ & 1u) : 0);
 }
 
 // covariance (any weight kind): streaming partials, then dense U; returns error code
@@ -1193,12 +1196,7 @@ extern "C" {
 int assx_launch_order(int B, int F, int T, int reverse, int* ranges, int capacity) {
   if (B < 1 || F < 1 || T < 1) return ASSX_E_ARG;
   FlatPart fp = flat_cov(B, F, T, 1);
-  int grid = fp.G;
-  if (B >= 2) {
-    fp.Gp = (fp.Gu + N_XCD - 1) / N_XCD * N_XCD;
-    fp.rev = reverse ? 1 : 0;
-    grid = B * fp.Gp;
-  }
+  const int grid = (int)set_launch_order(fp, B, reverse);
   if (ranges) {
     if (capacity < grid) return ASSX_E_ARG;
     for (int bid = 0; bid < grid; ++bid) ranges[bid] = workgroup_range(bid, grid, fp);

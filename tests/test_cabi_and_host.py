@@ -50,6 +50,7 @@ def test_launch_order_is_a_permutation(monkeypatch, forced_g, B, F, T):
     else:
         monkeypatch.delenv("ASSX_G", raising=False)
     seen = {}
+    legacy = os.environ.get("ASSX_UTT_ORDER", "1") == "0"  # read once per process by the library
     for rev in (0, 1):
         grid = _lib.lib.assx_launch_order(B, F, T, rev, None, 0)
         assert grid > 0
@@ -61,6 +62,8 @@ def test_launch_order_is_a_permutation(monkeypatch, forced_g, B, F, T):
         n = taken.size
         assert n % B == 0 and sorted(taken.tolist()) == list(range(n)), "not a permutation of the ranges"
         seen[rev] = r
+        if legacy:  # ASSX_UTT_ORDER=0 in the environment of this run: the older order, a permutation is all it promises
+            continue
         if B >= 2:
             gu, gp = n // B, grid // B
             assert gp % 8 == 0 and gu <= gp < gu + 8
@@ -73,7 +76,7 @@ def test_launch_order_is_a_permutation(monkeypatch, forced_g, B, F, T):
                     mine = mine[mine >= 0]
                     if mine.size > 1:
                         assert np.all(np.diff(mine) == (-1 if rev else 1))
-    if B >= 2:
+    if B >= 2 and not legacy:
         fwd, bwd = seen[0][seen[0] >= 0], seen[1][seen[1] >= 0]
         assert fwd[0] // (fwd.size // B) == 0 and bwd[0] // (bwd.size // B) == B - 1
 
