@@ -1,3 +1,8 @@
+# Outputs of the probes of the last session of round 2 -> gpurun_out/r02s5/ (copied to profiles/r02_*.txt by hand).
+# The two .hip probes are compiled HERE when their binaries did not travel (hipcc takes minutes on a fresh box:
+# build them before calling gpurun: hipcc --offload-arch=gfx950 -O3 -w tools/probes/X.hip -o tools/probes/X.bin).
+[ -x tools/probes/barrier_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/barrier_cost_probe.hip -o tools/probes/barrier_probe.bin
+[ -x tools/probes/vgpr_bank_probe.bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w tools/probes/vgpr_bank_probe.hip -o tools/probes/vgpr_bank_probe.bin
 O=gpurun_out/r02s5; mkdir -p $O
 tools/probes/barrier_probe.bin > $O/barrier_cost_probe.txt 2>&1
 tools/probes/vgpr_bank_probe.bin > $O/vgpr_bank_probe.txt 2>&1
