@@ -14,8 +14,6 @@ try:  # torch is the allocator / stream provider, not the compute engine
 except Exception as exc:  # pragma: no cover
     raise ImportError("PyTorch-ROCm is required as the device-memory container: %r" % (exc,))
 
-_CTX = {}
-
 REAL = {"float64": (torch.float64, torch.complex128, _lib.F64, np.float64, np.complex128),
         "float32": (torch.float32, torch.complex64, _lib.F32, np.float32, np.complex64)}
 
@@ -43,17 +41,40 @@ def require_gpu(device=None):
     return dev
 
 
+class _ThreadContexts:
+    """The assx contexts of ONE host thread (device index -> handle); destroyed with the thread."""
+
+    def __init__(self):
+        self.by_device = {}
+
+    def __del__(self):
+        for h in self.by_device.values():
+            try:
+                _lib.lib.assx_ctx_destroy(h)
+            except Exception:  # interpreter shutdown
+                pass
+        self.by_device = {}
+
+
+_TLS = threading.local()
+
+
 def context(dev):
-    """One assx context per (device, host thread), as include/assx.h specifies: a context is not thread-safe (it holds
-    the last error message), so two threads driving the same GPU get two contexts."""
-    key = (dev.index, threading.get_ident())
-    if key not in _CTX:
+    """The calling thread's assx context for `dev`, as include/assx.h specifies: a context is not thread-safe (last
+    error message, launch state, the staging ring), so two threads driving the same GPU get two contexts.  Resolved
+    per CALL (Engine.ctx is a property): a model built in one thread and driven from another uses the driving
+    thread's context.  A thread's contexts are destroyed when the thread ends."""
+    held = getattr(_TLS, "held", None)
+    if held is None:
+        held = _TLS.held = _ThreadContexts()
+    h = held.by_device.get(dev.index)
+    if h is None:
         h = ctypes.c_void_p()
         rc = _lib.lib.assx_ctx_create(int(dev.index), ctypes.byref(h))
         if rc != 0:
             raise _lib.AssxError("assx_ctx_create(%d) failed with code %d" % (dev.index, rc))
-        _CTX[key] = h
-    return _CTX[key]
+        held.by_device[dev.index] = h
+    return h
 
 
 def stream_ptr(dev):
@@ -67,19 +88,69 @@ def ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_NP_CODE = {np.dtype(np.float64): (_lib.F64, 1), np.dtype(np.float32): (_lib.F32, 1),
+            np.dtype(np.complex128): (_lib.F64, 2), np.dtype(np.complex64): (_lib.F32, 2)}
+_T_CODE = {torch.float64: (_lib.F64, 1), torch.float32: (_lib.F32, 1),
+           torch.complex128: (_lib.F64, 2), torch.complex64: (_lib.F32, 2)}
+_T_NP = {torch.float64: np.float64, torch.float32: np.float32, torch.complex128: np.complex128,
+         torch.complex64: np.complex64}
+
+
+def _native_call(dev, fn, *args):
+    """libassx refuses a call whose context device is not current (include/assx.h)."""
+    if torch.cuda.current_device() == dev.index:
+        return fn(*args)
+    with torch.cuda.device(dev):
+        return fn(*args)
+
+
 def to_device(a, dtype, dev):
-    """numpy array or torch tensor -> contiguous device tensor of `dtype` (copy only when needed)."""
+    """numpy array or torch tensor -> contiguous device tensor of `dtype` (copy only when needed).
+
+    A NumPy array goes through `assx_upload` (csrc/assx_xfer.hip): chunks ride a ring of pinned staging buffers, host
+    threads copy -- and convert to the device precision, so float32 mode moves half the bytes -- while the previous
+    chunk is on the bus.  The call returns once the host array has been consumed; the tail of the DMA is ordered before
+    later work on torch's current stream."""
     if isinstance(a, torch.Tensor):
-        t = a.to(device=dev, dtype=dtype)
-    else:
-        arr = np.ascontiguousarray(a)
-        t = torch.from_numpy(arr).to(device=dev, dtype=dtype)
-    return t.contiguous()
+        return a.to(device=dev, dtype=dtype).contiguous()
+    arr = np.ascontiguousarray(a)
+    code = _T_CODE.get(dtype)
+    if code is None:  # not a floating array of the path (status words, ...): torch's own copy
+        return torch.from_numpy(np.array(arr, copy=True)).to(device=dev, dtype=dtype).contiguous()
+    if arr.dtype not in _NP_CODE or _NP_CODE[arr.dtype][1] > code[1]:
+        # integer / bool / float16 input, or complex -> real (rejected by NumPy's own casting rules loudly)
+        arr = arr.astype(_T_NP[dtype])
+    hcode, hwidth = _NP_CODE[arr.dtype]
+    if hwidth < code[1]:  # real array into a complex tensor
+        arr = arr.astype(np.complex128 if hcode == _lib.F64 else np.complex64)
+        hwidth = 2
+    t = torch.empty(arr.shape, dtype=dtype, device=dev)
+    if arr.size:
+        ctx = context(dev)
+        rc = _native_call(dev, _lib.lib.assx_upload, ctx, ctypes.c_void_p(arr.ctypes.data), hcode,
+                          ctypes.c_void_p(t.data_ptr()), code[0], arr.size * hwidth, stream_ptr(dev))
+        _lib.check(ctx, rc, "assx_upload")
+    return t
 
 
 def to_numpy(t, np_dtype=None):
-    a = t.detach().cpu().numpy()
-    return a.astype(np_dtype, copy=False) if np_dtype is not None else a
+    """device tensor -> fresh NumPy array of `np_dtype` (default: the tensor's own type) through `assx_download`: pinned
+    staging ring, host threads convert / first-touch the destination while the next chunk is on the bus."""
+    t = t.detach()
+    code = _T_CODE.get(t.dtype)
+    out_dt = np.dtype(np_dtype) if np_dtype is not None else (np.dtype(_T_NP[t.dtype]) if code else None)
+    if (not t.is_cuda) or code is None or out_dt not in _NP_CODE or _NP_CODE[out_dt][1] != code[1]:
+        a = t.cpu().numpy()
+        return a.astype(np_dtype, copy=False) if np_dtype is not None else a
+    t = t.contiguous()
+    out = np.empty(tuple(t.shape), dtype=out_dt)
+    if out.size:
+        dev = t.device
+        ctx = context(dev)
+        rc = _native_call(dev, _lib.lib.assx_download, ctx, ctypes.c_void_p(t.data_ptr()), code[0],
+                          ctypes.c_void_p(out.ctypes.data), _NP_CODE[out_dt][0], out.size * code[1], stream_ptr(dev))
+        _lib.check(ctx, rc, "assx_download")
+    return out
 
 
 class Workspace:

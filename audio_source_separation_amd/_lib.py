@@ -77,6 +77,8 @@ SIGNATURES = {
     "assx_stft_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "assx_stft": (_i, [_vp, _vp, _vp, _d, _vp, _vp, _i, _ll, _i, _i, _i, _i, _vp]),
     "assx_istft": (_i, [_vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_upload": (_i, [_vp, _vp, _i, _vp, _i, _sz, _vp]),
+    "assx_download": (_i, [_vp, _vp, _i, _vp, _i, _sz, _vp]),
 }
 
 

@@ -22,6 +22,7 @@ int assx_ctx_create(int device, assx_ctx** out) {
 
 int assx_ctx_destroy(assx_ctx* ctx) {
   if (!ctx) return ASSX_E_NULL;
+  assx::xfer_destroy(ctx);
   free(ctx);
   return 0;
 }

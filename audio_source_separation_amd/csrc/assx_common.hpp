@@ -20,9 +20,13 @@ struct assx_ctx {
   // streaming passes launched so far: consecutive passes walk the utterances of a batch in opposite directions (the
   // one a pass ends with is what the Infinity Cache still holds when the next pass starts).  Never changes a result.
   unsigned stream_pass;
+  // pinned staging ring + host thread pool of assx_upload / assx_download (csrc/assx_xfer.hip), created on first use
+  void* xfer;
 };
 
 namespace assx {
+
+void xfer_destroy(assx_ctx* ctx);  // csrc/assx_xfer.hip
 
 struct NmfGroupScope {  // sets assx_ctx::nmf_group for the NMF calls made inside the scope
   assx_ctx* c;

@@ -1,19 +1,22 @@
 // Streaming kernels of the ILRMA / AuxIVA iteration: the three passes over X that dominate the runtime.
 //
-// Design (measured on MI355X):
-//   * ONE WAVE PER SOURCE.  A wave keeps only its own source's accumulators (M*M = 16 reals for the
-//     covariance, 2*KU = 8 for the NMF contractions) instead of all N of them, which takes the kernels
-//     from ~230 VGPRs (2 waves/SIMD, latency-bound at ~2.5 TB/s) to < 100 VGPRs.  The N waves that share a
-//     bin sit in ONE workgroup and walk the same frames together, so X comes from HBM once and the other
-//     N-1 reads hit that CU's L1 / the XCD's L2.
-//   * FLAT BALANCED PARTITION.  The (utterance, bin, 64-frame block) space is flattened and cut into G equal
-//     contiguous ranges, G = a small multiple of what the chip holds concurrently, so F = 1025 bins never
-//     quantise badly against 256 CUs.  A range may straddle a bin boundary: the wave then flushes its
-//     accumulators (a 15-shuffle butterfly reduce-scatter) into a per-(workgroup, slot) partial record;
-//     finalize kernels know which records cover a bin from the partition arithmetic alone (no atomics,
-//     run-to-run bit-stable).
-//   * REGISTER DOUBLE BUFFERING.  The loads of block q+1 (X row slices and the weight inputs) are issued
-//     before block q is consumed.
+// Design (measured on MI355X; DESIGN.md sections 4.1, 4.1.1, 4.2):
+//   * ALL SOURCES IN ONE WAVE, one wave per workgroup.  A lane owns one frame of a 64-frame block; the wave forms the
+//     M*M Hermitian products of its frames ONCE and fans each product into the N sources' accumulators (N*M*M reals
+//     per lane at M = 4; measured 2.7x fewer instructions than one wave per source, which repeats the products and
+//     the address arithmetic per source).  Per-bin rows (demixing filter, basis) are wave-uniform: SGPRs / broadcast
+//     loads.
+//   * FLAT BALANCED PARTITION (FlatPart below).  An utterance's (bin, 64-frame block) items are cut into equal
+//     contiguous ranges, a small multiple of what the chip holds concurrently, so F = 1025 bins never quantise badly
+//     against 256 CUs.  A range may straddle a bin boundary: the wave then flushes its accumulators (butterfly
+//     reduce-scatter) into a per-(workgroup, slot) partial record; the consumers know which records cover a bin from
+//     the partition arithmetic alone (no atomics, run-to-run bit-stable).  When the workgroup budget is a whole
+//     number of parts per group the partition is aligned to the groups instead (one segment, one record).
+//   * EXPLICIT MEMORY PIPELINE.  X blocks ride a register ring that is refilled IN PLACE by tied inline-asm buffer
+//     loads (depth = the kernel's D template parameter, 2-3 blocks); the activation tile of block i+2 lands in a
+//     wave-private LDS ring through LDS-direct loads (VTileDma, VDMA_SLOTS deep) and costs no registers.  Neither is
+//     visible to the compiler's wait-count model, so every `s_waitcnt vmcnt(N)` is written out and the distances are
+//     part of the kernels' contract with themselves (tests shrink the partition with ASSX_G to walk every trip kind).
 #pragma once
 #include <cstdlib>
 #include "assx_common.hpp"
@@ -70,9 +73,11 @@ inline FlatPart make_flat(int B, long long NB, int len, long long G_target) {
   const long long parts = G / p.Ju;
   static const bool align = getenv("ASSX_ALIGN") == nullptr || atoi(getenv("ASSX_ALIGN")) != 0;  // A/B switch
   if (align && parts >= 1 && parts <= len && p.Ju * parts * 100 >= G * 97) {
-    p.P = (int)parts;
+    // L first, then only as many parts as are not empty (len = 31 into 31 parts of L = 2 would leave 15 parts
+    // without an item: idle workgroups, and record / loss-partial slots nobody writes)
     p.L = (int)((len + parts - 1) / parts);
-    p.Gu = (int)(p.Ju * parts);
+    p.P = (len + p.L - 1) / p.L;
+    p.Gu = p.Ju * p.P;
     p.G = B * p.Gu;
     p.S = 1;
     return p;
@@ -191,10 +196,6 @@ __host__ __device__ __forceinline__ int workgroup_range(int bid, int grid, const
   }
   return b * fp.Gu + first + j;
 }
-
-constexpr int DX = 4;  // X prefetch depth in 64-frame blocks: keeps >= 4 KB of X in flight per wave (Little's law:
-                       // ~50 KB per CU are needed to cover HBM latency at 6 TB/s)
-constexpr int DW = 2;  // prefetch depth of the weight inputs (L2-resident)
 
 
 // ------------------------------------------------------------------------------------------

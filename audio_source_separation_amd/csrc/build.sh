@@ -14,7 +14,7 @@ FLAGS="$FLAGS ${ASSX_EXTRA_FLAGS:-}"
 OBJ=${ASSX_OBJ:-$OBJ}; mkdir -p "$OBJ"
 OUT=${ASSX_OUT:-libassx.so}
 pids=()
-for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem; do
+for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfer; do
   stale=0
   [ -f "$OBJ/$src.o" ] || stale=1
   for dep in "$src.hip" *.hpp ../../include/assx.h build.sh; do
@@ -26,5 +26,5 @@ for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o $OBJ/assx_xfer.o -lpthread
 echo "built $(pwd)/$OUT"

@@ -43,9 +43,14 @@ class Engine:
     def __init__(self, dtype="float64", device=None):
         self.dev = require_gpu(device)
         self.prec = Precision(dtype)
-        self.ctx = context(self.dev)
+        context(self.dev)  # fail here, not at the first kernel, if the device cannot be opened
         self._ws = Workspace(self.dev)
         self._L = _DeviceGuardedLib(self.dev)
+
+    @property
+    def ctx(self):
+        """The CALLING thread's context for this engine's device (contexts are per thread, include/assx.h)."""
+        return context(self.dev)
 
     # ------------------------------------------------------------------ helpers
     def _check(self, rc, what):

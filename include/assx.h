@@ -337,6 +337,19 @@ int assx_stft(assx_ctx* ctx, const void* x, const void* window, double window_su
 int assx_istft(assx_ctx* ctx, const void* X, const void* window, double window_sum, void* y, void* ws, int C,
                int fft_size, int hop, int n_frames, int dtype, void* stream);
 
+/* ---- host <-> HBM staging of the call's input / output ---------------------------------------------------------- */
+/* The reference's __call__ takes a pageable NumPy array and returns one (src/bss/ilrma.py:203-273, src/bss/iva.py:
+ * 289-479, src/algorithm/nmf.py:22-53): these two calls are that edge.  `host` is ordinary (pageable) host memory,
+ * `dev` a device array of `count` REAL elements (a complex array of n samples is 2n reals); host_dtype / dev_dtype are
+ * ASSX_F32 / ASSX_F64 and may differ -- the conversion happens on the host inside the staging copy, so the float32
+ * mode moves half the bytes over PCIe and the caller never makes a converted host copy.  The array rides a ring of
+ * pinned buffers owned by the context (chunked, host copy threads overlap the DMA of the previous chunk).
+ * assx_upload returns once `host` has been consumed (it may be freed / overwritten); the tail of the DMA is ordered
+ * before later work on `stream`, not waited for by the host.  assx_download first orders itself after the work already
+ * queued on `stream` and returns when `host` is complete.  Environment: ASSX_XFER_THREADS, ASSX_XFER_CHUNK_MB. */
+int assx_upload(assx_ctx* ctx, const void* host, int host_dtype, void* dev, int dev_dtype, size_t count, void* stream);
+int assx_download(assx_ctx* ctx, const void* dev, int dev_dtype, void* host, int host_dtype, size_t count, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

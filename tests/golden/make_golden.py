@@ -7,6 +7,9 @@ initial state the reference drew from the global NumPy RNG, and the reference's
 outputs after k iterations.  No reference source is copied.
 
     python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+    python tests/golden/make_golden.py f4 iss     # only the named groups
+    python tests/golden/make_golden.py --verify   # regenerate into a temporary directory and compare every array of
+                                                  # every committed fixture bit for bit (exit code 1 on any difference)
 
 NumPy >= 2 note (caveat 1): the reference's IP update
 calls ``np.linalg.solve(WU, e_n)`` with a stack of vectors as ``b``
@@ -696,26 +699,49 @@ def gen_wide_variants():
     gen_f4(idlma_cases=((5, 1.5), (6, 2)), mnmf_cases=((5, 3, 3, False), (6, 4, 2, True)), shape=(13, 256))
 
 
-if __name__ == "__main__":
-    if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py iss`
-        for name in sys.argv[1:]:
+ALL_GROUPS = ("iss", "nmf", "auxiva", "ilrma", "projection_back", "edge", "ip2", "part", "tilrma", "stft", "xnmf", "k10",
+              "tilrma_k10", "consistent", "part_k10", "f4", "wide_m", "wide_variants")
+
+
+def verify(groups):
+    """Regenerate `groups` into a temporary directory and compare with the committed files: the recipe, not only the
+    data, is what pins the oracle."""
+    import tempfile
+    global OUT_DIR
+    committed = OUT_DIR
+    bad = []
+    with tempfile.TemporaryDirectory() as tmp:
+        OUT_DIR = tmp
+        for name in groups:
             globals()["gen_" + name]()
-        sys.exit(0)
-    gen_iss()
-    gen_nmf()
-    gen_auxiva()
-    gen_ilrma()
-    gen_projection_back()
-    gen_edge()
-    gen_ip2()
-    gen_part()
-    gen_tilrma()
-    gen_stft()
-    gen_xnmf()
-    gen_k10()
-    gen_tilrma_k10()
-    gen_consistent()
-    gen_part_k10()
-    gen_f4()
-    gen_wide_m()
-    gen_wide_variants()
+        OUT_DIR = committed
+        fresh = sorted(f for f in os.listdir(tmp) if f.endswith(".npz"))
+        for f in fresh:
+            path = os.path.join(committed, f)
+            if not os.path.exists(path):
+                bad.append("%s: not committed" % f)
+                continue
+            a, b = np.load(os.path.join(tmp, f), allow_pickle=False), np.load(path, allow_pickle=False)
+            if sorted(a.files) != sorted(b.files):
+                bad.append("%s: keys differ %s" % (f, sorted(set(a.files) ^ set(b.files))))
+                continue
+            for k in a.files:
+                if k == "versions":
+                    continue
+                if a[k].dtype != b[k].dtype or a[k].shape != b[k].shape or a[k].tobytes() != b[k].tobytes():
+                    bad.append("%s[%s] differs" % (f, k))
+        if groups == ALL_GROUPS:
+            for f in sorted(set(x for x in os.listdir(committed) if x.endswith(".npz")) - set(fresh)):
+                bad.append("%s: committed but no generator writes it" % f)
+    print("verified %d files, %d problems" % (len(fresh), len(bad)))
+    for line in bad:
+        print("  MISMATCH", line)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    args = sys.argv[1:]
+    if args and args[0] == "--verify":
+        sys.exit(verify(tuple(args[1:]) or ALL_GROUPS))
+    for name in (args or ALL_GROUPS):  # regenerate only the named groups, e.g. `make_golden.py iss`
+        globals()["gen_" + name]()

@@ -522,6 +522,24 @@ def test_source_update_loss_of_entry_state(eng, few_workgroups, G, M, K, domain,
         assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("F,T", [(65, 2000), (65, 3800), (256, 600)])
+def test_fused_loss_on_aligned_partitions_with_short_groups(eng, F, T):
+    """Default (un-shrunk) partitions whose workgroup budget is a whole number of parts per bin, but where the parts
+    round up to fewer non-empty ones (F = 65, T = 2000: 31 parts of 2 frame blocks over 32 blocks = 16 used): every
+    loss partial the finish kernel sums must have been written.  The scratch is poisoned with NaN first."""
+    M, K = 2, 2
+    rng = np.random.default_rng(190)
+    X, W = mixture(M, F, T, 191), rand_filters(M, F, 192)
+    Tb, V = rng.random((M, F, K)) + 0.05, rng.random((M, K, T)) + 0.05
+    Xd, Wd, Td, Vd = dev_c(eng, X[None]), dev_c(eng, W[None]), dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    ref = host(eng.ilrma_loss(Xd, Wd, Td, Vd))[0]
+    eng._scratch(1, M, F, T, K).view(torch.uint8).fill_(0xFF)  # all-ones bytes = NaN in both precisions
+    lp = eng.empty((1,), dtype=torch.float64)
+    eng.ilrma_source_update(Xd, Wd, Td, Vd, loss_prev=lp)
+    np.testing.assert_allclose(host(lp)[0], ref, rtol=tol(eng, 1e-13, 1e-6))
+    np.testing.assert_allclose(ref, orc.ilrma_loss(X, W, Tb, V, 2), rtol=tol(eng, 1e-12, 1e-5))
+
+
 @pytest.mark.parametrize("G", [0, 2, 5])
 @pytest.mark.parametrize("M,K,domain,F,T", [(4, 10, 2, 19, 150), (2, 5, 2, 8, 64), (3, 17, 1, 21, 333), (4, 70, 2, 9, 130),
                                             (2, 6, 1.5, 17, 257)])

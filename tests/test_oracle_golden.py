@@ -374,3 +374,15 @@ def test_f4_fastmnmf_update_diagonalizer(name):
     g = load_golden(name)
     Q1 = orc.fastmnmf_update_diagonalizer(g["X"], g["Q0"], g["g"], g["variance"])
     assert rel_err(Q1, g["Q1"]) < 1e-11
+
+
+@pytest.mark.skipif(not os.path.isdir(os.environ.get("ASSX_REFERENCE_SRC", "/root/reference/src")),
+                    reason="the reference only exists in the build container")
+def test_committed_fixtures_are_reproducible_by_the_committed_generator():
+    """`make_golden.py --verify` re-runs the reference into a temporary directory and compares every array of every
+    committed fixture bit for bit: a fixture the script can no longer produce is a pin without a recipe."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden.py"), "--verify"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "0 problems" in r.stdout
