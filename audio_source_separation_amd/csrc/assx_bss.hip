@@ -20,6 +20,7 @@
 #include "assx_group_linalg.hpp"
 #include "assx_partition.hpp"
 #include "assx_cov_wide.hpp"
+#include "assx_cov_mfma.hpp"
 #include "assx_nmf_internal.hpp"
 #include "assx_widem.hpp"
 
@@ -1138,6 +1139,48 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
   if (K <= KU || !wide) return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, fp_out);
   const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
   const PowSpec p2d = make_pow(2.0 / domain);
+  // 4 < n_basis <= 16: the variance contraction on the matrix cores (assx_cov_mfma.hpp); ASSX_COV_MFMA=0 keeps round 2's
+  // LDS-tile kernel for A/B runs.  Same partition, same records.
+  static const int mfma = env_int("ASSX_COV_MFMA", 1);
+  if (fused && mfma && U_dense && K <= 16 && (size_t)B * MM * K * T * sizeof(R) < 0xffffffffull) {
+    const FlatPart fw = flat_cov_wide(B, F, T, 1);
+    const Dims d{B, F, T, K};
+    const int ks = (K + 3) / 4;
+    const size_t ldsm = CovMfmaGeom<R>::lds_bytes(MM, ks);
+    // timing-experiment builds (-DCOVM_TRACE=1) stamp the trips of one workgroup into the last 64 KiB of the scratch
+    unsigned long long* covm_trace = COVM_TRACE ? (unsigned long long*)((char*)ws + L.total - 65536) : nullptr;
+#define COVM_LAUNCH(D2V, KSV)                                                                                          \
+  do {                                                                                                                 \
+    if (ldsm > 64 * 1024) {                                                                                            \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_mfma_kernel<R, MM, D2V, KSV>),              \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsm);                       \
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(cov_mfma_kernel)");                            \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((cov_mfma_kernel<R, MM, D2V, KSV>), dim3(fw.G), dim3(WAVE * COVW_BINS), ldsm, st,               \
+                       (const Cx<R>*)X, (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d, covm_trace);            \
+  } while (0)
+    if (p2d.mode == POW_ID) {
+      if (ks == 2) COVM_LAUNCH(true, 2);
+      else if (ks == 3) COVM_LAUNCH(true, 3);
+      else COVM_LAUNCH(true, 4);
+    } else {
+      if (ks == 2) COVM_LAUNCH(false, 2);
+      else if (ks == 3) COVM_LAUNCH(false, 3);
+      else COVM_LAUNCH(false, 4);
+    }
+#undef COVM_LAUNCH
+    ASSX_LAUNCH_CHECK(ctx, "cov_mfma_kernel");
+    *fp_out = fw;
+    if (records_wb) {
+      *records_wb = COVW_BINS;
+      return 0;
+    }
+    hipLaunchKernelGGL((cov_wide_finalize_kernel<R, MM>), dim3(blocks_for((size_t)B * MM * F * MM * MM, 256)), dim3(256),
+                       0, st, (const R*)ws, (Cx<R>*)U_dense, B, F, fw, (R)(1.0 / (double)T));
+    ASSX_LAUNCH_CHECK(ctx, "cov_wide_finalize_kernel");
+    *dense = true;
+    return 0;
+  }
   const int sb = cov_wide_sb<R>(MM * K);
   const size_t lds = sb == 2 ? CovWideGeom<R, 2>::lds_bytes(MM * K) : CovWideGeom<R, 1>::lds_bytes(MM * K);
   if (fused && U_dense && lds <= 144 * 1024 && (size_t)B * MM * K * T * sizeof(R) < 0xffffffffull) {

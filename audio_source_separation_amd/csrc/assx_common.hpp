@@ -191,6 +191,13 @@ __device__ __forceinline__ void buf_ldv_tied(Vec2<double>& dst, buf_u4 rsrc, uns
 __device__ __forceinline__ void buf_ldv_tied(Vec2<float>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
   asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
+// one real per lane, same contract as buf_ldv_tied
+__device__ __forceinline__ void buf_ld_tied(double& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void buf_ld_tied(float& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 // one dword per lane, global -> LDS (lane L lands at lds_addr + 4 L), invisible to the compiler's vmcnt model like
 // buf_ldv_tied.  M0 carries the LDS address; nothing else in these kernels uses M0.
 #pragma clang diagnostic push
@@ -238,6 +245,8 @@ __device__ void buf_ldv_tied(Vec2<R>& dst, buf_u4 rsrc, unsigned voff, unsigned 
 template <int N, typename R, int M>
 __device__ void wait_slot(Vec2<R> (&x)[M]);
 __device__ void buf_dword_to_lds(unsigned lds_addr, buf_u4 rsrc, unsigned voff, unsigned soff);
+__device__ void buf_ld_tied(double& dst, buf_u4 rsrc, unsigned voff, unsigned soff);
+__device__ void buf_ld_tied(float& dst, buf_u4 rsrc, unsigned voff, unsigned soff);
 template <typename R>
 __device__ Vec2<R> buf_ldv(BufRsrc r, unsigned voff, unsigned soff);
 template <typename R>
