@@ -1,6 +1,7 @@
 // Wide-channel path (5 <= M <= 8): see assx_widem.hpp for the design.  Reference citations are next to the entry
 // points in include/assx.h; the arithmetic contract (floors, exponents, Gauss-Seidel order) is the M <= 4 path's.
 #include "assx_widem.hpp"
+#include "assx_widem_cov.hpp"
 #include "assx_group_linalg.hpp"
 #include "assx_nmf_internal.hpp"
 #include "assx_partition.hpp"
@@ -14,8 +15,22 @@ constexpr int RED_THREADS = 256;
 inline unsigned nblk(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 struct Ws {
-  size_t map0, map1, u, lpart, nmf, tmp, total;
+  size_t map0, map1, u, lpart, nmf, tmp, rec, total;
 };
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+// Flat partition of src_cov_kernel (assx_widem_cov.hpp): items = (utterance, bin, 64-frame block), two workgroups'
+// worth of ranges per CU (one or two are resident, depending on M and the precision: either way the ranges are equal,
+// so there is no tail).  A fixed function of the geometry -- never an occupancy query -- so the summation order is too.
+// ASSX_G forces the number of ranges (tests: long ranges on small inputs), read on every call.
+static FlatPart flat_src_cov(int B, int F, int T) {
+  const int tbk = (T + WAVE - 1) / WAVE;
+  const int forced = env_int("ASSX_G", 0);
+  return make_flat(B, (long long)F * tbk, tbk, forced > 0 ? forced : 512);
+}
 static Ws layout(int B, int M, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   const int Kc = K < 1 ? 1 : K;
@@ -29,6 +44,9 @@ static Ws layout(int B, int M, int F, int T, int K, int dtype) {
   off += align_up((size_t)B * M * F * M * M * 2 * r, 256);
   w.lpart = off;
   off += align_up((size_t)B * ((size_t)M * RB + (size_t)M * ((T + 255) / 256) + F + 64) * 8, 256);
+  w.rec = off;  // src_cov_kernel records [g][slot][n][M*M]; ahead of the regions whose size depends on n_basis
+  const FlatPart fc = flat_src_cov(B, F, T);
+  off += align_up((size_t)fc.G * fc.S * M * M * M * r, 256);
   w.nmf = off;
   off += align_up(assx_nmf_workspace_bytes(B * M, F, T, Kc, dtype), 256);
   w.tmp = off;
@@ -328,6 +346,43 @@ static int launch_cov(assx_ctx* ctx, const void* X, const void* r, int r_kind, i
   return 0;
 }
 
+// Weighted covariance of all N = M sources, streaming (assx_widem_cov.hpp) -> dense U.  wk: WK_TV (Tb, V; n_basis K <=
+// SRC_COV_KMAX), WK_NT (V = r (B,N,T)), WK_NFT (V = r (B,N,F,T)); `domain` matters for WK_TV only.
+template <typename R, int M>
+static int launch_src_cov(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int wk, int K, double domain,
+                          double eps, void* U, void* rec, int B, int F, int T, hipStream_t st) {
+  using GEO = SrcCovGeom<R>;
+  const FlatPart fp = flat_src_cov(B, F, T);
+  const Dims d{B, F, T, K};
+  const PowSpec p2d = make_pow(wk == WK_TV ? 2.0 / domain : 1.0);
+  const dim3 grid(fp.G), block(WAVE * M);
+  const size_t lds = GEO::lds_bytes(M);
+#define SRC_COV_LAUNCH(WKV, D2V, KCV)                                                                                   \
+  hipLaunchKernelGGL((src_cov_kernel<R, M, WKV, D2V, KCV>), grid, block, lds, st, (const Cx<R>*)X, (const R*)Tb,          \
+                     (const R*)V, (R*)rec, d, fp, (R)eps, p2d)
+  if (wk == WK_NT) SRC_COV_LAUNCH(WK_NT, true, 4);
+  else if (wk == WK_NFT) SRC_COV_LAUNCH(WK_NFT, true, 4);
+  else if (p2d.mode == POW_ID) {
+    if (K <= 4) SRC_COV_LAUNCH(WK_TV, true, 4);
+    else SRC_COV_LAUNCH(WK_TV, true, SRC_COV_KMAX);
+  } else {
+    if (K <= 4) SRC_COV_LAUNCH(WK_TV, false, 4);
+    else SRC_COV_LAUNCH(WK_TV, false, SRC_COV_KMAX);
+  }
+#undef SRC_COV_LAUNCH
+  ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_kernel");
+  hipLaunchKernelGGL((src_cov_finalize_kernel<R, M>), dim3(nblk((size_t)B * M * F * M * M, 256)), dim3(256), 0, st,
+                     (const R*)rec, (Cx<R>*)U, B, F, fp, (R)(1.0 / (double)T));
+  ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_finalize_kernel");
+  return 0;
+}
+// the streaming kernel addresses an utterance's X and weight arrays with 32-bit byte offsets; ASSX_WIDEM_COV=0 keeps
+// round 2's one-workgroup-per-bin kernel on materialised weights (A/B runs)
+static bool src_cov_ok(int M, int F, int T, size_t r) {
+  static const int on = env_int("ASSX_WIDEM_COV", 1);
+  return on != 0 && (size_t)M * F * T * 2 * r < 0xffffffffull;
+}
+
 template <typename R, int M>
 static int launch_sweep(assx_ctx* ctx, int spatial, int pm, int pn, const void* U, void* W, const void* C, double* pw,
                         double thr, int32_t* status, int B, int F, int T, hipStream_t st, double den_floor = 0.0) {
@@ -398,10 +453,15 @@ int power_map(assx_ctx* ctx, const void* X, const void* W, void* P, int B, int M
 
 int cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, double eps, void* U, void* ws, int B, int M,
                    int N, int F, int T, int dtype, hipStream_t st) {
-  (void)ws;
+  const Ws L = layout(B, M, F, T, 1, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
+    using R = decltype(rt);
+    constexpr int MM = decltype(mt)::value;
     const int rk = r_kind == ASSX_W_NONE ? RK_NONE : (r_kind == ASSX_W_NT ? RK_NT : RK_NFT);
-    return launch_cov<decltype(rt), decltype(mt)::value>(ctx, X, r, rk, N, eps, U, B, F, T, st);
+    if (rk != RK_NONE && N == MM && ws && src_cov_ok(MM, F, T, sizeof(R)))
+      return launch_src_cov<R, MM>(ctx, X, nullptr, r, rk == RK_NT ? WK_NT : WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F,
+                                   T, st);
+    return launch_cov<R, MM>(ctx, X, r, rk, N, eps, U, B, F, T, st);
   });
 }
 
@@ -472,7 +532,11 @@ int tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb,
     ASSX_LAUNCH_CHECK(ctx, "widem::xi_map_kernel");
     void* U = (char*)ws + L.u;
     // Xi is used as is (the reference does not floor it); no condition-number guard, normaliser floored at eps
-    if ((rc = launch_cov<R, MM>(ctx, X, Xi, RK_NFT, MM, 0.0, U, B, F, T, st))) return rc;
+    if (src_cov_ok(MM, F, T, sizeof(R)))
+      rc = launch_src_cov<R, MM>(ctx, X, nullptr, Xi, WK_NFT, 1, 2.0, 0.0, U, (char*)ws + L.rec, B, F, T, st);
+    else
+      rc = launch_cov<R, MM>(ctx, X, Xi, RK_NFT, MM, 0.0, U, B, F, T, st);
+    if (rc) return rc;
     return launch_sweep<R, MM>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, C, power_bins, INFINITY, status, B, F, T, st, eps);
   });
 }
@@ -522,9 +586,17 @@ int ilrma_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void*
     constexpr int MM = decltype(mt)::value;
     void* Rm = (char*)ws + L.map1;
     void* U = U_out ? U_out : (void*)((char*)ws + L.u);
-    int rc = launch_variance<R>(ctx, Tb, V, Rm, domain, B * MM, F, T, K, st);
+    int rc;
+    if (src_cov_ok(MM, F, T, sizeof(R)) && K <= SRC_COV_KMAX) {  // weights rebuilt in the kernel: no variance map
+      rc = launch_src_cov<R, MM>(ctx, X, Tb, V, WK_TV, K, domain, eps, U, (char*)ws + L.rec, B, F, T, st);
+    } else {
+      if ((rc = launch_variance<R>(ctx, Tb, V, Rm, domain, B * MM, F, T, K, st))) return rc;
+      if (src_cov_ok(MM, F, T, sizeof(R)))
+        rc = launch_src_cov<R, MM>(ctx, X, nullptr, Rm, WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
+      else
+        rc = launch_cov<R, MM>(ctx, X, Rm, RK_NFT, MM, eps, U, B, F, T, st);
+    }
     if (rc) return rc;
-    if ((rc = launch_cov<R, MM>(ctx, X, Rm, RK_NFT, MM, eps, U, B, F, T, st))) return rc;
     return launch_sweep<R, MM>(ctx, spatial, pm, pn, U, W, C, power_bins, thr, status, B, F, T, st);
   });
 }
@@ -614,7 +686,11 @@ int weighted_ip(assx_ctx* ctx, const void* X, const void* r, double eps, double 
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     void* U = (char*)ws + L.u;
-    int rc = launch_cov<R, MM>(ctx, X, r, RK_NFT, MM, eps, U, B, F, T, st);
+    int rc;
+    if (src_cov_ok(MM, F, T, sizeof(R)))
+      rc = launch_src_cov<R, MM>(ctx, X, nullptr, r, WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
+    else
+      rc = launch_cov<R, MM>(ctx, X, r, RK_NFT, MM, eps, U, B, F, T, st);
     if (rc) return rc;
     return launch_sweep<R, MM>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status, B, F, T, st, den_floor);
   });
@@ -689,7 +765,11 @@ int auxiva_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     void* U = U_out ? U_out : (void*)((char*)ws + L.u);
-    int rc = launch_cov<R, MM>(ctx, X, r, RK_NT, MM, eps, U, B, F, T, st);
+    int rc;
+    if (src_cov_ok(MM, F, T, sizeof(R)))
+      rc = launch_src_cov<R, MM>(ctx, X, nullptr, r, WK_NT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
+    else
+      rc = launch_cov<R, MM>(ctx, X, r, RK_NT, MM, eps, U, B, F, T, st);
     if (rc) return rc;
     return launch_sweep<R, MM>(ctx, spatial, pm, pn, U, W, nullptr, nullptr, thr, status, B, F, T, st);
   });

@@ -220,3 +220,45 @@ def test_batched_equals_single_and_unsupported_entry_points(eng):
     with pytest.raises(AssxError):
         eng.demix(dev_c(eng, np.zeros((1, 9, 3, 70), dtype=np.complex128)),
                   dev_c(eng, np.zeros((1, 3, 9, 9), dtype=np.complex128)))  # M = 9
+
+
+@pytest.mark.parametrize("M,K,domain,G", [(5, 3, 2, 1), (6, 10, 1, 3), (7, 4, 2, 7), (8, 4, 2, 2), (8, 10, 2, 5), (8, 16, 1.5, 3),
+                                          (8, 20, 2, 3)])
+def test_src_cov_long_ranges(eng, M, K, domain, G):
+    """src_cov_kernel (csrc/assx_widem_cov.hpp) on partitions forced down to a handful of workgroups (ASSX_G), so that a
+    small input drives what a full-size utterance does: prologue, steady trips of the three-slot X ring, ranges that
+    start / end inside a bin and flush several records, basis-row reloads at bin boundaries, ragged T, every weight form
+    (rebuilt from (Tb, V) for n_basis <= 16, map given beyond / for t-ILRMA and IDLMA, (N,T) for AuxIVA); two utterances
+    in one call == one at a time, bit for bit."""
+    import os
+    F, T = 9, 777
+    rng = np.random.default_rng(300 + M + K)
+    Xs = np.stack([mixture(M, F, T, 301 + M), mixture(M, F, T, 302 + M)])
+    W = np.stack([rand_filters(M, F, 303), rand_filters(M, F, 304)])
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    V[0, 1, :, 5:9] = 0.0  # variance below eps: floored
+    r_nt, r_nft = rng.random((2, M, T)) + 0.05, rng.random((2, M, F, T)) + 0.05
+    os.environ["ASSX_G"] = str(G)
+    try:
+        Xb = dev_c(eng, Xs)
+        Ub = eng.empty((2, M, F, M, M), complex_=True)
+        Wb = dev_c(eng, W)
+        eng.ilrma_spatial_update(Xb, Wb, dev_r(eng, Tb), dev_r(eng, V), domain=domain, status=eng.new_status(2), U_out=Ub)
+        U_nt = eng.cov_accumulate(Xb, dev_r(eng, r_nt))
+        U_nft = eng.cov_accumulate(Xb, dev_r(eng, r_nft))
+        for b in range(2):
+            Wref, Uref, mask = orc.ilrma_spatial_update_ip(Xs[b], W[b].copy(), Tb[b], V[b], domain)
+            assert rel_err(host(Ub)[b], Uref) < tol(eng, 1e-12, 2e-5)
+            if b == 1:  # utterance 0 has floored variances: weights of 1e12, a sweep that amplifies rounding
+                assert rel_err(host(Wb)[b], Wref) < tol(eng, 1e-9, 2e-3)
+            assert rel_err(host(U_nt)[b], orc.weighted_covariance(Xs[b], r_nt[b])) < tol(eng, 1e-12, 2e-5)
+            assert rel_err(host(U_nft)[b], orc.weighted_covariance(Xs[b], r_nft[b])) < tol(eng, 1e-12, 2e-5)
+            U1 = eng.empty((1, M, F, M, M), complex_=True)
+            eng.ilrma_spatial_update(Xb[b:b + 1], dev_c(eng, W[b:b + 1]), dev_r(eng, Tb[b:b + 1]), dev_r(eng, V[b:b + 1]),
+                                     domain=domain, status=eng.new_status(1), U_out=U1)
+            assert torch.equal(U1[0], Ub[b])
+            assert torch.equal(eng.cov_accumulate(Xb[b:b + 1], dev_r(eng, r_nft[b:b + 1]))[0], U_nft[b])
+        Uh = host(Ub)
+        assert np.array_equal(Uh, Uh.conj().swapaxes(-1, -2))  # Hermitian bit-exact
+    finally:
+        os.environ.pop("ASSX_G", None)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Wide-channel path (5 <= M <= 8): GaussILRMA.update_once rate and per-stage times at config-4 bins / frames."""
+"""Wide-channel path (5 <= M <= 8): GaussILRMA.update_once rate and per-stage times at config-4 bins / frames.
+
+    python tools/widem_bench.py [M:K ...] [--dtype float32]      (default: 4:4 5:4 6:4 8:4 8:10, float64)"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,12 +9,15 @@ from audio_source_separation_amd.bss.ilrma import GaussILRMA
 
 F, T = 1025, 4096
 dev = torch.device("cuda", 0)
-for M, K in ((4, 4), (5, 4), (6, 4), (8, 4), (8, 10)):
+args = [a for a in sys.argv[1:] if ":" in a]
+dtype = sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv else "float64"
+cases = [tuple(int(v) for v in a.split(":")) for a in args] or [(4, 4), (5, 4), (6, 4), (8, 4), (8, 10)]
+for M, K in cases:
     g = torch.Generator(device=dev).manual_seed(M)
     X = torch.view_as_complex(torch.randn((M, F, T, 2), dtype=torch.float64, device=dev, generator=g)).contiguous()
     np.random.seed(1)
-    m = GaussILRMA(n_basis=K, recordable_loss=False)
-    m.input = X
+    m = GaussILRMA(n_basis=K, recordable_loss=False, dtype=dtype)
+    m.input = X if dtype == "float64" else X.to(torch.complex64)
     m._reset()
     for _ in range(3):
         m.update_once()
@@ -31,4 +36,4 @@ for M, K in ((4, 4), (5, 4), (6, 4), (8, 4), (8, 10)):
             fn()
         e1.record(); e1.synchronize()
         e.append("%s %.0f us" % (name, e0.elapsed_time(e1) / 5 * 1e3))
-    print("M=%d K=%d: %.3f ms/iteration = %.0f it/s  (X = %.0f MB; %s)" % (M, K, dt * 1e3, 1 / dt, X.numel() * 16 / 1e6, ", ".join(e)))
+    print("M=%d K=%d: %.3f ms/iteration = %.0f it/s  (X = %.0f MB; %s)" % (M, K, dt * 1e3, 1 / dt, X.numel() * (16 if dtype == "float64" else 8) / 1e6, ", ".join(e)))
