@@ -347,30 +347,34 @@ static int launch_cov(assx_ctx* ctx, const void* X, const void* r, int r_kind, i
 }
 
 // Weighted covariance of all N = M sources, streaming (assx_widem_cov.hpp) -> dense U.  wk: WK_TV (Tb, V; n_basis K <=
-// SRC_COV_KMAX), WK_NT (V = r (B,N,T)), WK_NFT (V = r (B,N,F,T)); `domain` matters for WK_TV only.
+// SRC_COV_KMAX and domain 2 -- callers route everything else through the variance map), WK_NT (V = r (B,N,T)),
+// WK_NFT (V = r (B,N,F,T)).
+template <typename R, int M, int WKV>
+static int launch_src_cov_as(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int K, double eps, void* rec,
+                             const FlatPart& fp, int B, int F, int T, hipStream_t st) {
+  using GEO = SrcCovGeom<R, M, WKV>;
+  if (GEO::lds_bytes > 64 * 1024) {  // > 64 KB of dynamic LDS needs the opt-in (per device: set on every launch)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(src_cov_kernel<R, M, WKV>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::lds_bytes);
+    if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(src_cov_kernel)");
+  }
+  const Dims d{B, F, T, K};
+  hipLaunchKernelGGL((src_cov_kernel<R, M, WKV>), dim3(fp.G), dim3(WAVE * M), GEO::lds_bytes, st, (const Cx<R>*)X,
+                     (const R*)Tb, (const R*)V, (R*)rec, d, fp, (R)eps);
+  ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_kernel");
+  return 0;
+}
 template <typename R, int M>
 static int launch_src_cov(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int wk, int K, double domain,
                           double eps, void* U, void* rec, int B, int F, int T, hipStream_t st) {
-  using GEO = SrcCovGeom<R>;
   const FlatPart fp = flat_src_cov(B, F, T);
-  const Dims d{B, F, T, K};
-  const PowSpec p2d = make_pow(wk == WK_TV ? 2.0 / domain : 1.0);
-  const dim3 grid(fp.G), block(WAVE * M);
-  const size_t lds = GEO::lds_bytes(M);
-#define SRC_COV_LAUNCH(WKV, D2V, KCV)                                                                                   \
-  hipLaunchKernelGGL((src_cov_kernel<R, M, WKV, D2V, KCV>), grid, block, lds, st, (const Cx<R>*)X, (const R*)Tb,          \
-                     (const R*)V, (R*)rec, d, fp, (R)eps, p2d)
-  if (wk == WK_NT) SRC_COV_LAUNCH(WK_NT, true, 4);
-  else if (wk == WK_NFT) SRC_COV_LAUNCH(WK_NFT, true, 4);
-  else if (p2d.mode == POW_ID) {
-    if (K <= 4) SRC_COV_LAUNCH(WK_TV, true, 4);
-    else SRC_COV_LAUNCH(WK_TV, true, SRC_COV_KMAX);
-  } else {
-    if (K <= 4) SRC_COV_LAUNCH(WK_TV, false, 4);
-    else SRC_COV_LAUNCH(WK_TV, false, SRC_COV_KMAX);
-  }
-#undef SRC_COV_LAUNCH
-  ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_kernel");
+  int rc;
+  if (wk == WK_NT) rc = launch_src_cov_as<R, M, WK_NT>(ctx, X, nullptr, V, 1, eps, rec, fp, B, F, T, st);
+  else if (wk == WK_NFT) rc = launch_src_cov_as<R, M, WK_NFT>(ctx, X, nullptr, V, 1, eps, rec, fp, B, F, T, st);
+  else if (domain != 2.0 || K > SRC_COV_KMAX)
+    return fail(ctx, ASSX_E_UNSUPPORTED, "src_cov_kernel rebuilds the variance for domain 2 and n_basis <= %d only", SRC_COV_KMAX);
+  else rc = launch_src_cov_as<R, M, WK_TV>(ctx, X, Tb, V, K, eps, rec, fp, B, F, T, st);
+  if (rc) return rc;
   hipLaunchKernelGGL((src_cov_finalize_kernel<R, M>), dim3(nblk((size_t)B * M * F * M * M, 256)), dim3(256), 0, st,
                      (const R*)rec, (Cx<R>*)U, B, F, fp, (R)(1.0 / (double)T));
   ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_finalize_kernel");
@@ -587,7 +591,7 @@ int ilrma_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void*
     void* Rm = (char*)ws + L.map1;
     void* U = U_out ? U_out : (void*)((char*)ws + L.u);
     int rc;
-    if (src_cov_ok(MM, F, T, sizeof(R)) && K <= SRC_COV_KMAX) {  // weights rebuilt in the kernel: no variance map
+    if (src_cov_ok(MM, F, T, sizeof(R)) && K <= SRC_COV_KMAX && domain == 2.0) {  // weights rebuilt in the kernel: no variance map
       rc = launch_src_cov<R, MM>(ctx, X, Tb, V, WK_TV, K, domain, eps, U, (char*)ws + L.rec, B, F, T, st);
     } else {
       if ((rc = launch_variance<R>(ctx, Tb, V, Rm, domain, B * MM, F, T, K, st))) return rc;

@@ -7,76 +7,103 @@
 // the HBM peak for the iteration.  Here:
 //   * one WAVE PER SOURCE, M waves per workgroup: a source's packed Hermitian sums (M*M reals per lane) are all a wave's
 //     registers hold in float64, and every wave needs the same rows of X;
-//   * X rides a three-slot LDS ring filled by LDS-direct loads (one instruction of one wave per row of 64 frames, no
-//     registers): the rows of item i+2 are requested while item i is consumed; HBM is read once, the waves read their
-//     frames back with M ds_read per item;
-//   * the weights are rebuilt in the kernel from (Tb, V) -- r = sum_k Tb[n,f,k] V[n,k,t], k ascending, fused
-//     multiply-adds, then ^(2/domain), floor, 1/x exactly as the map + reader pair did -- for n_basis <= 16 (the basis
-//     row sits one value per lane and is broadcast with v_readlane; the activation values of item i+1 are requested
-//     before the arithmetic of item i and turned into the weight after it).  Larger ranks and the callers that own a
-//     weight map (t-ILRMA's Xi, IDLMA, FastMNMF) use the same kernel in its "map given" form, AuxIVA in its (N,T) form;
 //   * work is the flat balanced partition of the streaming kernels over (utterance, bin, 64-frame block) items
 //     (assx_stream.hpp: FlatPart): no quantisation against the CU count, a record per (workgroup, bin crossed, source),
-//     reduced to dense U by a small finalize in fixed order (deterministic, batch-invariant).
-// Memory pipeline.  Per trip a wave issues [activation / weight loads of item i+1][its X row of item i+2] and, after the
-// arithmetic, waits until at most that one X request is in flight: the weight inputs have landed -- and so has the row
-// of item i+1 it requested a trip earlier (VMEM returns in order), which is what the barrier at the top of the next trip
-// publishes to the other waves.  The same barrier frees the slot item i-1 was read from for the request of item i+2.
-// All loads inside the loop are inline asm or LDS-direct (invisible to the compiler's wait model), the LDS reads are
-// inline asm as well (the compiler would otherwise drain vmcnt before any LDS read that might alias an LDS-direct load).
+//     reduced to dense U by a small finalize in fixed order (deterministic, batch-invariant);
+//   * EVERYTHING an item needs rides one LDS ring, DXS items deep, filled by LDS-direct loads (no registers): the M
+//     rows of X (wave n carries row n: HBM is read once per workgroup, the waves read their frames back with M ds_read),
+//     and -- wave-private -- the weight inputs of the wave's source: for the ILRMA form with n_basis <= 4 the four
+//     activation rows and the bin's basis row (the weight is rebuilt in the kernel: r = sum_k Tb[n,f,k] V[n,k,t], k
+//     ascending, fused multiply-adds, floor, 1/x exactly as the map + reader pair did; no variance map), otherwise one row
+//     of the caller's weights ((N,T) for AuxIVA; (N,F,T) for t-ILRMA's Xi, IDLMA, FastMNMF, ILRMA with n_basis > 4 or
+//     domain != 2, whose variance map costs half of X's bytes -- re-reading n_basis activation rows per 64 frames of ONE
+//     bin would cost more from L2 than that from HBM).
+// Why the weight inputs go through the ring as well: VMEM returns in order.  A weight input requested a trip ahead is
+// the YOUNGEST entry of the queue when it is needed, so waiting for it drains every X request behind which it queued:
+// the first version of this kernel (three X slots, weight inputs as register loads one item ahead) never had more than
+// one item of X per workgroup in flight and ran at 2.3-2.6 TB/s.  Requested together, DXS - 1 items ahead, all of an
+// item's inputs have the same age, and one counted wait per trip -- vmcnt((DXS - 2) * C), C = the instructions of one
+// item's request, the same for every wave -- leaves DXS - 2 items in flight behind the one the next trip reads.
+// Trip `it` runs the arithmetic of item `it` from REGISTERS (x, wgt: read / formed a trip earlier) and threads through it
+// the LDS reads of item it+1 and its weight chain (a dozen dependent instructions), then requests item it+DXS into the
+// slot item `it` has left.  All loads in the loop are LDS-direct or inline asm, the LDS reads are inline asm (the compiler
+// would otherwise drain vmcnt before any LDS read that might alias an LDS-direct load), every wait is explicit.
 #pragma once
 #include "assx_stream.hpp"
 
 namespace assx {
 namespace widem {
 
-template <typename R>
+constexpr int SRC_COV_KMAX = 4;  // largest n_basis whose variance is rebuilt in the kernel
+
+template <typename R, int M, int WK>
 struct SrcCovGeom {
-  static constexpr int DXS = 3;                         // X ring slots (items)
-  static constexpr int RB = WAVE * 2 * (int)sizeof(R);  // bytes of one row of X: 64 complex frames
-  static constexpr int LPR = RB / 16;                   // lanes per row of a 16-byte-per-lane LDS-direct load
-  static constexpr int RPI = WAVE / LPR;                // rows per instruction (f64: 1, f32: 2)
-  static __host__ __device__ constexpr int nxi(int M) { return (M + RPI - 1) / RPI; }  // instructions per item
-  static __host__ __device__ constexpr int mp(int M) { return nxi(M) * RPI; }          // rows per slot, padded
-  static __host__ __device__ constexpr size_t lds_bytes(int M) { return (size_t)DXS * mp(M) * RB; }
+  static constexpr int RB = WAVE * 2 * (int)sizeof(R);     // bytes of one row of X: 64 complex frames
+  static constexpr int LPR = RB / 16;                      // lanes that carry an X row (f64: 64, f32: the lower 32)
+  static constexpr int RBV = WAVE * (int)sizeof(R);        // bytes of one weight-input row: 64 reals
+  static constexpr int VR = WK == WK_TV ? SRC_COV_KMAX : 1;  // weight-input rows per wave and item
+  static constexpr int VBYTES = VR * RBV;
+  static constexpr int NVI = (VBYTES + 1023) / 1024;       // instructions that carry them (f64 ILRMA form: 2, else 1)
+  static constexpr int VLANES = VBYTES >= 1024 ? WAVE : VBYTES / 16;  // active lanes of such an instruction
+  static constexpr int TBYTES = WK == WK_TV ? 4 * WAVE : 0;  // landing area of the basis row (one dword per lane)
+  static constexpr int C = 1 + NVI + (WK == WK_TV ? 1 : 0);  // VMEM instructions of one item's request, per wave
+  static constexpr int WSLOT = VBYTES + TBYTES;            // wave-private bytes per slot
+  static constexpr int SLOT = M * RB + M * WSLOT;          // bytes per ring slot
+  static constexpr int DXS = M <= 6 ? 4 : 5;               // slots (M = 8, f64, ILRMA form: 5 x 26 KB of the CU's 160 KB)
+  static constexpr size_t lds_bytes = (size_t)DXS * SLOT;
 };
 
-constexpr int SRC_COV_KMAX = 16;  // largest n_basis whose variance is rebuilt in the kernel
-
-// this lane's frame of the row at byte offset OFF of a landed item; the value is readable after xrow_wait()
+// ---- LDS reads (inline asm: see the header).  Values are readable after the matching lds_wait<N>().
 template <int OFF>
-__device__ __forceinline__ void xrow_read_at(unsigned addr, Vec2<double>& x) {
+__device__ __forceinline__ void lds_read_cx(unsigned addr, Vec2<double>& x) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x) : "v"(addr), "n"(OFF) : "memory");
 }
 template <int OFF>
-__device__ __forceinline__ void xrow_read_at(unsigned addr, Vec2<float>& x) {
+__device__ __forceinline__ void lds_read_cx(unsigned addr, Vec2<float>& x) {
   asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(x) : "v"(addr), "n"(OFF) : "memory");
 }
-template <typename R, int M>
-__device__ __forceinline__ void xrow_wait(Vec2<R> (&x)[M]) {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int m = 0; m < M; ++m) asm volatile("" : "+v"(x[m]));
+// rows 2p and 2p+1 of the wave's weight-input tile (rows are 64 reals apart)
+template <int P>
+__device__ __forceinline__ void lds_read_rows2(unsigned addr, Vec2<double>& v) {
+  asm volatile("ds_read2st64_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(2 * P), "n"(2 * P + 1) : "memory");
 }
-__device__ __forceinline__ double lane_value(double v, int l) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-  return __hiloint2double(hi, lo);
+template <int P>
+__device__ __forceinline__ void lds_read_rows2(unsigned addr, Vec2<float>& v) {
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(2 * P), "n"(2 * P + 1) : "memory");
 }
-__device__ __forceinline__ float lane_value(float v, int l) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+__device__ __forceinline__ void lds_read_real(unsigned addr, double& v) {
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read_real(unsigned addr, float& v) {
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+}
+// the first four reals of the basis row (every lane reads the same address: a broadcast)
+__device__ __forceinline__ void lds_read_row4(unsigned addr, double (&t)[4]) {
+  Vec2<double> a, b;
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
+  t[0] = a.x, t[1] = a.y, t[2] = b.x, t[3] = b.y;
+}
+__device__ __forceinline__ void lds_read_row4(unsigned addr, float (&t)[4]) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 q;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"(addr) : "memory");
+  t[0] = q.x, t[1] = q.y, t[2] = q.z, t[3] = q.w;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// WK: WK_TV (Tb (B,N,F,K), V (B,N,K,T)), WK_NT (V = r (B,N,T)), WK_NFT (V = r (B,N,F,T)).  KC: activation values kept
-// per lane (4 or SRC_COV_KMAX; n_basis <= KC).  D2: no power (domain 2, or a weight that is used as given).
-template <typename R, int M, int WK, bool D2, int KC>
+// WK: WK_TV (Tb (B,N,F,K), V (B,N,K,T); n_basis <= SRC_COV_KMAX, domain 2), WK_NT (V = r (B,N,T)), WK_NFT (V = r (B,N,F,T))
+template <typename R, int M, int WK>
 __global__ void __launch_bounds__(WAVE * M)
     src_cov_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
-                   Dims d, FlatPart fp, R eps, PowSpec p2d) {
+                   Dims d, FlatPart fp, R eps) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int N = M, HM = M * M, NV = next_pow2_c(HM);
-  using GEO = SrcCovGeom<R>;
-  constexpr int NXI = GEO::nxi(M), MP = GEO::mp(M), RB = GEO::RB, DXS = GEO::DXS;
-  constexpr unsigned SLOT_BYTES = (unsigned)MP * RB;
+  using GEO = SrcCovGeom<R, M, WK>;
+  constexpr int RB = GEO::RB, DXS = GEO::DXS;
+  constexpr unsigned SLOT = (unsigned)GEO::SLOT;
   const int F = d.F, T = d.T, K = WK == WK_TV ? d.K : 1, TBk = fp.len;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & (WAVE - 1);
@@ -84,139 +111,163 @@ __global__ void __launch_bounds__(WAVE * M)
   const int g = (int)blockIdx.x;
   int b0, f0, tb0, nblk;
   if (!flat_start(fp, g, b0, f0, tb0, nblk)) return;  // whole workgroup: the range is wave-uniform
-  Cursor c0;
-  c0.b = b0;
-  c0.f = f0;
-  c0.tb = tb0;
   const size_t FT = (size_t)F * T;
-  const bool mine = n < NXI;  // this wave carries one X instruction per item
+  // slot layout: [M rows of X][wave 0: weight-input rows, basis row][wave 1: ...]
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wpriv = (unsigned)M * RB + (unsigned)n * GEO::WSLOT;  // this wave's private part of a slot
 
-  // ---- X requests (the range never leaves utterance b0)
+  // ---- requests.  The range never leaves utterance b0; offsets inside an utterance's arrays are 32-bit (host check).
   const BufRsrc rx = make_rsrc_sized(X + (size_t)b0 * M * FT, (size_t)M * FT * sizeof(Cx<R>));
-  const int xrow = min(n * GEO::RPI + lane / GEO::LPR, M - 1);  // the padding row of an odd M repeats row M-1
-  const unsigned xlane = (unsigned)((size_t)xrow * FT * sizeof(Cx<R>)) + (unsigned)(lane % GEO::LPR) * 16u;
-  auto request_x = [&](const Cursor& c, int sl) {
-    if (mine) {
-      // frames past T read into the next row (zeros past the end of the utterance): their weight is 0
-      const unsigned voff = xlane + (unsigned)(((size_t)c.f * T + (size_t)c.tb * WAVE) * sizeof(Cx<R>));
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rx, (__attribute__((address_space(3))) void*)(smem + (unsigned)sl * SLOT_BYTES + (unsigned)n * GEO::RPI * RB), 16,
-          (int)voff, 0, 0, 0);
-    }
-  };
-  const unsigned xread0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem + (unsigned)lane * (unsigned)sizeof(Cx<R>);
-
-  // ---- weight inputs of one item, in place (tied loads): vv[j] = V[b, n, j, t] (TV) or r[b, n, (f,) t] in vv[0]
+  const unsigned xlane = (unsigned)((size_t)n * FT * sizeof(Cx<R>)) + (unsigned)lane * 16u;  // wave n carries row n
   const size_t vrows = WK == WK_TV ? (size_t)N * K : (WK == WK_NT ? (size_t)N : (size_t)N * F);
-  buf_u4 rv = make_rsrc_words(V + (size_t)b0 * vrows * T, vrows * T * sizeof(R));
-  rv.x = __builtin_amdgcn_readfirstlane(rv.x);
-  rv.y = __builtin_amdgcn_readfirstlane(rv.y);
-  rv.z = __builtin_amdgcn_readfirstlane(rv.z);
-  rv.w = __builtin_amdgcn_readfirstlane(rv.w);
-  const unsigned vlane = (unsigned)lane * (unsigned)sizeof(R);
-  R vv[KC];
+  const BufRsrc rvb = make_rsrc_sized(V + (size_t)b0 * vrows * T, vrows * T * sizeof(R));
+  // lane -> (row, 16-byte piece) of a weight-input instruction; rows past n_basis repeat the last one (their basis is 0)
+  constexpr int LPV = GEO::RBV / 16;  // lanes per weight-input row
+  unsigned vlane[GEO::NVI];
 #pragma unroll
-  for (int j = 0; j < KC; ++j) vv[j] = 0;
-  auto request_w = [&](const Cursor& c) {
-    if (WK == WK_TV) {
-      const unsigned row0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(((size_t)n * K * T + (size_t)c.tb * WAVE) * sizeof(R)));
-      const unsigned tstep = (unsigned)__builtin_amdgcn_readfirstlane((int)((size_t)T * sizeof(R)));
-      static_for<KC>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        if (j < K) buf_ld_tied(vv[j], rv, vlane, row0 + (unsigned)j * tstep);
-      });
-    } else {
-      const size_t row = WK == WK_NT ? (size_t)n : (size_t)n * F + c.f;
-      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((row * T + (size_t)c.tb * WAVE) * sizeof(R)));
-      buf_ld_tied(vv[0], rv, vlane, soff);
-    }
-  };
-  // basis row of (source n, bin f): lane k holds Tb[b, n, f, k] (0 beyond n_basis).  A tied load like the others (a
-  // compiler-managed one would put its own vmcnt(0) -- draining the X request -- at the merge point of every trip); the
-  // mask is applied by row_value() after the trip's wait.
+  for (int j = 0; j < GEO::NVI; ++j) {
+    const int row = min(j * (WAVE / LPV) + lane / LPV, K - 1);
+    vlane[j] = (unsigned)((size_t)row * T * sizeof(R)) + (unsigned)(lane % LPV) * 16u;
+  }
   buf_u4 rt = make_rsrc_words(Tb + (size_t)b0 * N * F * K, (size_t)N * F * K * sizeof(R));
   rt.x = __builtin_amdgcn_readfirstlane(rt.x);
   rt.y = __builtin_amdgcn_readfirstlane(rt.y);
   rt.z = __builtin_amdgcn_readfirstlane(rt.z);
   rt.w = __builtin_amdgcn_readfirstlane(rt.w);
-  auto request_row = [&](const Cursor& c, R& dst) {
-    if (WK == WK_TV) {
+  // one item's inputs into ring slot sl: C instructions, the same for every wave.  Frames past T read into the next row
+  // (zeros past the end of the array): their weight is 0.
+  auto request = [&](const Cursor& c, int sl) {
+    const unsigned sbase = (unsigned)sl * SLOT;
+    if (WK == WK_TV) {  // basis row: lane L's dword lands at +4L (only the first n_basis reals are used)
       const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((((size_t)n * F + c.f) * K) * sizeof(R)));
-      buf_ld_tied(dst, rt, vlane, soff);
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + sbase + wpriv + GEO::VBYTES));
+      buf_dword_to_lds(dst, rt, (unsigned)lane * 4u, soff);
+    }
+    const size_t vrow = WK == WK_TV ? (size_t)n * K : (WK == WK_NT ? (size_t)n : (size_t)n * F + c.f);
+    const unsigned vsoff = (unsigned)((vrow * T + (size_t)c.tb * WAVE) * sizeof(R));
+#pragma unroll
+    for (int j = 0; j < GEO::NVI; ++j)
+      if (GEO::VLANES == WAVE || lane < GEO::VLANES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rvb, (__attribute__((address_space(3))) void*)(smem + sbase + wpriv + (unsigned)j * 1024u), 16, (int)vlane[j],
+            (int)vsoff, 0, 0);
+    const unsigned xoff = xlane + (unsigned)(((size_t)c.f * T + (size_t)c.tb * WAVE) * sizeof(Cx<R>));
+    if (GEO::LPR == WAVE || lane < GEO::LPR)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rx, (__attribute__((address_space(3))) void*)(smem + sbase + (unsigned)n * RB), 16, (int)xoff, 0, 0, 0);
+  };
+  // ---- LDS reads of a landed item: weight inputs first (their wait leaves the M X reads in flight), then X
+  struct WIn {
+    Vec2<R> v01, v23;  // ILRMA form: activation rows 0..3 at this lane's frame ...
+    R t[4];            // ... and the basis row (broadcast)
+    R r;               // weights given: this lane's value
+  };
+  auto read_w = [&](int sl, WIn& w) {
+    const unsigned base = lds0 + (unsigned)sl * SLOT + wpriv;
+    if (WK == WK_TV) {
+      const unsigned va = base + (unsigned)lane * (unsigned)sizeof(R);
+      lds_read_rows2<0>(va, w.v01);
+      lds_read_rows2<1>(va, w.v23);
+      lds_read_row4(base + GEO::VBYTES, w.t);
+    } else {
+      lds_read_real(base + (unsigned)lane * (unsigned)sizeof(R), w.r);
     }
   };
-  auto row_value = [&](R raw) -> R { return WK != WK_TV ? (R)1 : (lane < K ? raw : (R)0); };
-  auto weight = [&](const Cursor& c, R tbl) -> R {  // 1 / max(r^(2/domain), eps) of this lane's frame, 0 past T
+  auto read_x = [&](int sl, Vec2<R> (&xr)[M]) {
+    const unsigned xa = lds0 + (unsigned)sl * SLOT + (unsigned)lane * (unsigned)sizeof(Cx<R>);
+    static_for<M>([&](auto mc) { lds_read_cx<decltype(mc)::value * RB>(xa, xr[decltype(mc)::value]); });
+  };
+  auto fence_w = [&](WIn& w) {
+    if (WK == WK_TV) asm volatile("" : "+v"(w.v01), "+v"(w.v23), "+v"(w.t[0]), "+v"(w.t[1]), "+v"(w.t[2]), "+v"(w.t[3]));
+    else asm volatile("" : "+v"(w.r));
+  };
+  auto weight = [&](const Cursor& c, const WIn& w) -> R {  // 1 / max(r, eps) of this lane's frame, 0 past T
     R tv;
-    if (WK == WK_TV) {
-      tv = 0;
-#pragma unroll
-      for (int j = 0; j < KC; ++j) tv = fma(lane_value(tbl, j), vv[j], tv);  // k ascending; rows past n_basis add 0 * 0
+    if (WK == WK_TV) {  // k ascending from 0 (variance_map_kernel's order); entries past n_basis contribute 0 * finite
+      tv = fma(w.t[0], w.v01.x, (R)0);
+      tv = fma(K > 1 ? w.t[1] : (R)0, w.v01.y, tv);
+      tv = fma(K > 2 ? w.t[2] : (R)0, w.v23.x, tv);
+      tv = fma(K > 3 ? w.t[3] : (R)0, w.v23.y, tv);
     } else {
-      tv = vv[0];
+      tv = w.r;
     }
-    const R rr = floor_eps<R>(D2 ? tv : powspec<R>(tv, p2d), eps);  // floored AFTER the power (ilrma.py:499-509)
+    const R rr = floor_eps<R>(tv, eps);
     return c.tb * WAVE + lane < T ? fast_rcp(rr) : (R)0;
   };
 
   R acc[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) acc[q] = 0;
+  Cursor c0;  // item `it`
+  c0.b = b0;
+  c0.f = f0;
+  c0.tb = tb0;
+  // prologue: items 0 .. DXS-1 requested (past the end of the range: item 0 again -- the queue keeps its shape)
+  Cursor cr = c0;  // item it + DXS, the next one to request
+  {
+    const Cursor first = c0;
+#pragma unroll
+    for (int i = 0; i < DXS; ++i) {
+      request(i < nblk ? cr : first, i);
+      advance(cr, TBk, F);
+    }
+  }
   Cursor c1 = c0;
   advance(c1, TBk, F);
-  Cursor c2 = c1;
-  advance(c2, TBk, F);
-  // prologue: weight of item 0; X of items 0 and 1 on their way
-  R traw = 0;
-  request_row(c0, traw);
-  request_w(c0);
-  request_x(c0, 0);
-  request_x(nblk > 1 ? c1 : c0, 1);
-  if (mine) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmcnt<(DXS - 2) * GEO::C>();  // items 0 and 1 have landed (this wave's share: the barriers publish the rest)
+  asm volatile("s_barrier" ::: "memory");
+  Vec2<R> x[M];
+  R wgt;
+  {
+    WIn w;
+    read_w(0, w);
+    read_x(0, x);
+    lds_wait<0>();
+    fence_w(w);
 #pragma unroll
-  for (int j = 0; j < KC; ++j) asm volatile("" : "+v"(vv[j]));
-  asm volatile("" : "+v"(traw));
-  R tbl = row_value(traw);
-  R wgt = weight(c0, tbl);
-  int sl = 0;
+    for (int m = 0; m < M; ++m) asm volatile("" : "+v"(x[m]));
+    wgt = weight(c0, w);
+  }
+  int sl = 0;  // ring slot of item `it`
   for (int it = 0; it < nblk; ++it) {
-    const bool more = it + 1 < nblk, more2 = it + 2 < nblk;
-    // every wave's row of item `it` has landed (each waited for its own at the end of the previous trip) and nobody reads
-    // the slot of item it-1 any more.  A bare barrier: only LDS traffic crosses waves, and __syncthreads() would drain
-    // the X request that has to stay in flight.
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const Cursor c1v = more ? c1 : c0, c2v = more2 ? c2 : c0;
-    const bool new_bin = more && c1.tb == 0;  // the next item starts a new bin: its basis row
-    if (new_bin) request_row(c1, traw);
-    request_w(c1v);
-    request_x(c2v, sl == 0 ? DXS - 1 : sl - 1);  // the slot item it-1 has left
-    Vec2<R> xv[M];
-    const unsigned xaddr = xread0 + (unsigned)sl * SLOT_BYTES;
-    static_for<M>([&](auto mc) { xrow_read_at<decltype(mc)::value * RB>(xaddr, xv[decltype(mc)::value]); });
-    xrow_wait(xv);
+    const bool more = it + 1 < nblk;
+    // every wave's row of item it+1 has landed (each waited for its own at the end of the previous trip) and every wave
+    // has item `it` in registers.  A bare barrier: only LDS traffic crosses waves, and __syncthreads() would drain the
+    // requests that have to stay in flight.
+    asm volatile("s_barrier" ::: "memory");
+    const int sl1 = sl + 1 == DXS ? 0 : sl + 1;
+    WIn wn;
+    Vec2<R> xn[M];
+    read_w(sl1, wn);
+    read_x(sl1, xn);
+    request(it + DXS < nblk ? cr : c0, sl);  // past the end: the current item again (an L2 hit nobody reads)
+    lds_wait<M>();  // LDS returns in order: the weight inputs are here, the X reads may still travel
+    fence_w(wn);
+    R wgt_n = weight(more ? c1 : c0, wn);
     // x_i conj(x_j) for j >= i, weighted: diagonal terms in acc[i], pairs (re, im) at herm_pair_base
 #pragma unroll
     for (int i = 0; i < M; ++i) {
-      const R sx = wgt * xv[i].x, sy = wgt * xv[i].y;
-      acc[i] = fma(sx, xv[i].x, acc[i]);
-      acc[i] = fma(sy, xv[i].y, acc[i]);
+      const R sx = wgt * x[i].x, sy = wgt * x[i].y;
+      acc[i] = fma(sx, x[i].x, acc[i]);
+      acc[i] = fma(sy, x[i].y, acc[i]);
 #pragma unroll
       for (int j = i + 1; j < M; ++j) {
         const int hb = herm_pair_base<M>(i, j);  // compile-time after unrolling
-        acc[hb] = fma(sx, xv[j].x, acc[hb]);
-        acc[hb] = fma(sy, xv[j].y, acc[hb]);
-        acc[hb + 1] = fma(sy, xv[j].x, acc[hb + 1]);
-        acc[hb + 1] = fma(-sx, xv[j].y, acc[hb + 1]);
+        acc[hb] = fma(sx, x[j].x, acc[hb]);
+        acc[hb] = fma(sy, x[j].y, acc[hb]);
+        acc[hb + 1] = fma(sy, x[j].x, acc[hb + 1]);
+        acc[hb + 1] = fma(-sx, x[j].y, acc[hb + 1]);
       }
     }
-    // the weight inputs of item it+1 -- and this wave's X row of item it+1, requested a trip ago -- have landed once at
-    // most this trip's X request is in flight
-    if (mine) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int j = 0; j < KC; ++j) asm volatile("" : "+v"(vv[j]));
-    asm volatile("" : "+v"(traw));
+    for (int q = 0; q < HM; ++q) asm volatile("" : "+v"(acc[q]));  // the arithmetic stays HERE, above the waits (left alone
+                                                                   // it is sunk below them; the padding of acc stays foldable) ...
+    asm volatile("" : "+v"(wgt_n));  // ... and so does the weight chain of the next item
+    lds_wait<0>();
+#pragma unroll
+    for (int m = 0; m < M; ++m) asm volatile("" : "+v"(xn[m]));
+    // this wave's share of item it+2 has landed once only the requests of items it+3 .. it+DXS are in flight
+    wait_vmcnt<(DXS - 2) * GEO::C>();
     if (c1.tb == 0 || !more) {  // the bin is complete (or the range ends): flush
       const R tot = wave_reduce_scatter<R, NV>(acc);
       const int i = scatter_index<NV>();
@@ -225,14 +276,15 @@ __global__ void __launch_bounds__(WAVE * M)
 #pragma unroll
       for (int q = 0; q < NV; ++q) acc[q] = 0;
     }
-    if (new_bin) tbl = row_value(traw);
-    wgt = weight(c1v, tbl);
-    sl = sl + 1 == DXS ? 0 : sl + 1;
+#pragma unroll
+    for (int m = 0; m < M; ++m) x[m] = xn[m];
+    wgt = wgt_n;
+    sl = sl1;
     c0 = c1;
-    c1 = c2;
-    advance(c2, TBk, F);
+    advance(c1, TBk, F);
+    advance(cr, TBk, F);
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in LDS after the workgroup has gone
+  wait_vmcnt<0>();  // nothing may land in LDS after the workgroup has gone
 #endif
 }
 
