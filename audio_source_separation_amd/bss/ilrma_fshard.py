@@ -37,6 +37,7 @@ class HipShardOps:
         self.eng = Engine(dtype=dtype, device=device)
         self.device = self.eng.dev
         self.real, self.cplx = self.eng.prec.real, self.eng.prec.cplx
+        self._pb = {}
 
     def cov(self, X):
         B, M, F, T = X.shape
@@ -54,7 +55,11 @@ class HipShardOps:
 
     def spatial(self, X, W, Tb, V, C, domain, eps, threshold, status):
         B, M, F, T = X.shape
-        pb = self.eng.empty((B, M, F), dtype=torch.float64) if C is not None else None
+        pb = None
+        if C is not None:  # per-bin power statistic the entry point emits next to the sweep: one buffer per shard shape
+            pb = self._pb.get((B, M, F))
+            if pb is None:
+                pb = self._pb[(B, M, F)] = self.eng.empty((B, M, F), dtype=torch.float64)
         self.eng.ilrma_spatial_update(X, W, Tb, V, domain=domain, eps=eps, threshold=threshold, status=status, C=C,
                                       power_bins=pb)
 
@@ -230,12 +235,22 @@ class FrequencyShardedGaussILRMA:
                 blocks[r * per_rank + j] = t[: widths[r]].movedim(0, axis)
         return torch.cat(blocks, dim=axis)
 
+    def gather_state(self):
+        """COLLECTIVE: every rank must call it.  Gathers the bin-sharded model over the ranks and returns
+        (demix_filter (F,N,M), basis (N,F,K), activation (N,K,T)) as NumPy arrays on every rank."""
+        W = self._gather_bins([w[0] for w in self._Ws], axis=0).cpu().numpy().astype(np.complex128)
+        Tb = self._gather_bins([t[0] for t in self._Ts], axis=1).cpu().numpy().astype(np.float64)
+        return W, Tb, self.activation
+
     @property
     def demix_filter(self):
+        """The gathered filter.  With more than one rank this is a COLLECTIVE (an all-gather over the bin shards): read it
+        on every rank or on none -- `if rank == 0: model.demix_filter` hangs the job.  `gather_state()` says so by name."""
         return self._gather_bins([w[0] for w in self._Ws], axis=0).cpu().numpy().astype(np.complex128)
 
     @property
     def basis(self):
+        """The gathered basis: a COLLECTIVE like `demix_filter`."""
         return self._gather_bins([t[0] for t in self._Ts], axis=1).cpu().numpy().astype(np.float64)
 
     @property

@@ -250,3 +250,61 @@ def test_frequency_sharded_ilrma_two_ranks_equal_two_shards_bitwise():
         np.testing.assert_allclose(got[1], ref["loss"], rtol=1e-12)
         assert np.linalg.norm(got[2] - ref["W"]) / np.linalg.norm(ref["W"]) < 1e-10
         assert np.linalg.norm(got[3] - ref["T"]) / np.linalg.norm(ref["T"]) < 1e-11
+
+
+def test_edge_operation_lists_for_eight_ranks(monkeypatch):
+    """What `scatter_utterances` / `gather_utterances` hand to `batch_isend_irecv` on a node of 8 ranks -- peers, shapes,
+    dtypes, contiguity and aliasing of the operands -- checked without a process group (the first real 8-GPU run must not
+    die on a non-contiguous `view_as_real` view): the root sends / receives ONE op per peer on a view of its own array,
+    a peer posts exactly one op of its block's shape, nobody talks to itself, empty blocks post nothing."""
+    from audio_source_separation_amd import distributed as D
+
+    class Op:  # stands in for dist.P2POp (whose constructor needs an initialised group)
+        def __init__(self, op, tensor, peer):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    sent = []
+    monkeypatch.setattr(D.dist, "P2POp", Op)
+    monkeypatch.setattr(D, "_run_p2p", lambda ops: sent.append(list(ops)))
+    for n_items, dtype in ((64, torch.complex128), (13, torch.complex64), (5, torch.complex128)):
+        item = (4, 9, 20)
+        x_all = torch.view_as_complex(torch.arange(n_items * 4 * 9 * 20 * 2, dtype=torch.float64).reshape(
+            (n_items,) + item + (2,))).to(dtype)
+        real = x_all.real.dtype
+        for rank in range(8):
+            monkeypatch.setattr(D, "_world", lambda rank=rank: (rank, 8))
+            lo, hi = D.shard_range(n_items, 8, rank)
+            sent.clear()
+            got = D.scatter_utterances(x_all if rank == 0 else None, n_items, item, dtype, "cpu")
+            ops = sent[0] if sent else []
+            if rank == 0:
+                peers = [r for r in range(1, 8) if D.shard_range(n_items, 8, r)[1] > D.shard_range(n_items, 8, r)[0]]
+                assert [o.peer for o in ops] == peers and all(o.op is D.dist.isend for o in ops)
+                for o in ops:
+                    a, b = D.shard_range(n_items, 8, o.peer)
+                    assert o.tensor.shape == (b - a,) + item + (2,) and o.tensor.dtype == real and o.tensor.is_contiguous()
+                    assert o.tensor.data_ptr() == x_all[a:b].data_ptr()  # a view of the root's array, not a copy
+                assert got.data_ptr() == x_all[lo:hi].data_ptr()
+            elif hi > lo:
+                assert len(ops) == 1 and ops[0].op is D.dist.irecv and ops[0].peer == 0
+                assert ops[0].tensor.shape == (hi - lo,) + item + (2,) and ops[0].tensor.dtype == real
+                assert ops[0].tensor.is_contiguous() and ops[0].tensor.data_ptr() == got.data_ptr()
+            else:
+                assert ops == [] and got.shape == (0,) + item
+            # gather: the mirror image
+            sent.clear()
+            y_local = x_all[lo:hi].clone()
+            out = D.gather_utterances(y_local, n_items)
+            ops = sent[0] if sent else []
+            if rank == 0:
+                assert [o.peer for o in ops] == peers and all(o.op is D.dist.irecv for o in ops)
+                for o in ops:
+                    a, b = D.shard_range(n_items, 8, o.peer)
+                    assert o.tensor.shape == (b - a,) + item + (2,) and o.tensor.is_contiguous()
+                    assert o.tensor.data_ptr() == out[a:b].data_ptr()  # received straight into the result
+                assert torch.equal(out[lo:hi], y_local)
+            elif hi > lo:
+                assert out is None and len(ops) == 1 and ops[0].op is D.dist.isend and ops[0].peer == 0
+                assert ops[0].tensor.shape == (hi - lo,) + item + (2,) and ops[0].tensor.is_contiguous()
+            else:
+                assert out is None and ops == []

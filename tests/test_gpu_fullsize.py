@@ -282,3 +282,50 @@ def test_engine_guards_the_current_device():
             rc = _lib.lib.assx_demix(eng.ctx, ctypes.c_void_p(X.data_ptr()), ctypes.c_void_p(Wd.data_ptr()), None,
                                      ctypes.c_void_p(Y.data_ptr()), 1, 2, 5, 70, _lib.F64, None)
             assert rc == -1 and b"current device" in _lib.lib.assx_last_error(eng.ctx)
+
+
+def test_frequency_sharded_mode_full_size_matches_the_class():
+    """bss/ilrma_fshard.py at config-4 size: 4 bin shards on one process against the unsharded GaussILRMA class from the
+    same initial model, two iterations + the final projection back.  They differ by the rounding of the reduction over
+    f only (shard partials added in shard order): W, basis, activation, output to 1e-8, the recorded loss to 1e-10."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    from audio_source_separation_amd.bss.ilrma_fshard import FrequencyShardedGaussILRMA
+    M, F, T, K = 4, 1025, 4096, 4
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(77)
+    S = torch.view_as_complex(torch.randn((M, F, T, 2), dtype=torch.float64, device=dev, generator=g))
+    env = 0.1 + torch.rand((M, 1, T), dtype=torch.float64, device=dev, generator=g) ** 2
+    A = torch.view_as_complex(torch.randn((F, M, M, 2), dtype=torch.float64, device=dev, generator=g))
+    X = torch.einsum("fmn,nft->mft", A, S * env).contiguous()
+    st = np.random.RandomState(78)
+    T0, V0 = st.rand(M, F, K), st.rand(M, K, T)
+    m = FrequencyShardedGaussILRMA(n_basis=K, n_shards=4)
+    Y = m(X, iteration=2, basis=T0, activation=V0)
+    ref = GaussILRMA(n_basis=K)
+    ref.basis, ref.activation = T0, V0
+    Yr = ref(X, iteration=2)
+    Yr = Yr.cpu().numpy() if isinstance(Yr, torch.Tensor) else Yr
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)  # noqa: E731
+    assert rel(m.demix_filter, np.asarray(ref.demix_filter)) < 1e-8
+    assert rel(m.basis, np.asarray(ref.basis)) < 1e-8 and rel(m.activation, np.asarray(ref.activation)) < 1e-8
+    assert rel(Y, Yr) < 1e-8
+    np.testing.assert_allclose(m.loss, np.asarray(ref.loss), rtol=1e-10)
+
+
+@pytest.mark.parametrize("M,K", [(8, 4), (5, 4), (8, 10)])
+def test_wide_channel_full_size_oracle_step(M, K):
+    """The wide-channel path (5 <= M <= 8: src_cov_kernel's deep LDS ring, flat partition with the real 512 ranges, the
+    demixed-power map + matrix-core source model, 64-lane IP groups) at config-4 bins / frames against ONE oracle step:
+    W, basis, activation, the cond mask and the loss after it."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    X, T0, V0 = _cfg4_state(40 + M, K=K, M=M)
+    m = GaussILRMA(n_basis=K)
+    m.basis, m.activation = T0, V0
+    m.input = X
+    m._reset()
+    m.update_once()
+    W = np.tile(np.eye(M, dtype=np.complex128), (1025, 1, 1))
+    W, Tr, Vr, mask = orc.ilrma_update_once(X, W, T0, V0)
+    assert mask.all()
+    assert rel_err(m.basis, Tr) < 1e-10 and rel_err(m.activation, Vr) < 1e-10 and rel_err(m.demix_filter, W) < 1e-8
+    np.testing.assert_allclose(m.compute_negative_loglikelihood(), orc.ilrma_loss(X, W, Tr, Vr), rtol=1e-10)

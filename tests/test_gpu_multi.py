@@ -132,6 +132,46 @@ def test_rccl_single_rank_group_and_bench_under_launcher():
     assert out["config5"]["utterances"] == 3 and out["config5"]["outputs_finite"] and out["config5"]["value"] > 0
 
 
+def test_rccl_grouped_send_recv_on_views_of_a_complex_array():
+    """The edge traffic of config 5 through RCCL itself, on what one GPU can run: a 1-rank "nccl" group whose rank sends
+    to and receives from ITSELF inside one grouped batch (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd -- the
+    call sequence `scatter_utterances` / `gather_utterances` issue towards 7 peers), on exactly the operands those
+    functions build: `view_as_real` views of contiguous row blocks of a complex array at non-zero storage offsets, for a
+    ragged partition, complex128 and complex64.  Received blocks must equal the sent ones bit for bit, and the rest of
+    the destination must stay untouched.  (More than one rank over xGMI needs more than one GPU: the driver's run.)"""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='%d')\n"
+        "from audio_source_separation_amd import distributed as D\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "for dt in (torch.complex128, torch.complex64):\n"
+        "    g = torch.Generator(device=dev).manual_seed(5)\n"
+        "    x = torch.view_as_complex(torch.randn((13, 4, 9, 40, 2), dtype=torch.float64, device=dev, generator=g)).to(dt)\n"
+        "    out = torch.full_like(x, 7.0)\n"
+        "    ops, blocks = [], []\n"
+        "    for r in range(1, 8):  # the blocks of peers 1..7 of an 8-way partition of 13 utterances (ragged)\n"
+        "        a, b = D.shard_range(13, 8, r)\n"
+        "        s, d = D._as_real(x[a:b]), D._as_real(out[a:b])\n"
+        "        assert s.is_contiguous() and d.is_contiguous() and s.storage_offset() > 0 and s.dtype == x.real.dtype\n"
+        "        ops += [dist.P2POp(dist.isend, s, 0), dist.P2POp(dist.irecv, d, 0)]\n"
+        "        blocks.append((a, b))\n"
+        "    D._run_p2p(ops)\n"
+        "    torch.cuda.synchronize()\n"
+        "    a0, b0 = D.shard_range(13, 8, 0)\n"
+        "    assert torch.equal(out[b0:], x[b0:]) and bool((out[a0:b0] == 7.0).all())\n"
+        "    # the library functions themselves on a 1-rank group\n"
+        "    xl = D.scatter_utterances(x, 13, (4, 9, 40), dt, dev)\n"
+        "    assert torch.equal(D.gather_utterances(xl, 13), x)\n"
+        "assert D.max_over_ranks(3.5, device=dev) == 3.5\n"
+        "D.barrier(dev); dist.destroy_process_group(); print('edges ok')\n" % (ROOT, _free_port()))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "edges ok" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # F-sharded single utterance with the HIP shard ops (bss/ilrma_fshard.py)
 # ---------------------------------------------------------------------------------------------------------------
