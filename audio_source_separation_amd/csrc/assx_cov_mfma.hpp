@@ -19,14 +19,12 @@
 // item i (the matrix pipe works beside the vector pipe), the rcp/Newton sequence is evaluated once per (source, bin,
 // frame) by exactly one lane, and no activation tile lives in LDS.  The bits are those of cov_wide_kernel: the matrix
 // core accumulates k in ascending order with fused multiply-adds, as the vector form did (tools/covw_ab.py digests).
-// (2) X rides a wave-private three-slot LDS ring filled by LDS-direct loads (no registers): a trip reads its item's frames
-// out of the slot into registers first and then requests item i+3 into that very slot, so two items' worth of X per CU
-// (64 KB) is in flight behind the one the next trip reads, and the per-item barrier no longer gates the memory
-// pipeline.  Those loads -- and the tied register loads of the activation operand -- are invisible to the compiler's
-// wait-count model: the one VMEM wait per item is explicit.  Issue order per trip is [activation operand of item i+4]
-// [X of item i+3]; a trip needs the X of its own item and the operand of item i+2, so vmcnt(2 X requests + 1 operand set)
-// is what may stay in flight (the operand sets alternate between two register sets: one is consumed and refilled in
-// place while the other one's loads travel).  Records, partition and finalize are those of cov_wide_kernel
+// (2) X rides a wave-private three-slot LDS ring filled by LDS-direct loads (no registers): the rows of item i+2 are
+// requested while item i is consumed, so two items' worth of X per CU (64 KB) is in flight and the per-item barrier no
+// longer gates the memory pipeline.  Those loads -- and the tied register loads of the activation operand -- are
+// invisible to the compiler's wait-count model: the one VMEM wait per item is explicit, vmcnt(instructions of one X
+// request) -- issue order per trip is [activation operand of item i+2][X of item i+2], so that leaves exactly the
+// youngest X request in flight.  Records, partition and finalize are those of cov_wide_kernel
 // (part[g][slot][w][n][M*M]).
 #pragma once
 #include "assx_cov_wide.hpp"
@@ -331,9 +329,9 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
   R acc[NV];
 #pragma unroll
   for (int q = 0; q < NV; ++q) acc[q] = 0;
-  R bn[NB], bm[NB];  // two operand sets: trip `it` consumes (and refills) bn when `it` is even, bm when it is odd
+  R bn[NB];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) bn[i] = bm[i] = 0;
+  for (int i = 0; i < NB; ++i) bn[i] = 0;
   acc_t tv[NT], tvp[NT];
   Cursor c1 = c0;
   advance(c1, TBk, FG);
@@ -341,15 +339,9 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
   advance(c2, TBk, FG);
   Cursor c3 = c2;
   advance(c3, TBk, FG);
-  Cursor c4 = c3;
-  advance(c4, TBk, FG);
-  // Software pipeline (trip `it` consumes item `it`):  X of item i is requested in trip i-3 (into the slot item i-3 has
-  // just been read from), its activation operand in trip i-4, its variance products are issued in trip i-2 and turned
-  // into weights in trip i-1 -- every consumer's input was produced at least one trip earlier, so no trip waits for a
-  // matrix-core result or a memory round trip of its own.  VMEM returns in order, so what a trip may leave in flight is
-  // whatever was issued after the youngest thing it needs: with the operand of item i requested a trip ahead of where
-  // the first build had it (a second register set), that is TWO X requests (64 KB per CU) instead of one -- one item in
-  // flight per CU was the Little's-law bound the first build sat on (32 KB x 256 CUs per ~2 us round trip = 4 TB/s).
+  // Software pipeline (trip `it` consumes item `it`):  X of item i is requested in trip i-2, its activation operand in
+  // trip i-3, its variance products are issued in trip i-2 and turned into weights in trip i-1 -- every consumer's input
+  // was produced at least one trip earlier, so no trip waits for a matrix-core result or a memory round trip of its own.
   int par = 0;  // Tl slot of the bin group the NEXT variance product belongs to
   // prologue: weights of item 0; products of item 1 (-> tvp); operand of item 2; X of items 0 and 1
   load_rows(c0, 0);
@@ -373,24 +365,16 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
       par ^= 1;
       load_rows(c2, par);
     }
-    const Cursor c3v = nblk > 3 ? c3 : c0;
-    request_v(c2v, bn);  // consumed by trip 0 (even: bn), which refills it with item 4's
-    request_v(c3v, bm);  // consumed by trip 1
+    request_v(c2v, bn);  // loop order: [activation operand][X]
     request_x(c1v, 1);
-    request_x(c2v, 2);
   }
   int sl = 0;  // ring slot of item `it`
-  // one trip; bo = the operand set of this trip's parity.  The loop below is unrolled by two so that each copy names its
-  // set statically (a run-time choice between the two sets inside ONE copy of the body cost 94 spilled registers)
-  auto trip = [&](const int it, R (&bo)[NB]) __attribute__((always_inline)) {
-    const bool more = it + 1 < nblk, more3 = it + 3 < nblk, more4 = it + 4 < nblk;
+  for (int it = 0; it < nblk; ++it) {
+    const bool more = it + 1 < nblk, more2 = it + 2 < nblk, more3 = it + 3 < nblk;
     stamp();
-    // VMEM queue, oldest first: ... [operand it+2][X it+1] (trip it-2) [operand it+3][X it+2] (trip it-1).  X of item `it`
-    // and the operand of item it+2 have landed once only what follows that operand is in flight: two X requests and one
-    // operand set
-    wait_values<(COVM_SKIP & 4) ? 0 : 2 * NXI + NB>(bn);
-#pragma unroll
-    for (int i = 0; i < NB; ++i) asm volatile("" : "+v"(bm[i]));
+    // X of item `it` (requested two trips ago) and the activation operand of item it+2 (first requests of the previous
+    // trip) have landed once at most the previous trip's X request -- the NXI youngest operations -- is in flight
+    wait_values<(COVM_SKIP & 4) ? 0 : NXI>(bn);
     stamp();
     Vec2<R> xv[M];
     xrows_read<RB>(xread0 + (unsigned)sl * SLOT_BYTES, xv);  // wave-private: needs no barrier, overlaps the wait for one
@@ -404,17 +388,18 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
     // the load path, the matrix pipe, a chain of dependent f64 instructions -- is hit by all of them at once while the
     // others idle (in-kernel stamps: the trip was the SUM of its phases).  The order below therefore threads the phases
     // through each other, pinned with scheduling barriers because the scheduler's own choice groups like with like.
-    Cursor c1v = c1, c3v = c3, c4v = c4;
+    Cursor c1v = c1, c2v = c2, c3v = c3;
     if (!more) c1v = c0;
+    if (!more2) c2v = c0;
     if (!more3) c3v = c0;
-    if (!more4) c4v = c0;
+    const int sl2 = sl == 0 ? DXS - 1 : sl - 1;  // slot of item it+2 = the one item it-1 has left
     R wgt[N];
 #pragma unroll
     for (int n = 0; n < N; ++n) wgt[n] = Wt[(((it & 1) * N + n) * WB + w) * WAVE + lane];
     R av[NT][KS];
     read_rows(par, av);
-    const VReq vq = v_item(c4v);     // operand of item it+4 into the set this trip empties
-    const XReq xq = x_item(c3v, sl);  // X of item it+3 into the slot of item `it` (read into registers before the requests)
+    const VReq vq = v_item(c3v);
+    const XReq xq = x_item(c2v, sl2);
     __builtin_amdgcn_sched_barrier(0);
     // (1) weights of item it+1 from the previous trip's products (long complete) while the LDS reads above travel
     if (!(COVM_SKIP & 8)) publish(c1v, (it + 1) & 1, tvp, [&](auto) { __builtin_amdgcn_sched_barrier(0); });
@@ -450,22 +435,20 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
       }
     };
     constexpr int NSTEP = NB + NXI;  // shares of the fan-out: one per product, one per X request
-    {  // bo: this trip's operand set (item it+2), refilled in place with item it+4's
-      static_for<NSTEP>([&](auto qc) {
-        constexpr int q = decltype(qc)::value;
-        if constexpr (q < NB) {
-          constexpr int sq = q / NT, iq = q % NT;  // slice-major: a tile's chain is NT products apart
-          if (!(COVM_SKIP & 1))
-            if (tile_on(iq)) tv[iq] = MM::mma(av[iq][sq], bo[iq * KS + sq], tv[iq]);
-          if (!(COVM_SKIP & 32)) request_v1(vq, bo, IntC<iq>(), IntC<sq>());
-        } else {
-          if (!(COVM_SKIP & 4)) request_x1(xq, IntC<q - NB>());
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!(COVM_SKIP & 2)) static_for<(q + 1) * NU / NSTEP - q * NU / NSTEP>([&](auto jc) { fan_unit(IntC<q * NU / NSTEP + decltype(jc)::value>()); });
-        __builtin_amdgcn_sched_barrier(0);
-      });
-    }
+    static_for<NSTEP>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      if constexpr (q < NB) {
+        constexpr int sq = q / NT, iq = q % NT;  // slice-major: a tile's chain is NT products apart
+        if (!(COVM_SKIP & 1))
+          if (tile_on(iq)) tv[iq] = MM::mma(av[iq][sq], bn[iq * KS + sq], tv[iq]);
+        if (!(COVM_SKIP & 32)) request_v1(vq, bn, IntC<iq>(), IntC<sq>());
+      } else {
+        if (!(COVM_SKIP & 4)) request_x1(xq, IntC<q - NB>());
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!(COVM_SKIP & 2)) static_for<(q + 1) * NU / NSTEP - q * NU / NSTEP>([&](auto jc) { fan_unit(IntC<q * NU / NSTEP + decltype(jc)::value>()); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
     value_fence(acc);  // the fan-out stays HERE (left alone it is sunk below load_rows / the flush)
     stamp();
 #pragma unroll
@@ -484,13 +467,8 @@ __global__ void __launch_bounds__(WAVE * COVW_BINS)
     c0 = c1;
     c1 = c2;
     c2 = c3;
-    c3 = c4;
-    advance(c4, TBk, FG);
+    advance(c3, TBk, FG);
     stamp();
-  };
-  for (int it = 0; it < nblk; it += 2) {
-    trip(it, bn);
-    if (it + 1 < nblk) trip(it + 1, bm);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may land in LDS after the workgroup has gone
 #endif
