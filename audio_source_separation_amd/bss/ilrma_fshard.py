@@ -16,7 +16,9 @@ on one process gives bit-identical results to S ranks with one shard each (tests
 a NumPy stand-in for the shard ops, tests/test_gpu_multi.py with the HIP kernels).  Different S differ by rounding
 only (summation order of the f-reduction).
 
-Scope: algorithm_spatial='IP', no partitioning function, n_basis <= 64, normalize in {'power', False}.
+Scope: algorithm_spatial in {'IP', 'ISS', 'IP2' / 'pairwise'} (the sweeps are per bin: ilrma.py:483-646), normalize in
+{'power', 'projection-back', False} (projection back is per bin as well: ilrma.py:323-330, no exchange), n_basis <= 64,
+no partitioning function (its latent variables couple all bins).
 """
 import numpy as np
 import torch
@@ -53,15 +55,16 @@ class HipShardOps:
     def apply_sums(self, A, sums, domain, eps):
         self.eng.nmf_apply_sums(_lib.NMF_IS_MM, A, sums, domain=domain, eps=eps)
 
-    def spatial(self, X, W, Tb, V, C, domain, eps, threshold, status):
+    def spatial(self, X, W, Tb, V, C, domain, eps, threshold, status, spatial='IP', pair=(0, 1)):
         B, M, F, T = X.shape
+        code = {'IP': _lib.SPATIAL_IP, 'ISS': _lib.SPATIAL_ISS, 'IP2': _lib.SPATIAL_IP2, 'pairwise': _lib.SPATIAL_IP2}[spatial]
         pb = None
         if C is not None:  # per-bin power statistic the entry point emits next to the sweep: one buffer per shard shape
             pb = self._pb.get((B, M, F))
             if pb is None:
                 pb = self._pb[(B, M, F)] = self.eng.empty((B, M, F), dtype=torch.float64)
         self.eng.ilrma_spatial_update(X, W, Tb, V, domain=domain, eps=eps, threshold=threshold, status=status, C=C,
-                                      power_bins=pb)
+                                      power_bins=pb, spatial=code, pair=pair)
 
     def shard_power_mean(self, C, W, n_frames):
         """mean over the shard's bins of w_n^H C_f w_n: (N,) in the compute dtype (weighted by the shard's bin count
@@ -75,6 +78,11 @@ class HipShardOps:
 
     def normalize(self, W, Tb, power, domain, eps):
         self.eng.ilrma_normalize_power(W, Tb, power, domain=domain, eps=eps)
+
+    def normalize_pb(self, X, W, Tb, ref, domain, status):
+        """'projection-back' normalisation of one shard (ilrma.py:323-330): per bin, nothing to exchange."""
+        scale = self.eng.projection_back_scale(X, W, ref, status)
+        self.eng.ilrma_normalize_pb(W, Tb, scale, domain=domain)
 
     def loss(self, X, W, Tb, V, domain, eps):
         return self.eng.ilrma_loss(X, W, Tb, V, domain=domain, eps=eps)[0]
@@ -105,10 +113,15 @@ class FrequencyShardedGaussILRMA:
     """
 
     def __init__(self, n_basis=10, domain=2, normalize='power', reference_id=0, recordable_loss=True, eps=EPS,
-                 threshold=THRESHOLD, *, dtype='float64', device=None, n_shards=None, comm_device=None, ops=None):
+                 threshold=THRESHOLD, *, algorithm_spatial='IP', dtype='float64', device=None, n_shards=None,
+                 comm_device=None, ops=None):
         assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
-        if normalize not in ('power', False):
-            raise NotImplementedError("The F-sharded mode supports normalize='power' or False, got {!r}.".format(normalize))
+        if normalize not in ('power', 'projection-back', False):
+            raise ValueError("Not support normalization based on {}. Choose 'power' or 'projection-back'".format(normalize))
+        if algorithm_spatial not in ('IP', 'ISS', 'IP2', 'pairwise'):
+            raise NotImplementedError("Not support {}-based spatial update.".format(algorithm_spatial))
+        self.algorithm_spatial = algorithm_spatial
+        self.update_pair = None
         if n_basis > 64:
             raise NotImplementedError("The F-sharded mode needs n_basis <= 64 (matrix-core NMF halves).")
         self.n_basis, self.domain, self.normalize = n_basis, domain, normalize
@@ -144,6 +157,7 @@ class FrequencyShardedGaussILRMA:
         N, K = M, self.n_basis
         self.n_sources = self.n_channels = M
         self.n_bins, self.n_frames = F, T
+        self.update_pair = None
         if self.n_shards > F:
             raise ValueError("more shards ({}) than bins ({})".format(self.n_shards, F))
         if basis is None or activation is None:
@@ -188,18 +202,34 @@ class FrequencyShardedGaussILRMA:
     def update_once(self):
         ops, d, eps = self.ops, self.domain, self.eps
         Xs, Ws, Ts, V = self._Xs, self._Ws, self._Ts, self._V
+        pairwise = self.algorithm_spatial in ('IP2', 'pairwise')
+        if pairwise:  # (0,1), (1,2), ..., (N-1,0)   (ilrma.py:635-646): host-side integer logic, the same on every rank
+            m, n = (0, 1) if self.update_pair is None else ((self.update_pair[0] + 1) % self.n_sources,
+                                                           (self.update_pair[1] + 1) % self.n_sources)
+            self.update_pair = m, n
+
+        def apply(A, sums):  # A (N, ...), sums (2, N, count): every source, or the selected pair only (ilrma.py:432-481)
+            if not pairwise:
+                ops.apply_sums(A, sums, d, eps)
+            else:
+                for src in self.update_pair:
+                    ops.apply_sums(A[src:src + 1], sums[:, src:src + 1].contiguous(), d, eps)
         Ps = []
         # ---- source model: basis (per bin: local), then activation (reduce over f: the one real exchange)
         for i in range(len(Xs)):
             P = ops.power_map(Xs[i], Ws[i])
-            ops.apply_sums(Ts[i][0], ops.half_sums(0, P, Ts[i], V, d, eps), d, eps)
+            apply(Ts[i][0], ops.half_sums(0, P, Ts[i], V, d, eps))
             Ps.append(P)
         act = self._ordered_sum([ops.half_sums(1, Ps[i], Ts[i], V, d, eps) for i in range(len(Xs))])
-        ops.apply_sums(V[0], act, d, eps)
+        apply(V[0], act)
         del Ps
-        # ---- spatial model: covariance + IP, per bin
+        # ---- spatial model: covariance + the sweep (IP / ISS / IP2), per bin
         for i in range(len(Xs)):
-            ops.spatial(Xs[i], Ws[i], Ts[i], V, self._Cs[i], d, eps, self.threshold, self._status)
+            if self.algorithm_spatial == 'IP':
+                ops.spatial(Xs[i], Ws[i], Ts[i], V, self._Cs[i], d, eps, self.threshold, self._status)
+            else:
+                ops.spatial(Xs[i], Ws[i], Ts[i], V, self._Cs[i], d, eps, self.threshold, self._status,
+                            spatial=self.algorithm_spatial, pair=self.update_pair if pairwise else (0, 1))
         # ---- power normalisation: N scalars
         if self.normalize == 'power':
             # mean over all bins = sum_s (F_s / F) * mean over shard s
@@ -208,6 +238,9 @@ class FrequencyShardedGaussILRMA:
                                       weights=wts).reshape(1, -1).contiguous()
             for i in range(len(Xs)):
                 ops.normalize(Ws[i], Ts[i], power, d, eps)
+        elif self.normalize == 'projection-back':
+            for i in range(len(Xs)):
+                ops.normalize_pb(Xs[i], Ws[i], Ts[i], self.reference_id, d, self._status)
 
     def compute_negative_loglikelihood(self):
         parts = [self.ops.loss(self._Xs[i], self._Ws[i], self._Ts[i], self._V, self.domain, self.eps).reshape(1)
@@ -258,5 +291,5 @@ class FrequencyShardedGaussILRMA:
         return self._V[0].cpu().numpy().astype(np.float64)
 
     def __repr__(self):
-        return "FrequencySharded-Gauss-ILRMA(n_basis={}, domain={}, normalize={}, n_shards={})".format(
-            self.n_basis, self.domain, self.normalize, self.n_shards)
+        return "FrequencySharded-Gauss-ILRMA(n_basis={}, domain={}, normalize={}, algorithm_spatial={}, n_shards={})".format(
+            self.n_basis, self.domain, self.normalize, self.algorithm_spatial, self.n_shards)

@@ -14,6 +14,11 @@
 #pragma once
 #include "assx_common.hpp"
 
+#ifndef NMF_SKIP
+#define NMF_SKIP 0  // timing experiments only (tools/probes/nmf_parts.sh; results are wrong by construction): 1 product (1),
+                    // 2 element terms, 4 product (3), 8 X loads, 16 operand-tile loads and staging
+#endif
+
 namespace assx {
 
 typedef double v4d_t __attribute__((ext_vector_type(4)));
@@ -111,8 +116,15 @@ __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R
 // basis half: num|den (F,K) = [A|Bm] (F,T) . V^T, reduced over this workgroup's frame range.
 //   grid (ceil(F/64), TS, B), 4 waves, wave w owns bins f0 = (4*blockIdx.x + w)*16 .. +15.
 //   part[ts][b*2 + s][f*K + k]
+// NS sub-tiles (of 16 frames) may advance TOGETHER through the three products (sub-tile s accumulates into its own
+// num/den set, the sets are added in ascending s at the end).  Measured in round 3 and NOT used (NS = 1 everywhere): the
+// parts of a trip add up -- tools/probes/nmf_parts.sh: compiling out any one part saves only its own share,
+// profiles/r03_nmf_parts.txt -- and a dependent v_mfma_f64_16x16x4 issues ~184 cycles after its predecessor while the pipe
+// takes one every 64-80, so twin chains looked like the cure; but NS = 2 costs 288 registers at n_basis 32 (176 at
+// n_basis <= 16): one wave per SIMD, one workgroup per CU, i.e. a second round of workgroups -- config 2 took 123 us
+// instead of 66, the n_basis 10 ILRMA source update 232 us instead of 200.
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT, int D2K = -1>
+template <typename R, int KT, int D2K = -1, int NS = 1>
 __global__ void __launch_bounds__(256)
     nmf_basis_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
                           R* __restrict__ part, int B, int F, int T, int K, int tchunk, R eps, TermSpec s) {
@@ -121,11 +133,11 @@ __global__ void __launch_bounds__(256)
   constexpr int KS = KT * 4;      // k-slices of 4 in product (1)
   constexpr int KP = KT * 16;     // n_basis padded to the tile
   constexpr int LD = 17;          // padded row of the staged tile (bank-conflict-free column reads)
-  constexpr int NLD = KP * 16 / 64;  // staged elements per lane
+  constexpr int NLD = KP * 16 / 64;  // staged elements per lane and sub-tile
   // The V tile (KP x 16 frames) is read in two layouts -- as A operand of (1) and as B operand of (3).  Each wave
   // stages it once through its private LDS slice with coalesced 128-byte row reads instead of issuing 16 narrow
   // global loads per sub-tile (the CU's single L1 pipe made the first version load-issue bound).
-  __shared__ R vt[4][KP][LD];
+  __shared__ R vt[4][NS][KP][LD];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.z, ts = blockIdx.y;
@@ -142,73 +154,109 @@ __global__ void __launch_bounds__(256)
     const int k = 4 * j + lk;
     tb[j] = (k < K) ? Tb[((size_t)b * F + f) * K + k] : (R)0;
   }
-  acc_t num[KT], den[KT];
+  acc_t num[NS][KT], den[NS][KT];
 #pragma unroll
-  for (int c = 0; c < KT; ++c)
+  for (int q = 0; q < NS; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      num[c][r] = 0;
-      den[c][r] = 0;
-    }
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        num[q][c][r] = 0;
+        den[q][c][r] = 0;
+      }
 
   const int ta = ts * tchunk;
   const int te = min(T, ta + tchunk);
   // staged element e = i*64 + lane  ->  row k = e / 16, frame t0 + e % 16 (16 lanes cover one 128-byte row segment)
-  R stage[NLD];
-  R xq[4];  // X of the next sub-tile, in the accumulator layout (HBM latency hidden behind the current tile)
+  R stage[NS][NLD];
+  R xq[NS][4];  // X of the next sub-tiles, in the accumulator layout (HBM latency hidden behind the current ones)
   auto fetch = [&](int t0) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = i * 64 + lane;
-      const int k = e >> 4, tt = min(t0 + (e & 15), T - 1);
-      stage[i] = (k < K) ? vb[(size_t)k * T + tt] : (R)0;
-    }
+    for (int q = 0; q < NS; ++q) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xq[r] = xrow[min(t0 + MM::crow(r, lane), T - 1)];
+      for (int i = 0; i < NLD; ++i) {
+        const int e = i * 64 + lane;
+        const int k = e >> 4, tt = min(t0 + 16 * q + (e & 15), T - 1);
+        stage[q][i] = (NMF_SKIP & 16) ? (R)0.5 : ((k < K) ? vb[(size_t)k * T + tt] : (R)0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        xq[q][r] = (NMF_SKIP & 8) ? (R)1 : xrow[min(t0 + 16 * q + MM::crow(r, lane), T - 1)];
+    }
   };
   fetch(ta);
-  for (int t0 = ta; t0 < te; t0 += 16) {
-    R xc[4];
+  for (int t0 = ta; t0 < te; t0 += 16 * NS) {
+    R xc[NS][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xc[r] = xq[r];
+    for (int q = 0; q < NS; ++q)
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = i * 64 + lane;
-      vt[wv][e >> 4][e & 15] = stage[i];
+      for (int r = 0; r < 4; ++r) xc[q][r] = xq[q][r];
+    if (!(NMF_SKIP & 16)) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int e = i * 64 + lane;
+          vt[wv][q][e >> 4][e & 15] = stage[q][i];
+        }
     }
-    if (t0 + 16 < te) fetch(t0 + 16);  // next tile travels while this one is consumed
+    if (t0 + 16 * NS < te) fetch(t0 + 16 * NS);  // the next tiles travel while these are consumed
     __builtin_amdgcn_wave_barrier();
-    // (1) TV^T sub-tile: rows = frames t0 + crow, columns = bins f0 + li
-    acc_t tv;
+    // (1) TV^T sub-tiles: rows = frames t0 + 16 q + crow, columns = bins f0 + li; the NS chains alternate
+    acc_t tv[NS];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tv[r] = 0;
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[q][r] = 0;
 #pragma unroll
     for (int j = 0; j < KS; ++j)
-      if (4 * j < K) tv = MM::mma(vt[wv][4 * j + lk][li], tb[j], tv);  // A operand: V^T[t = li][k]; all-padding k-slices skipped
-    // (2) elementwise in the accumulator layout
-    R a[4], bm[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int t = t0 + MM::crow(r, lane);
-      nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
-      if (!(fvalid && t < te)) {
-        a[r] = 0;
-        bm[r] = 0;
+      for (int q = 0; q < NS; ++q)
+        if (4 * j < K && !(NMF_SKIP & 1))
+          tv[q] = MM::mma(vt[wv][q][4 * j + lk][li], tb[j], tv[q]);  // A operand: V^T[t = li][k]; all-padding k-slices skipped
+    if (NMF_SKIP & 1)
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tv[q][r] = xc[q][r] + (R)1;
+    // (2) elementwise in the accumulator layout
+    R a[NS][4], bm[NS][4];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int t = t0 + 16 * q + MM::crow(r, lane);
+        if (NMF_SKIP & 2) {
+          a[q][r] = xc[q][r];
+          bm[q][r] = tv[q][r];
+        } else
+          nmf_terms<R, D2K>(s, xc[q][r], tv[q][r], eps, a[q][r], bm[q][r]);
+        if (!(fvalid && t < te)) {
+          a[q][r] = 0;
+          bm[q][r] = 0;
+        }
       }
-    }
     // (3) num[f, kb] += sum_t a[f,t] V[kb,t]: accumulator register r is k-slice r of the A operand
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const R vv = vt[wv][16 * c + li][MM::crow(r, lane)];  // B operand: V^T[t-pos of slice r][kb]; rows >= K are 0
-        num[c] = MM::mma(a[r], vv, num[c]);
-        den[c] = MM::mma(bm[r], vv, den[c]);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          if (NMF_SKIP & 4) {
+            num[q][c][r] += a[q][r];
+            den[q][c][r] += bm[q][r];
+            continue;
+          }
+          const R vv = vt[wv][q][16 * c + li][MM::crow(r, lane)];  // B operand: V^T[t-pos of slice r][kb]; rows >= K are 0
+          num[q][c] = MM::mma(a[q][r], vv, num[q][c]);
+          den[q][c] = MM::mma(bm[q][r], vv, den[q][c]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // D[row = f0 + crow][col = kb]
+  // D[row = f0 + crow][col = kb]; the NS sets in ascending order
   const size_t FK = (size_t)F * K;
   R* pn = part + ((size_t)ts * B * 2 + (size_t)b * 2) * FK;
 #pragma unroll
@@ -217,9 +265,15 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int fo = f0 + MM::crow(r, lane);
+      R n = num[0][c][r], dd = den[0][c][r];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) {
+        n += num[q][c][r];
+        dd += den[q][c][r];
+      }
       if (fo < F && kb < K) {
-        pn[(size_t)fo * K + kb] = num[c][r];
-        pn[FK + (size_t)fo * K + kb] = den[c][r];
+        pn[(size_t)fo * K + kb] = n;
+        pn[FK + (size_t)fo * K + kb] = dd;
       }
     }
   }
@@ -229,8 +283,9 @@ __global__ void __launch_bounds__(256)
 // activation half: num|den (K,T) = Tb^T (K,F) . [A|Bm] (F,T), reduced over this workgroup's bin range.
 //   grid (ceil(T/16), FS, B); the 4 waves stride over the bin range in sub-tiles of 16 and are combined through LDS.
 //   part[fs][b*2 + s][k*T + t]
+// NS sub-tiles of 16 bins (64 bins apart: a wave's consecutive sub-tiles) advance together, as in the basis half.
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT, int D2K = -1>
+template <typename R, int KT, int D2K = -1, int NS = 1>
 __global__ void __launch_bounds__(256)
     nmf_act_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
                         int B, int F, int T, int K, int fchunk, R eps, TermSpec s) {
@@ -239,8 +294,8 @@ __global__ void __launch_bounds__(256)
   constexpr int KS = KT * 4;
   constexpr int KP = KT * 16;
   constexpr int LD = KP + 4;          // padded row of the staged 16 x KP basis tile
-  constexpr int NLD = KP * 16 / 64;   // staged elements per lane
-  __shared__ R tt_[4][16][LD];        // wave-private basis tiles (read as A operand of (1) and of (3))
+  constexpr int NLD = KP * 16 / 64;   // staged elements per lane and sub-tile
+  __shared__ R tt_[4][NS][16][LD];    // wave-private basis tiles (read as A operand of (1) and of (3))
   __shared__ R red[3][KT * 2 * 4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int li = lane & 15, lk = lane >> 4;
@@ -257,81 +312,127 @@ __global__ void __launch_bounds__(256)
     const int k = 4 * j + lk;
     vbr[j] = (k < K) ? V[((size_t)b * K + k) * T + t] : (R)0;
   }
-  acc_t num[KT], den[KT];
+  acc_t num[NS][KT], den[NS][KT];
 #pragma unroll
-  for (int c = 0; c < KT; ++c)
+  for (int q = 0; q < NS; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      num[c][r] = 0;
-      den[c][r] = 0;
-    }
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        num[q][c][r] = 0;
+        den[q][c][r] = 0;
+      }
 
   const int fa = fs * fchunk;
   const int fe = min(F, fa + fchunk);
   // staged element e = i*64 + lane -> bin f0 + e / KP, basis e % KP: consecutive lanes read consecutive k of a row
-  R stage[NLD];
-  R xq[4];  // X of the next sub-tile, in the accumulator layout
+  R stage[NS][NLD];
+  R xq[NS][4];  // X of the next sub-tiles, in the accumulator layout
   auto fetch = [&](int f0) {
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = i * 64 + lane;
-      const int fr = f0 + e / KP, k = e % KP;
-      stage[i] = (k < K && fr < fe) ? tbb[(size_t)fr * K + k] : (R)0;  // bins beyond the range contribute 0
-    }
+    for (int q = 0; q < NS; ++q) {
+      const int fq = f0 + 64 * q;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xq[r] = xb[(size_t)min(f0 + MM::crow(r, lane), F - 1) * T + t];
+      for (int i = 0; i < NLD; ++i) {
+        const int e = i * 64 + lane;
+        const int fr = fq + e / KP, k = e % KP;
+        stage[q][i] = (NMF_SKIP & 16) ? (R)0.5 : ((k < K && fr < fe) ? tbb[(size_t)fr * K + k] : (R)0);  // bins beyond the range contribute 0
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        xq[q][r] = (NMF_SKIP & 8) ? (R)1 : xb[(size_t)min(fq + MM::crow(r, lane), F - 1) * T + t];
+    }
   };
   int f0 = fa + 16 * wv;
   if (f0 < fe) fetch(f0);
-  for (; f0 < fe; f0 += 64) {
-    R xc[4];
+  for (; f0 < fe; f0 += 64 * NS) {
+    R xc[NS][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xc[r] = xq[r];
+    for (int q = 0; q < NS; ++q)
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-      const int e = i * 64 + lane;
-      tt_[wv][e / KP][e % KP] = stage[i];
+      for (int r = 0; r < 4; ++r) xc[q][r] = xq[q][r];
+    if (!(NMF_SKIP & 16)) {
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int e = i * 64 + lane;
+          tt_[wv][q][e / KP][e % KP] = stage[q][i];
+        }
     }
-    if (f0 + 64 < fe) fetch(f0 + 64);
+    if (f0 + 64 * NS < fe) fetch(f0 + 64 * NS);
     __builtin_amdgcn_wave_barrier();
-    // (1) TV sub-tile: rows = bins f0 + crow, columns = frames t0 + li
-    acc_t tv;
+    // (1) TV sub-tiles: rows = bins f0 + 64 q + crow, columns = frames t0 + li; the NS chains alternate
+    acc_t tv[NS];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) tv[r] = 0;
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[q][r] = 0;
 #pragma unroll
     for (int j = 0; j < KS; ++j)
-      if (4 * j < K) tv = MM::mma(tt_[wv][li][4 * j + lk], vbr[j], tv);  // A operand: Tb[f = li][k]; padding slices skipped
-    // (2)
-    R a[4], bm[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int fr = f0 + MM::crow(r, lane);
-      nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
-      if (!(tvalid && fr < fe)) {
-        a[r] = 0;
-        bm[r] = 0;
+      for (int q = 0; q < NS; ++q)
+        if (4 * j < K && !(NMF_SKIP & 1))
+          tv[q] = MM::mma(tt_[wv][q][li][4 * j + lk], vbr[j], tv[q]);  // A operand: Tb[f = li][k]; padding slices skipped
+    if (NMF_SKIP & 1)
+#pragma unroll
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tv[q][r] = xc[q][r] + (R)1;
+    // (2)
+    R a[NS][4], bm[NS][4];
+#pragma unroll
+    for (int q = 0; q < NS; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int fr = f0 + 64 * q + MM::crow(r, lane);
+        if (NMF_SKIP & 2) {
+          a[q][r] = xc[q][r];
+          bm[q][r] = tv[q][r];
+        } else
+          nmf_terms<R, D2K>(s, xc[q][r], tv[q][r], eps, a[q][r], bm[q][r]);
+        if (!(tvalid && fr < fe)) {
+          a[q][r] = 0;
+          bm[q][r] = 0;
+        }
       }
-    }
     // (3) num[kb, t] += sum_f Tb[f,kb] a[f,t]: accumulator register r is k-slice r of the B operand
 #pragma unroll
     for (int c = 0; c < KT; ++c) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const R tv3 = tt_[wv][MM::crow(r, lane)][16 * c + li];  // A operand: Tb^T[kb][f-pos of slice r]
-        num[c] = MM::mma(tv3, a[r], num[c]);
-        den[c] = MM::mma(tv3, bm[r], den[c]);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          if (NMF_SKIP & 4) {
+            num[q][c][r] += a[q][r];
+            den[q][c][r] += bm[q][r];
+            continue;
+          }
+          const R tv3 = tt_[wv][q][MM::crow(r, lane)][16 * c + li];  // A operand: Tb^T[kb][f-pos of slice r]
+          num[q][c] = MM::mma(tv3, a[q][r], num[q][c]);
+          den[q][c] = MM::mma(tv3, bm[q][r], den[q][c]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
-  // combine the 4 waves
+  // the NS sets in ascending order, then the 4 waves
+#pragma unroll
+  for (int c = 0; c < KT; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int q = 1; q < NS; ++q) {
+        num[0][c][r] += num[q][c][r];
+        den[0][c][r] += den[q][c][r];
+      }
   if (wv > 0) {
 #pragma unroll
     for (int c = 0; c < KT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[c][r];
-        red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[c][r];
+        red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[0][c][r];
+        red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[0][c][r];
       }
   }
   __syncthreads();
@@ -342,7 +443,7 @@ __global__ void __launch_bounds__(256)
     for (int c = 0; c < KT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        R n = num[c][r], d = den[c][r];
+        R n = num[0][c][r], d = den[0][c][r];
 #pragma unroll
         for (int w = 0; w < 3; ++w) {
           n += red[w][(c * 2 + 0) * 4 + r][lane];

@@ -118,7 +118,10 @@ def cov_contract_bytes(B, M, F, T, K, r, lds_ok=True):
         rpi = 2 if r == 8 else 4                      # rows per LDS-direct instruction (csrc/assx_cov_wide.hpp)
         lds = 2 * ((M * K + rpi - 1) // rpi * rpi) * 64 * r + 8 * M * K * r
         if lds <= 144 * 1024 and os.environ.get("ASSX_COV_WIDE", "1") != "0":
-            name = "cov_wide_kernel (+ cov_wide_finalize_kernel)"   # still "weights rebuilt in-kernel"
+            # still "weights rebuilt in-kernel"; n_basis <= 16 runs the matrix-core variance form since round 3
+            # (csrc/assx_cov_mfma.hpp; ASSX_COV_MFMA=0 keeps round 2's cov_wide_kernel)
+            mfma = K <= 16 and os.environ.get("ASSX_COV_MFMA", "1") != "0"
+            name = ("cov_mfma_kernel" if mfma else "cov_wide_kernel") + " (+ cov_wide_finalize_kernel)"
         else:
             # the source variance is materialised first (write N.F.T reals), then read back as (N,F,T) weights --
             # the "weights materialised" contract of SURVEY.md 8d plus the map's own write

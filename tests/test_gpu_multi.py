@@ -212,6 +212,31 @@ def test_frequency_sharded_ilrma_matches_oracle_and_class(Mx, Kx, domain, normal
         assert np.linalg.norm(Y - Yg) / np.linalg.norm(Yg) < 1e-8
 
 
+@pytest.mark.parametrize("spatial,normalize", [("ISS", "power"), ("IP2", "power"), ("IP", "projection-back"),
+                                               ("ISS", "projection-back"), ("IP2", False)])
+def test_frequency_sharded_other_sweeps_and_projection_back(spatial, normalize):
+    """The F-sharded mode beyond IP + 'power' (ilrma.py:313-330, 537-646): ISS and IP2 sweeps and the projection-back
+    normalisation are per bin, so a shard runs them unchanged; 1 and 3 ragged shards against the oracle's unsharded
+    run (IP2: the pair sequence and the pair-restricted source model included)."""
+    from audio_source_separation_amd.bss.ilrma_fshard import FrequencyShardedGaussILRMA
+    from oracle import oracle_np as orc
+    Mx, Fx, Tx, Kx, iters = 4, 23, 200, 3, 5
+    X, T0, V0 = _fs_problem(Mx, Fx, Tx, Kx, seed=37)
+    if spatial == "ISS":
+        ref = orc.gauss_ilrma_iss(X, iters, T0, V0, normalize=normalize)
+    elif spatial == "IP2":
+        ref = orc.gauss_ilrma_ip2(X, iters, T0, V0, normalize=normalize)
+    else:
+        ref = orc.gauss_ilrma(X, iters, T0, V0, normalize=normalize)
+    for S in (1, 3):
+        m = FrequencyShardedGaussILRMA(n_basis=Kx, normalize=normalize, algorithm_spatial=spatial, n_shards=S)
+        Y = m(X, iteration=iters, basis=T0, activation=V0)
+        assert np.linalg.norm(Y - ref["Y"]) / np.linalg.norm(ref["Y"]) < 1e-7
+        assert np.linalg.norm(m.basis - ref["T"]) / np.linalg.norm(ref["T"]) < 1e-7
+        assert np.linalg.norm(m.activation - ref["V"]) / np.linalg.norm(ref["V"]) < 1e-7
+        np.testing.assert_allclose(m.loss, ref["loss"], rtol=1e-9)
+
+
 def _fs_worker(rank, world, port, backend, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank if backend == "nccl" else 0),
                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything profiles/<tag>_* is made of, in one run on the GPU box:  bash tools/collect_profiles.sh r02_a
+# Everything profiles/<tag>_* is made of, in one run on the GPU box:  bash tools/collect_profiles.sh r03
 # (bench lines, rocprofv3 kernel tables, SQ / traffic PMC passes -- PMC only ever with --kernel-trace, as gpurun wants)
-TAG="${1:-r02}"
+TAG="${1:-r03}"
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,25 +14,30 @@ py $B --cpu-iters 0 --utterances-per-gpu 8 --steps 100 --warmup 10 --roofline-b8
 py $B --cpu-iters 0 --basis 10 --steps 200 --warmup 20 > $OUT/bench_f64_k10.json 2>/dev/null
 py $B --cpu-iters 0 --basis 10 --utterances-per-gpu 8 --steps 50 --warmup 5 --roofline-b8 0 > $OUT/bench_f64_k10_8utt.json 2>/dev/null
 py $B --cpu-iters 0 --with-loss --roofline-b8 0 > $OUT/bench_f64_with_loss.json 2>/dev/null
-py $B --cpu-iters 0 --config5 on --config5-utterances 16 --config5-iterations 100 --roofline-b8 0 > $OUT/bench_f64_config5_1gpu_16utt.json 2>/dev/null
+py $B --cpu-iters 0 --config5 on --config5-utterances 64 --config5-iterations 100 --roofline-b8 0 > $OUT/bench_f64_config5_1gpu_64utt.json 2>/dev/null
 py $ROOT/tools/bench_configs.py > $OUT/bench_configs.json 2>/dev/null
 py $ROOT/tools/nmf_bench.py float64 > $OUT/nmf_bench_f64.txt 2>/dev/null
 py $ROOT/tools/nmf_bench.py float32 > $OUT/nmf_bench_f32.txt 2>/dev/null
-# rocprofv3 kernel tables: the driver's own command line, the K=10 line, NMF config 2
+py $ROOT/tools/widem_bench.py 5:4 6:4 7:4 8:4 8:10 > $OUT/widem_bench.txt 2>/dev/null
+py $ROOT/tools/widem_bench.py 5:4 8:4 --dtype float32 > $OUT/widem_bench_f32.txt 2>/dev/null
+py $ROOT/tools/fshard_bench.py > $OUT/fshard_bench_k4.json 2>/dev/null
+# rocprofv3 kernel tables: the driver's own command line, the K=10 line, NMF config 2, the wide-channel path
 rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg4 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_f32 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --dtype float32 --roofline-b8 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_k10 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --basis 10 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_nmf -o p -- python $ROOT/tools/nmf_bench.py float64 > /dev/null 2>&1
-for t in cfg4 f32 k10 nmf; do py $ROOT/tools/rocprof_summary.py $OUT/prof_$t > $OUT/${t}_kernel_stats.md 2>&1; done
+rocprofv3 --kernel-trace --stats -d $OUT/prof_m8 -o p -- python $ROOT/tools/widem_bench.py 8:4 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_m5 -o p -- python $ROOT/tools/widem_bench.py 5:4 > /dev/null 2>&1
+for t in cfg4 f32 k10 nmf m8 m5; do py $ROOT/tools/rocprof_summary.py $OUT/prof_$t > $OUT/${t}_kernel_stats.md 2>&1; done
 # SQ counters
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_stream $TAG/sq_cov_k4 > $OUT/sq_cov_k4.txt 2>&1
-bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_wide $TAG/sq_cov_k10 --K 10 > $OUT/sq_cov_k10.txt 2>&1
+bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_mfma $TAG/sq_cov_k10 --K 10 > $OUT/sq_cov_k10.txt 2>&1
+bash $ROOT/tools/pmc_kernel.sh "ilrma_spatial_update" src_cov $TAG/sq_src_cov_m8 --M 8 > $OUT/sq_src_cov_m8.txt 2>&1
 # HBM traffic
 py $ROOT/tools/pmc_traffic.py collect > /dev/null 2>&1
 py $ROOT/tools/pmc_traffic.py report > $OUT/cov_traffic.json 2>&1
 cp $ROOT/profiles/cov_traffic.json $OUT/cov_traffic.json 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/mfma_f64_rate_probe.hip -o /tmp/mfma_rate && /tmp/mfma_rate > $OUT/mfma_rate_probe.txt
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/valu_f64_rate_probe.hip -o /tmp/valu_rate && /tmp/valu_rate > $OUT/valu_f64_rate_probe.txt
-py $ROOT/tools/widem_bench.py > $OUT/widem_bench.txt 2>/dev/null
-rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > $OUT/clock_probe.txt
+cd $ROOT && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $OUT/gpu_tests.log
+rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] $ROOT/gpurun_out/pmc_fetch_* $ROOT/gpurun_out/pmc_write_* 2>/dev/null
 ls -la $OUT

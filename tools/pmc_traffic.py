@@ -23,18 +23,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "gpurun_out")
 
 
-CASES = (("k4", 4, "cov_stream_kernel"), ("k10", 10, "cov_wide_kernel"))  # (tag, n_basis, kernel-name substring)
+# (tag, n_basis, kernel-name substring, channels, microbench entry).  k10: cov_mfma_kernel since round 3 (the records'
+# finalize is a separate kernel and not part of the figure); m8: the wide-channel streaming covariance inside one spatial
+# update (src_cov_kernel; contract bytes M F T c + (N F K + N K T) r + N F M^2 c with M = N = 8)
+CASES = (("k4", 4, "cov_stream_kernel", 4, "cov TV"), ("k10", 10, "cov_mfma_kernel", 4, "cov TV"),
+         ("m8", 4, "src_cov_kernel", 8, "ilrma_spatial_update"))
 
 
 def collect():
     env = dict(os.environ, TMPDIR="/tmp")
-    for tag, K, _ in CASES:
+    for tag, K, _, M, only in CASES:
         for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             for dtype in ("float64", "float32"):
                 d = os.path.join(OUT, "%s_%s_%s" % (name, tag, dtype))
                 cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
-                       sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "--only", "cov TV", "--reps", "5",
-                       "--dtype", dtype, "--K", str(K)]
+                       sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "--only", only, "--reps", "5",
+                       "--dtype", dtype, "--K", str(K), "--M", str(M)]
                 subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
@@ -50,7 +54,7 @@ def _mean_counter(d, counter, kernel_substr):
 def report():
     import datetime
     out = {}
-    for tag, K, ksub in CASES:
+    for tag, K, ksub, M, _ in CASES:
         for dtype in ("float64", "float32"):
             f, nf = _mean_counter(os.path.join(OUT, "pmc_fetch_%s_%s" % (tag, dtype)), "FETCH_SIZE", ksub)
             w, nw = _mean_counter(os.path.join(OUT, "pmc_write_%s_%s" % (tag, dtype)), "WRITE_SIZE", ksub)
@@ -62,17 +66,22 @@ def report():
             # once and raw FETCH_SIZE reports 69 MB = 0.51x -> the same x2 applies to this access pattern.
             corr = 2.0
             rec = {
-                "workload": "%s (TV weights rebuilt in-kernel), M=4 F=1025 T=4096 K=%d, one launch" % (ksub, K),
+                "workload": "%s (TV weights rebuilt in-kernel), M=%d F=1025 T=4096 K=%d, one launch" % (ksub, M, K),
                 "fetch_size_kib": f, "write_size_kib": w, "launches_averaged": [nf, nw],
                 "fetch_bytes_raw": fetch_raw, "write_bytes_raw": write_raw,
                 "fetch_correction": corr,
                 "traffic_bytes": fetch_raw * corr + write_raw,
-                "collected": "round 2, %s" % datetime.date.today().isoformat(),
+                "collected": "round 3, %s" % datetime.date.today().isoformat(),
                 "note": "FETCH_SIZE x1024 x%g (gfx950 counts 128 B requests as 64 B on coalesced streaming reads; x2 "
                         "from MI355X_MICROARCH.md for 16 B/lane, re-calibrated on the known X byte count for 8 B/lane) "
                         "+ WRITE_SIZE x1024 (uncalibrated, <1%% of the total)" % corr,
             }
-            if K <= 4:
+            r = 8 if dtype == "float64" else 4
+            rec["contract_bytes"] = M * 1025 * 4096 * 2 * r + (M * 1025 * K + M * K * 4096) * r + M * 1025 * M * M * 2 * r
+            rec["traffic_over_contract"] = round(rec["traffic_bytes"] / rec["contract_bytes"], 4)
+            if M > 4:
+                out.setdefault("widem_m%d" % M, {})[dtype] = rec
+            elif K <= 4:
                 out[dtype] = rec
             else:
                 out.setdefault("wide_k%d" % K, {})[dtype] = rec
