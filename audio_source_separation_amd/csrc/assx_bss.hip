@@ -21,6 +21,7 @@
 #include "assx_partition.hpp"
 #include "assx_cov_wide.hpp"
 #include "assx_cov_mfma.hpp"
+#include "assx_src_nmf.hpp"
 #include "assx_nmf_internal.hpp"
 #include "assx_widem.hpp"
 
@@ -775,6 +776,7 @@ struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte al
   size_t map;      // n_basis > 4 only: (B,N,F,T) reals (demixed power / source variance)
   size_t nmf;      // n_basis > 4 only: scratch of the batched IS-NMF update
   size_t tmp;      // n_basis > 4 only: copies of (Tb, V) for a source-masked update
+  size_t srcnmf;   // 4 < n_basis <= 16 only: records + sums of the streaming source model (assx_src_nmf.hpp)
   size_t total;
 };
 
@@ -871,6 +873,11 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
     off += align_up(assx_nmf_workspace_bytes(B * M, F, T, K, dtype), 256);
     L.tmp = off;
     off += align_up(((size_t)B * M * F * K + (size_t)B * M * K * T) * r, 256);
+  }
+  L.srcnmf = off;
+  if (K > KU && K <= SRC_NMF_KMAX) {
+    const SrcNmfPlan sp = src_nmf_plan(B, M, F, T, K, r, g_target(2));
+    off += sp.rec_bytes + sp.sums_bytes;
   }
   L.total = off;
   return L;
@@ -1392,6 +1399,17 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
                            (const Cx<R>*)W, lpart, B, F, T, lstride, ncov);
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
       }
+    }
+    static const int src_nmf = env_int("ASSX_SRC_NMF", 1);
+    if (K > KU && wide_k && full_mask && !have_map && src_nmf && src_nmf_ok(MM, F, T, K, domain, sizeof(R))) {
+      // 4 < n_basis <= 16, domain 2, no power map at hand: two streaming passes over X, one wave per source
+      // (assx_src_nmf.hpp) -- no map to write and read back, no rank padding
+      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+      const SrcNmfPlan plan = src_nmf_plan(B, MM, F, T, K, sizeof(R), g_target(2));
+      void* rec = (char*)ws + L.srcnmf;
+      void* sums = (char*)rec + plan.rec_bytes;
+      const int rs = src_nmf_update<R, MM>(ctx, X, W, Tb, V, eps, rec, sums, plan, B, F, T, K, dtype, st);
+      if (rs != SRC_NMF_NO_FIT) return rs;
     }
     if (K > KU && wide_k && full_mask) {
       // n_basis > 4: P = |W x|^2 once, then the batched IS-NMF MM update on the matrix cores (same update rule,

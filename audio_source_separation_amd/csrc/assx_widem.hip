@@ -2,6 +2,7 @@
 // points in include/assx.h; the arithmetic contract (floors, exponents, Gauss-Seidel order) is the M <= 4 path's.
 #include "assx_widem.hpp"
 #include "assx_widem_cov.hpp"
+#include "assx_src_nmf.hpp"
 #include "assx_group_linalg.hpp"
 #include "assx_nmf_internal.hpp"
 #include "assx_partition.hpp"
@@ -15,7 +16,7 @@ constexpr int RED_THREADS = 256;
 inline unsigned nblk(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 struct Ws {
-  size_t map0, map1, u, lpart, nmf, tmp, rec, total;
+  size_t map0, map1, u, lpart, nmf, tmp, rec, srcnmf, total;
 };
 
 static int env_int(const char* name, int dflt) {
@@ -51,6 +52,12 @@ static Ws layout(int B, int M, int F, int T, int K, int dtype) {
   off += align_up(assx_nmf_workspace_bytes(B * M, F, T, Kc, dtype), 256);
   w.tmp = off;
   off += align_up(((size_t)B * M * F * Kc + (size_t)B * M * Kc * T) * r, 256);
+  w.srcnmf = off;  // records + sums of the streaming source model (assx_src_nmf.hpp); last: shifts nothing else
+  if (Kc <= SRC_NMF_KMAX) {
+    const int forced = env_int("ASSX_G", 0);
+    const SrcNmfPlan sp = src_nmf_plan(B, M, F, T, Kc, r, forced > 0 ? forced : 512);
+    off += sp.rec_bytes + sp.sums_bytes;
+  }
   w.total = off;
   return w;
 }
@@ -553,6 +560,20 @@ int ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, v
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
     void* P = (char*)ws + L.map0;
+    const unsigned all_src = (1u << MM) - 1u;
+    static const int src_nmf = env_int("ASSX_SRC_NMF", 1);
+    if (!loss_prev && (source_mask & all_src) == all_src && src_nmf && src_nmf_ok(MM, F, T, K, domain, sizeof(R))) {
+      // no loss asked for, every source, n_basis <= 16, domain 2: two streaming passes over X, one wave per source
+      // (assx_src_nmf.hpp) instead of the power map + the matrix-core NMF halves on it
+      const int forced = env_int("ASSX_G", 0);
+      const SrcNmfPlan plan = src_nmf_plan(B, MM, F, T, K, sizeof(R), forced > 0 ? forced : 512);
+      {
+        void* rec = (char*)ws + L.srcnmf;
+        void* sums = (char*)rec + plan.rec_bytes;
+        const int rs = src_nmf_update<R, MM>(ctx, X, W, Tb, V, eps, rec, sums, plan, B, F, T, K, dtype, st);
+        if (rs != SRC_NMF_NO_FIT) return rs;
+      }
+    }
     int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // P = |W x|^2, once
     if (rc) return rc;
     if (loss_prev) {  // the loss of the model at entry needs the same P

@@ -166,6 +166,38 @@ def test_ilrma_source_update(eng, M, K, domain):
     assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("M,K,G", [(4, 10, 0), (4, 10, 3), (2, 5, 2), (3, 8, 5), (4, 12, 1), (4, 16, 7), (3, 13, 4), (2, 7, 0)])
+def test_streaming_source_model_wide_basis(eng, M, K, G):
+    """src_nmf_kernel (csrc/assx_src_nmf.hpp): the n_basis 5..16 source model as two streaming passes over X, on
+    partitions forced down to a handful of workgroups (ASSX_G; 0 = the default partition) so that a small input walks
+    ranges that start / end inside a bin (basis half) or a frame block (activation half), flush several records, reload
+    the activation block, and re-request past the end of the range; ragged T; zero entries in the model (floors);
+    two utterances in one call == one at a time, bit for bit; == the power-map route (ASSX_SRC_NMF=0) to rounding."""
+    import os
+    F, T = 11, 461
+    rng = np.random.default_rng(500 + 10 * M + K)
+    Xs = np.stack([mixture(M, F, T, 501 + M), mixture(M, F, T, 502 + M)])
+    W = np.stack([rand_filters(M, F, 503), rand_filters(M, F, 504)])
+    Tb, V = rng.random((2, M, F, K)) + 0.02, rng.random((2, M, K, T)) + 0.02
+    Tb[0, 0, 2, :] = 0.0
+    V[1, M - 1, :, 70:75] = 0.0  # variance 0 -> floored at eps
+    if G:
+        os.environ["ASSX_G"] = str(G)
+    try:
+        Xb, Wb = dev_c(eng, Xs), dev_c(eng, W)
+        Td, Vd = dev_r(eng, Tb), dev_r(eng, V)
+        eng.ilrma_source_update(Xb, Wb, Td, Vd)
+        for b in range(2):
+            T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], W[b])) ** 2, Tb[b], V[b], 2)
+            assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
+            assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
+            t1, v1 = dev_r(eng, Tb[b:b + 1]), dev_r(eng, V[b:b + 1])
+            eng.ilrma_source_update(Xb[b:b + 1], Wb[b:b + 1], t1, v1)
+            assert torch.equal(t1[0], Td[b]) and torch.equal(v1[0], Vd[b])
+    finally:
+        os.environ.pop("ASSX_G", None)
+
+
 @pytest.mark.parametrize("M,K,domain", [(2, 2, 2), (4, 4, 2), (3, 5, 2), (4, 2, 1)])
 def test_ilrma_spatial_update(eng, M, K, domain):
     F, T = 19, 330

@@ -262,3 +262,32 @@ def test_src_cov_long_ranges(eng, M, K, domain, G):
         assert np.array_equal(Uh, Uh.conj().swapaxes(-1, -2))  # Hermitian bit-exact
     finally:
         os.environ.pop("ASSX_G", None)
+
+
+@pytest.mark.parametrize("M,K,G", [(5, 3, 1), (6, 4, 3), (7, 10, 2), (8, 4, 0), (8, 4, 5), (8, 8, 3), (5, 16, 2), (8, 16, 2)])
+def test_streaming_source_model(eng, M, K, G):
+    """src_nmf_kernel on the wide-channel path (n_basis <= 16, domain 2, no loss asked for): both halves on forced
+    partitions against the oracle, batched == single bit for bit; (8, 16) in float64 does not fit the LDS ring and takes
+    the power-map route (same result to rounding)."""
+    import os
+    F, T = 9, 400
+    rng = np.random.default_rng(600 + 10 * M + K)
+    Xs = np.stack([mixture(M, F, T, 601 + M), mixture(M, F, T, 602 + M)])
+    W = np.stack([rand_filters(M, F, 603), rand_filters(M, F, 604)])
+    Tb, V = rng.random((2, M, F, K)) + 0.02, rng.random((2, M, K, T)) + 0.02
+    V[0, 1, :, 3:6] = 0.0
+    if G:
+        os.environ["ASSX_G"] = str(G)
+    try:
+        Xb, Wb = dev_c(eng, Xs), dev_c(eng, W)
+        Td, Vd = dev_r(eng, Tb), dev_r(eng, V)
+        eng.ilrma_source_update(Xb, Wb, Td, Vd)
+        for b in range(2):
+            T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], W[b])) ** 2, Tb[b], V[b], 2)
+            assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 1e-4)
+            assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 1e-4)
+            t1, v1 = dev_r(eng, Tb[b:b + 1]), dev_r(eng, V[b:b + 1])
+            eng.ilrma_source_update(Xb[b:b + 1], Wb[b:b + 1], t1, v1)
+            assert torch.equal(t1[0], Td[b]) and torch.equal(v1[0], Vd[b])
+    finally:
+        os.environ.pop("ASSX_G", None)
