@@ -21,7 +21,6 @@
 #include "assx_partition.hpp"
 #include "assx_cov_wide.hpp"
 #include "assx_cov_mfma.hpp"
-#include "assx_src_nmf.hpp"
 #include "assx_nmf_internal.hpp"
 #include "assx_widem.hpp"
 
@@ -357,7 +356,7 @@ template <typename R>
 __global__ void __launch_bounds__(256) normalize_power_bins_kernel(Cx<R>* __restrict__ W, R* __restrict__ Tb,
                                                                   const double* __restrict__ pbins, int M, int F,
                                                                   int K, R eps, PowSpec pd) {
-  __shared__ R anorm[8];
+  __shared__ R anorm[32];  // M <= 32 (checked by the entry point)
   const int b = blockIdx.y;
   const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
   // this thread's element of W / Tb is requested first: its round trip overlaps the reduction instead of following it
@@ -776,7 +775,6 @@ struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte al
   size_t map;      // n_basis > 4 only: (B,N,F,T) reals (demixed power / source variance)
   size_t nmf;      // n_basis > 4 only: scratch of the batched IS-NMF update
   size_t tmp;      // n_basis > 4 only: copies of (Tb, V) for a source-masked update
-  size_t srcnmf;   // 4 < n_basis <= 16 only: records + sums of the streaming source model (assx_src_nmf.hpp)
   size_t total;
 };
 
@@ -874,11 +872,6 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
     L.tmp = off;
     off += align_up(((size_t)B * M * F * K + (size_t)B * M * K * T) * r, 256);
   }
-  L.srcnmf = off;
-  if (K > KU && K <= SRC_NMF_KMAX) {
-    const SrcNmfPlan sp = src_nmf_plan(B, M, F, T, K, r, g_target(2));
-    off += sp.rec_bytes + sp.sums_bytes;
-  }
   L.total = off;
   return L;
 }
@@ -911,8 +904,8 @@ int dispatch_rm(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
     return fail(ctx, ASSX_E_ARG, "dtype must be ASSX_F32 or ASSX_F64, got %d", dtype);
   }
   return fail(ctx, ASSX_E_UNSUPPORTED,
-              "this entry point supports 2 <= M <= 4 channels, got M=%d (5 <= M <= 8 runs on the wide-channel path of the "
-              "model entry points; more than 8 channels are not supported)", M);
+              "this entry point supports 2 <= M <= 4 channels, got M=%d (5 <= M <= 32 runs on the wide-channel path of the "
+              "model entry points; more than 32 channels are not supported)", M);
 }
 
 #define CHECK_COMMON(ctx, B, M, F, T)                                                        \
@@ -1400,17 +1393,6 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
       }
     }
-    static const int src_nmf = env_int("ASSX_SRC_NMF", 1);
-    if (K > KU && wide_k && full_mask && !have_map && src_nmf && src_nmf_ok(MM, F, T, K, domain, sizeof(R))) {
-      // 4 < n_basis <= 16, domain 2, no power map at hand: two streaming passes over X, one wave per source
-      // (assx_src_nmf.hpp) -- no map to write and read back, no rank padding
-      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
-      const SrcNmfPlan plan = src_nmf_plan(B, MM, F, T, K, sizeof(R), g_target(2));
-      void* rec = (char*)ws + L.srcnmf;
-      void* sums = (char*)rec + plan.rec_bytes;
-      const int rs = src_nmf_update<R, MM>(ctx, X, W, Tb, V, eps, rec, sums, plan, B, F, T, K, dtype, st);
-      if (rs != SRC_NMF_NO_FIT) return rs;
-    }
     if (K > KU && wide_k && full_mask) {
       // n_basis > 4: P = |W x|^2 once, then the batched IS-NMF MM update on the matrix cores (same update rule,
       // ilrma.py:409-430 == nmf.py:302-327 with target P)
@@ -1730,7 +1712,7 @@ int assx_ilrma_normalize_power_bins(assx_ctx* ctx, void* W, void* Tb, const doub
                                     double eps, int B, int M, int F, int K, int dtype, void* stream) {
   CHECK_COMMON(ctx, B, M, F, 1);
   ASSX_REQUIRE(ctx, W && Tb && power_bins, ASSX_E_NULL, "assx_ilrma_normalize_power_bins: NULL array");
-  ASSX_REQUIRE(ctx, M <= 8, ASSX_E_UNSUPPORTED, "M > 8 unsupported");
+  ASSX_REQUIRE(ctx, M <= 32, ASSX_E_UNSUPPORTED, "more than 32 channels are not supported (M = %d)", M);
   hipStream_t st = (hipStream_t)stream;
   const size_t per_b = (size_t)F * M * M + (size_t)M * F * K;
   const PowSpec pd = make_pow(domain);

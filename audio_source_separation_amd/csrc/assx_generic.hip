@@ -10,7 +10,7 @@ namespace assx {
 // with partial row pivoting -- LAPACK's zgetrf pivot rule (|re| + |im|), which is what numpy.linalg.inv runs.
 // One thread; returns false on an exactly zero pivot (numpy raises LinAlgError("Singular matrix")).
 __device__ inline bool gj_inverse_rt(Cd* A, int M) {
-  int piv[8];
+  int piv[widem::RT_MMAX];
   bool ok = true;
   for (int c = 0; c < M; ++c) {
     int p = c;
@@ -130,6 +130,50 @@ __global__ __launch_bounds__(256) void stack_gram_solve_kernel(const Cx<R>* __re
   }
 }
 
+// The same for a run-time channel count (9 <= M <= 32; assx_widem_rt.hpp's path): S in dynamic LDS, a wave takes the rows
+// of [A; B] round-robin and, per row, the columns one after the other (lanes own frames, float64 sums).
+template <typename R>
+__global__ __launch_bounds__(256) void stack_gram_solve_rt_kernel(const Cx<R>* __restrict__ A, size_t a_bstride, int na,
+                                                                  const Cx<R>* __restrict__ Bm, Cx<R>* __restrict__ out,
+                                                                  size_t ob, size_t of, size_t oi, size_t oj,
+                                                                  int32_t* __restrict__ status, int F, int T, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_sgs[];
+  Cd* S = reinterpret_cast<Cd*>(smem_sgs);  // [(na + M)][M]
+  const int f = blockIdx.x, b = blockIdx.y;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const size_t plane = (size_t)F * T;
+  const Cx<R>* Xb = Bm + (size_t)b * M * plane + (size_t)f * T;
+  const Cx<R>* Ab = A + (size_t)b * a_bstride + (size_t)f * T;
+  const int rows = na + M;
+  for (int r = wave; r < rows; r += 4) {
+    const Cx<R>* srow = r < na ? Ab + (size_t)r * plane : Xb + (size_t)(r - na) * plane;
+    for (int j = 0; j < M; ++j) {
+      double re = 0.0, im = 0.0;
+      for (int t = lane; t < T; t += WAVE) {
+        const Cx<R> sv = srow[t], xv = Xb[(size_t)j * plane + t];
+        const double sx = (double)sv.x, sy = (double)sv.y, xx = (double)xv.x, xy = (double)xv.y;
+        re += __dmul_rn(sx, xx) + __dmul_rn(sy, xy);  // separately rounded products: exactly Hermitian for rows of B
+        im += __dmul_rn(sy, xx) - __dmul_rn(sx, xy);
+      }
+      re = wave_allreduce_sum(re);
+      im = wave_allreduce_sum(im);
+      if (lane == 0) S[r * M + j] = cmake<double>(re, im);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    bool ok = gj_inverse_rt(S + (size_t)na * M, M);
+    if (!ok && status) atomicOr(&status[b], ASSX_STATUS_SINGULAR);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < na * M; e += blockDim.x) {
+    const int n = e / M, m = e % M;
+    Cd w = cmake<double>(0.0, 0.0);
+    for (int k = 0; k < M; ++k) cfma(w, S[n * M + k], S[(na + k) * M + m]);
+    out[(size_t)b * ob + (size_t)f * of + (size_t)n * oi + (size_t)m * oj] = cmake<R>((R)w.x, (R)w.y);
+  }
+}
+
 template <typename R>
 static int launch_sgs(assx_ctx* ctx, const void* A, size_t a_bstride, int na, const void* Bm, int M, void* out, size_t ob,
                       size_t of, size_t oi, size_t oj, int32_t* status, int B, int F, int T, hipStream_t st) {
@@ -149,7 +193,12 @@ static int launch_sgs(assx_ctx* ctx, const void* A, size_t a_bstride, int na, co
     ASSX_SGS_CASE(8)
 #undef ASSX_SGS_CASE
     default:
-      return fail(ctx, ASSX_E_UNSUPPORTED, "2 <= M <= 8 required, got %d", M);
+      if (M > 8 && M <= widem::RT_MMAX) {
+        hipLaunchKernelGGL((stack_gram_solve_rt_kernel<R>), grid, dim3(256), (size_t)(na + M) * M * sizeof(Cd), st,
+                           (const Cx<R>*)A, a_bstride, na, (const Cx<R>*)Bm, (Cx<R>*)out, ob, of, oi, oj, status, F, T, M);
+        break;
+      }
+      return fail(ctx, ASSX_E_UNSUPPORTED, "2 <= M <= %d required, got %d", widem::RT_MMAX, M);
   }
   ASSX_LAUNCH_CHECK(ctx, "stack_gram_solve_kernel");
   return 0;
@@ -158,7 +207,8 @@ static int launch_sgs(assx_ctx* ctx, const void* A, size_t a_bstride, int na, co
 int stack_gram_solve(assx_ctx* ctx, const void* A, size_t a_batch_stride, int na, const void* Bm, int M, void* out,
                      size_t ob, size_t of, size_t oi, size_t oj, int32_t* status, int B, int F, int T, int dtype,
                      hipStream_t st) {
-  if (na < 1 || na > 8) return fail(ctx, ASSX_E_UNSUPPORTED, "stack_gram_solve: 1 <= na <= 8 required, got %d", na);
+  if (na < 1 || na > (M > 8 ? widem::RT_MMAX : 8))
+    return fail(ctx, ASSX_E_UNSUPPORTED, "stack_gram_solve: 1 <= na <= %d required, got %d", M > 8 ? widem::RT_MMAX : 8, na);
   if (dtype == ASSX_F64) return launch_sgs<double>(ctx, A, a_batch_stride, na, Bm, M, out, ob, of, oi, oj, status, B, F, T, st);
   if (dtype == ASSX_F32) return launch_sgs<float>(ctx, A, a_batch_stride, na, Bm, M, out, ob, of, oi, oj, status, B, F, T, st);
   return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
@@ -204,7 +254,8 @@ extern "C" int assx_compute_demix_filter(assx_ctx* ctx, const void* Y, const voi
   ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, B >= 1 && F >= 1 && T >= 1, ASSX_E_ARG, "invalid sizes B=%d F=%d T=%d", B, F, T);
   ASSX_REQUIRE(ctx, Y && X && W, ASSX_E_NULL, "assx_compute_demix_filter: NULL array");
-  ASSX_REQUIRE(ctx, M >= 2 && M <= 8, ASSX_E_UNSUPPORTED, "assx_compute_demix_filter: 2 <= M <= 8 required, got %d", M);
+  ASSX_REQUIRE(ctx, M >= 2 && M <= widem::RT_MMAX, ASSX_E_UNSUPPORTED, "assx_compute_demix_filter: 2 <= M <= %d required, got %d",
+               widem::RT_MMAX, M);
   const size_t plane = (size_t)F * T;
   return stack_gram_solve(ctx, Y, (size_t)M * plane, M, X, M, W, (size_t)F * M * M, (size_t)M * M, (size_t)M, 1, status, B,
                           F, T, dtype, (hipStream_t)stream);

@@ -2,7 +2,7 @@
 // points in include/assx.h; the arithmetic contract (floors, exponents, Gauss-Seidel order) is the M <= 4 path's.
 #include "assx_widem.hpp"
 #include "assx_widem_cov.hpp"
-#include "assx_src_nmf.hpp"
+#include "assx_widem_rt.hpp"
 #include "assx_group_linalg.hpp"
 #include "assx_nmf_internal.hpp"
 #include "assx_partition.hpp"
@@ -16,7 +16,7 @@ constexpr int RED_THREADS = 256;
 inline unsigned nblk(size_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
 
 struct Ws {
-  size_t map0, map1, u, lpart, nmf, tmp, rec, srcnmf, total;
+  size_t map0, map1, u, lpart, nmf, tmp, rec, total;
 };
 
 static int env_int(const char* name, int dflt) {
@@ -52,12 +52,6 @@ static Ws layout(int B, int M, int F, int T, int K, int dtype) {
   off += align_up(assx_nmf_workspace_bytes(B * M, F, T, Kc, dtype), 256);
   w.tmp = off;
   off += align_up(((size_t)B * M * F * Kc + (size_t)B * M * Kc * T) * r, 256);
-  w.srcnmf = off;  // records + sums of the streaming source model (assx_src_nmf.hpp); last: shifts nothing else
-  if (Kc <= SRC_NMF_KMAX) {
-    const int forced = env_int("ASSX_G", 0);
-    const SrcNmfPlan sp = src_nmf_plan(B, M, F, T, Kc, r, forced > 0 ? forced : 512);
-    off += sp.rec_bytes + sp.sums_bytes;
-  }
   w.total = off;
   return w;
 }
@@ -332,23 +326,36 @@ static int dispatch(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
     WIDEM_CASE(8)
   }
 #undef WIDEM_CASE
-  return fail(ctx, ASSX_E_UNSUPPORTED, "the wide-channel path handles 5 <= M <= 8, got M=%d", M);
+  // 9 <= M <= 32: IntC<0> = "M is a run-time value" (assx_widem_rt.hpp: functional, not tuned)
+  if (M > MMAX && M <= RT_MMAX) return dtype == ASSX_F64 ? fn(double(), IntC<0>()) : fn(float(), IntC<0>());
+  return fail(ctx, ASSX_E_UNSUPPORTED, "the wide-channel path handles 5 <= M <= %d, got M=%d", RT_MMAX, M);
 }
 
 template <typename R, int M>
-static int launch_demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y, void* P, int B, int F,
-                        int T, hipStream_t st) {
-  hipLaunchKernelGGL((demix_map_kernel<R, M>), dim3(nblk(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
-                     (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T);
+static int launch_demix(assx_ctx* ctx, int Mr, const void* X, const void* W, const void* scale, void* Y, void* P, int B,
+                        int F, int T, hipStream_t st) {
+  if constexpr (M == 0)  // run-time channel count (Mr > 8)
+    hipLaunchKernelGGL((demix_map_rt_kernel<R>), dim3(nblk(T, 256), F, B), dim3(256), (size_t)Mr * Mr * sizeof(Cx<R>), st,
+                       (const Cx<R>*)X, (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T, Mr);
+  else
+    hipLaunchKernelGGL((demix_map_kernel<R, M>), dim3(nblk(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
+                       (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T);
   ASSX_LAUNCH_CHECK(ctx, "widem::demix_map_kernel");
   return 0;
 }
 
 template <typename R, int M>
-static int launch_cov(assx_ctx* ctx, const void* X, const void* r, int r_kind, int N, double eps, void* U, int B, int F,
-                      int T, hipStream_t st) {
-  hipLaunchKernelGGL((cov_bin_kernel<R, M>), dim3(F, B), dim3(64 * (N > 1 ? N : 4)), 0, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
-                     (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T));
+static int launch_cov(assx_ctx* ctx, int Mr, const void* X, const void* r, int r_kind, int N, double eps, void* U, int B,
+                      int F, int T, hipStream_t st) {
+  if constexpr (M == 0) {  // run-time channel count: one workgroup per (bin, source), a thread per pair (i <= j)
+    const int np = Mr * (Mr + 1) / 2;
+    const int threads = np >= 256 ? 256 : (np + 63) / 64 * 64;
+    const size_t lds = (size_t)RT_TILE * Mr * sizeof(Cx<R>) + RT_TILE * sizeof(R);
+    hipLaunchKernelGGL((cov_rt_kernel<R>), dim3(F, N, B), dim3(threads), lds, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
+                       (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T), Mr);
+  } else
+    hipLaunchKernelGGL((cov_bin_kernel<R, M>), dim3(F, B), dim3(64 * (N > 1 ? N : 4)), 0, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
+                       (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T));
   ASSX_LAUNCH_CHECK(ctx, "widem::cov_bin_kernel");
   return 0;
 }
@@ -374,6 +381,9 @@ static int launch_src_cov_as(assx_ctx* ctx, const void* X, const void* Tb, const
 template <typename R, int M>
 static int launch_src_cov(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int wk, int K, double domain,
                           double eps, void* U, void* rec, int B, int F, int T, hipStream_t st) {
+  if constexpr (M == 0) {  // run-time channel count: never routed here (src_cov_ok)
+    return fail(ctx, ASSX_E_UNSUPPORTED, "src_cov_kernel needs a compile-time channel count");
+  } else {
   const FlatPart fp = flat_src_cov(B, F, T);
   int rc;
   if (wk == WK_NT) rc = launch_src_cov_as<R, M, WK_NT>(ctx, X, nullptr, V, 1, eps, rec, fp, B, F, T, st);
@@ -386,18 +396,33 @@ static int launch_src_cov(assx_ctx* ctx, const void* X, const void* Tb, const vo
                      (const R*)rec, (Cx<R>*)U, B, F, fp, (R)(1.0 / (double)T));
   ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_finalize_kernel");
   return 0;
+  }
 }
 // the streaming kernel addresses an utterance's X and weight arrays with 32-bit byte offsets; ASSX_WIDEM_COV=0 keeps
 // round 2's one-workgroup-per-bin kernel on materialised weights (A/B runs)
-static bool src_cov_ok(int M, int F, int T, size_t r) {
+static bool src_cov_ok(int M, int F, int T, size_t r) {  // M = 0: run-time channel count (> 8), not served
   static const int on = env_int("ASSX_WIDEM_COV", 1);
-  return on != 0 && (size_t)M * F * T * 2 * r < 0xffffffffull;
+  return M != 0 && on != 0 && (size_t)M * F * T * 2 * r < 0xffffffffull;
 }
 
 template <typename R, int M>
-static int launch_sweep(assx_ctx* ctx, int spatial, int pm, int pn, const void* U, void* W, const void* C, double* pw,
+static int launch_sweep(assx_ctx* ctx, int Mr, int spatial, int pm, int pn, const void* U, void* W, const void* C, double* pw,
                         double thr, int32_t* status, int B, int F, int T, hipStream_t st, double den_floor = 0.0) {
   const dim3 grid((unsigned)((size_t)B * F)), block(64);  // 64 lanes = one bin (GW = 64 for M >= 5)
+  if constexpr (M == 0) {  // run-time channel count: IP only (one wave per bin, matrices in LDS)
+    if (spatial != ASSX_SPATIAL_IP)
+      return fail(ctx, ASSX_E_UNSUPPORTED, "more than %d channels: only the IP sweep is available (M = %d)", MMAX, Mr);
+    const size_t lds = ip_rt_lds_bytes(Mr);
+    if (lds > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ip_rt_kernel<R>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(ip_rt_kernel)");
+    }
+    hipLaunchKernelGGL((ip_rt_kernel<R>), grid, block, lds, st, (const Cx<R>*)U, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status,
+                       B, F, den_floor, Mr);
+    ASSX_LAUNCH_CHECK(ctx, "widem::ip_rt_kernel");
+    return 0;
+  } else {
   const FlatPart fp{};
   if (spatial == ASSX_SPATIAL_IP)
     hipLaunchKernelGGL((ip_group_kernel<R, M, false>), grid, block, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
@@ -412,6 +437,7 @@ static int launch_sweep(assx_ctx* ctx, int spatial, int pm, int pn, const void* 
     return fail(ctx, ASSX_E_ARG, "bad spatial algorithm %d", spatial);
   ASSX_LAUNCH_CHECK(ctx, "widem sweep (group kernel)");
   return 0;
+  }
 }
 
 template <typename R>
@@ -425,19 +451,23 @@ static int launch_variance(assx_ctx* ctx, const void* Tb, const void* V, void* R
 
 // loss[b] = sum_{n,f,t} P/R + log R  -  2 T sum_f log|det W_f|, from the maps already in ws
 template <typename R, int M>
-static int loss_from_maps(assx_ctx* ctx, const Ws& L, const void* W, double eps, double* loss, void* ws, int B, int F,
-                          int T, hipStream_t st, double nu = -1.0) {
+static int loss_from_maps(assx_ctx* ctx, int Mr, const Ws& L, const void* W, double eps, double* loss, void* ws, int B,
+                          int F, int T, hipStream_t st, double nu = -1.0) {
   double* lpart = (double*)((char*)ws + L.lpart);
   const int lstride = RB + F;
   if (nu >= 0.0)  // Student-t term (t-ILRMA)
     hipLaunchKernelGGL((map_sum_kernel<R, 2>), dim3(RB, B), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
-                       (const R*)((char*)ws + L.map1), lpart, (size_t)M * F * T, lstride, (R)eps, (R)nu);
+                       (const R*)((char*)ws + L.map1), lpart, (size_t)Mr * F * T, lstride, (R)eps, (R)nu);
   else
     hipLaunchKernelGGL((map_sum_kernel<R, 1>), dim3(RB, B), dim3(RED_THREADS), 0, st, (const R*)((char*)ws + L.map0),
-                       (const R*)((char*)ws + L.map1), lpart, (size_t)M * F * T, lstride, (R)eps, (R)0);
+                       (const R*)((char*)ws + L.map1), lpart, (size_t)Mr * F * T, lstride, (R)eps, (R)0);
   ASSX_LAUNCH_CHECK(ctx, "widem::map_sum_kernel(loss)");
-  hipLaunchKernelGGL((logdet_kernel<R, M>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B, F,
-                     T, lstride, RB);
+  if constexpr (M == 0)  // run-time channel count: one wave per bin, LU in LDS
+    hipLaunchKernelGGL((logdet_rt_kernel<R>), dim3((unsigned)((size_t)B * F)), dim3(64), (size_t)Mr * Mr * sizeof(Cd), st,
+                       (const Cx<R>*)W, lpart, B, F, T, lstride, RB, Mr);
+  else
+    hipLaunchKernelGGL((logdet_kernel<R, M>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B, F,
+                       T, lstride, RB);
   ASSX_LAUNCH_CHECK(ctx, "widem::logdet_kernel");
   hipLaunchKernelGGL((row_sum_kernel<double>), dim3(B), dim3(RED_THREADS), 0, st, (const double*)lpart, loss, lstride,
                      lstride, 1.0);
@@ -451,14 +481,14 @@ static int loss_from_maps(assx_ctx* ctx, const Ws& L, const void* W, double eps,
 int demix(assx_ctx* ctx, const void* X, const void* W, const void* scale, void* Y, int B, int M, int F, int T, int dtype,
           hipStream_t st) {
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
-    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, X, W, scale, Y, nullptr, B, F, T, st);
+    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, M, X, W, scale, Y, nullptr, B, F, T, st);
   });
 }
 
 int power_map(assx_ctx* ctx, const void* X, const void* W, void* P, int B, int M, int F, int T, int dtype,
               hipStream_t st) {
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
-    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);
+    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, M, X, W, nullptr, nullptr, P, B, F, T, st);
   });
 }
 
@@ -467,32 +497,33 @@ int cov_accumulate(assx_ctx* ctx, const void* X, const void* r, int r_kind, doub
   const Ws L = layout(B, M, F, T, 1, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     const int rk = r_kind == ASSX_W_NONE ? RK_NONE : (r_kind == ASSX_W_NT ? RK_NT : RK_NFT);
-    if (rk != RK_NONE && N == MM && ws && src_cov_ok(MM, F, T, sizeof(R)))
-      return launch_src_cov<R, MM>(ctx, X, nullptr, r, rk == RK_NT ? WK_NT : WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F,
+    if (rk != RK_NONE && N == MM && ws && src_cov_ok(MT, F, T, sizeof(R)))
+      return launch_src_cov<R, MT>(ctx, X, nullptr, r, rk == RK_NT ? WK_NT : WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F,
                                    T, st);
-    return launch_cov<R, MM>(ctx, X, r, rk, N, eps, U, B, F, T, st);
+    return launch_cov<R, MT>(ctx, MM, X, r, rk, N, eps, U, B, F, T, st);
   });
 }
 
 int ip_update(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int B, int M, int F, int dtype,
               hipStream_t st) {
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
-    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status,
+    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, M, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status,
                                                            B, F, 1, st);
   });
 }
 int iss_update(assx_ctx* ctx, const void* U, void* W, int n_frames, int B, int M, int F, int dtype, hipStream_t st) {
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
-    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, ASSX_SPATIAL_ISS, 0, 1, U, W, nullptr, nullptr, 0.0,
+    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, M, ASSX_SPATIAL_ISS, 0, 1, U, W, nullptr, nullptr, 0.0,
                                                            nullptr, B, F, n_frames, st);
   });
 }
 int ip2_update(assx_ctx* ctx, const void* U, void* W, double thr, int32_t* status, int pm, int pn, int B, int M, int F,
                int dtype, hipStream_t st) {
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
-    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, ASSX_SPATIAL_IP2, pm, pn, U, W, nullptr, nullptr, thr,
+    return launch_sweep<decltype(rt), decltype(mt)::value>(ctx, M, ASSX_SPATIAL_IP2, pm, pn, U, W, nullptr, nullptr, thr,
                                                            status, B, F, 1, st);
   });
 }
@@ -502,11 +533,12 @@ int ilrma_loss(assx_ctx* ctx, const void* X, const void* W, const void* Tb, cons
   const Ws L = layout(B, M, F, T, K, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
     if (rc) return rc;
     if ((rc = launch_variance<R>(ctx, Tb, V, (char*)ws + L.map1, domain, B * MM, F, T, K, st))) return rc;
-    return loss_from_maps<R, MM>(ctx, L, W, eps, loss, ws, B, F, T, st, nu);
+    return loss_from_maps<R, MT>(ctx, MM, L, W, eps, loss, ws, B, F, T, st, nu);
   });
 }
 
@@ -517,9 +549,10 @@ int tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, 
   const Ws L = layout(B, M, F, T, K, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     void* P = (char*)ws + L.map0;
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, P, B, F, T, st);
     if (rc) return rc;
     NmfGroupScope grp(ctx, MM);
     return assx_nmf_update_ex(ctx, ASSX_NMF_T_RAW, 2.0, nu, eps, P, Tb, V, (char*)ws + L.nmf, B * MM, F, T, K, dtype, st);
@@ -532,9 +565,10 @@ int tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb,
   const Ws L = layout(B, M, F, T, K, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     void* P = (char*)ws + L.map0;
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // with the filters BEFORE the sweep
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, P, B, F, T, st);  // with the filters BEFORE the sweep
     if (rc) return rc;
     if ((rc = launch_variance<R>(ctx, Tb, V, Xi, 2.0, B * MM, F, T, K, st))) return rc;
     const size_t count = (size_t)B * MM * F * T;
@@ -543,12 +577,12 @@ int tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void* Tb,
     ASSX_LAUNCH_CHECK(ctx, "widem::xi_map_kernel");
     void* U = (char*)ws + L.u;
     // Xi is used as is (the reference does not floor it); no condition-number guard, normaliser floored at eps
-    if (src_cov_ok(MM, F, T, sizeof(R)))
-      rc = launch_src_cov<R, MM>(ctx, X, nullptr, Xi, WK_NFT, 1, 2.0, 0.0, U, (char*)ws + L.rec, B, F, T, st);
+    if (src_cov_ok(MT, F, T, sizeof(R)))
+      rc = launch_src_cov<R, MT>(ctx, X, nullptr, Xi, WK_NFT, 1, 2.0, 0.0, U, (char*)ws + L.rec, B, F, T, st);
     else
-      rc = launch_cov<R, MM>(ctx, X, Xi, RK_NFT, MM, 0.0, U, B, F, T, st);
+      rc = launch_cov<R, MT>(ctx, MM, X, Xi, RK_NFT, MM, 0.0, U, B, F, T, st);
     if (rc) return rc;
-    return launch_sweep<R, MM>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, C, power_bins, INFINITY, status, B, F, T, st, eps);
+    return launch_sweep<R, MT>(ctx, MM, ASSX_SPATIAL_IP, 0, 1, U, W, C, power_bins, INFINITY, status, B, F, T, st, eps);
   });
 }
 
@@ -558,29 +592,16 @@ int ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* Tb, v
   const Ws L = layout(B, M, F, T, K, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     void* P = (char*)ws + L.map0;
-    const unsigned all_src = (1u << MM) - 1u;
-    static const int src_nmf = env_int("ASSX_SRC_NMF", 1);
-    if (!loss_prev && (source_mask & all_src) == all_src && src_nmf && src_nmf_ok(MM, F, T, K, domain, sizeof(R))) {
-      // no loss asked for, every source, n_basis <= 16, domain 2: two streaming passes over X, one wave per source
-      // (assx_src_nmf.hpp) instead of the power map + the matrix-core NMF halves on it
-      const int forced = env_int("ASSX_G", 0);
-      const SrcNmfPlan plan = src_nmf_plan(B, MM, F, T, K, sizeof(R), forced > 0 ? forced : 512);
-      {
-        void* rec = (char*)ws + L.srcnmf;
-        void* sums = (char*)rec + plan.rec_bytes;
-        const int rs = src_nmf_update<R, MM>(ctx, X, W, Tb, V, eps, rec, sums, plan, B, F, T, K, dtype, st);
-        if (rs != SRC_NMF_NO_FIT) return rs;
-      }
-    }
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // P = |W x|^2, once
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, P, B, F, T, st);  // P = |W x|^2, once
     if (rc) return rc;
     if (loss_prev) {  // the loss of the model at entry needs the same P
       if ((rc = launch_variance<R>(ctx, Tb, V, (char*)ws + L.map1, domain, B * MM, F, T, K, st))) return rc;
-      if ((rc = loss_from_maps<R, MM>(ctx, L, W, eps, loss_prev, ws, B, F, T, st))) return rc;
+      if ((rc = loss_from_maps<R, MT>(ctx, MM, L, W, eps, loss_prev, ws, B, F, T, st))) return rc;
     }
-    const unsigned all = (1u << MM) - 1u;
+    const unsigned all = MM >= 32 ? ~0u : (1u << MM) - 1u;
     if ((source_mask & all) == 0u) return 0;
     NmfGroupScope grp(ctx, MM);
     if ((source_mask & all) == all)  // ilrma.py:409-430 == nmf.py:302-327 with target P, batch B*N
@@ -608,21 +629,22 @@ int ilrma_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void*
   const Ws L = layout(B, M, F, T, K, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     void* Rm = (char*)ws + L.map1;
     void* U = U_out ? U_out : (void*)((char*)ws + L.u);
     int rc;
-    if (src_cov_ok(MM, F, T, sizeof(R)) && K <= SRC_COV_KMAX && domain == 2.0) {  // weights rebuilt in the kernel: no variance map
-      rc = launch_src_cov<R, MM>(ctx, X, Tb, V, WK_TV, K, domain, eps, U, (char*)ws + L.rec, B, F, T, st);
+    if (src_cov_ok(MT, F, T, sizeof(R)) && K <= SRC_COV_KMAX && domain == 2.0) {  // weights rebuilt in the kernel: no variance map
+      rc = launch_src_cov<R, MT>(ctx, X, Tb, V, WK_TV, K, domain, eps, U, (char*)ws + L.rec, B, F, T, st);
     } else {
       if ((rc = launch_variance<R>(ctx, Tb, V, Rm, domain, B * MM, F, T, K, st))) return rc;
-      if (src_cov_ok(MM, F, T, sizeof(R)))
-        rc = launch_src_cov<R, MM>(ctx, X, nullptr, Rm, WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
+      if (src_cov_ok(MT, F, T, sizeof(R)))
+        rc = launch_src_cov<R, MT>(ctx, X, nullptr, Rm, WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
       else
-        rc = launch_cov<R, MM>(ctx, X, Rm, RK_NFT, MM, eps, U, B, F, T, st);
+        rc = launch_cov<R, MT>(ctx, MM, X, Rm, RK_NFT, MM, eps, U, B, F, T, st);
     }
     if (rc) return rc;
-    return launch_sweep<R, MM>(ctx, spatial, pm, pn, U, W, C, power_bins, thr, status, B, F, T, st);
+    return launch_sweep<R, MT>(ctx, MM, spatial, pm, pn, U, W, C, power_bins, thr, status, B, F, T, st);
   });
 }
 
@@ -635,9 +657,11 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
                                     hipStream_t st) {
   const Ws L = layout(B, M, F, T, K, dtype);
   if (K > 64) return fail(ctx, ASSX_E_UNSUPPORTED, "partitioning with M = %d > 4 needs n_basis <= 64, got %d", M, K);
+  if (M > MMAX) return fail(ctx, ASSX_E_UNSUPPORTED, "the partitioning function is available for up to %d channels, got %d", MMAX, M);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     const size_t nT = (size_t)B * MM * F * K, nV = (size_t)B * MM * K * T;
     auto expand = [&](bool with_v) -> int {
       hipLaunchKernelGGL((part_expand_kernel<R>), dim3(nblk(with_v ? nT + nV : nT, 256)), dim3(256), 0, st, (const R*)Z,
@@ -648,7 +672,7 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
     void* P = (char*)ws + L.map0;
     R* rec = (R*)((char*)ws + L.map1);
     void* nws = (char*)ws + L.nmf;
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, P, B, F, T, st);  // W does not move here: P once
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, P, B, F, T, st);  // W does not move here: P once
     if (rc) return rc;
     const int TBk = (T + WAVE - 1) / WAVE;
     const FlatPart fpb{(long long)F * TBk, TBk, TBk, B * F, 1, F, F};      // one record per bin
@@ -671,7 +695,8 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
     };
     if ((rc = expand(true))) return rc;
     if ((rc = sums(NMF_HALF_BASIS))) return rc;
-    hipLaunchKernelGGL((part_latent_kernel<R, MM>), dim3(K, B), dim3(256), 0, st, (const R*)rec, (const R*)Tb, (R*)Z, F, K,
+    if constexpr (MT != 0)
+    hipLaunchKernelGGL((part_latent_kernel<R, MT>), dim3(K, B), dim3(256), 0, st, (const R*)rec, (const R*)Tb, (R*)Z, F, K,
                        fpb, (R)eps);
     ASSX_LAUNCH_CHECK(ctx, "part_latent_kernel");
     if ((rc = expand(false))) return rc;
@@ -690,11 +715,14 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
 
 int normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins, double eps,
                                      void* ws, int B, int M, int F, int K, int dtype, hipStream_t st) {
+  if (M > MMAX) return fail(ctx, ASSX_E_UNSUPPORTED, "the partitioning function is available for up to %d channels, got %d", MMAX, M);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     const size_t per_b = (size_t)F * MM * MM + (size_t)F * K;
-    hipLaunchKernelGGL((part_normalize_power_kernel<R, MM>), dim3(nblk(per_b, 256), B), dim3(256), (size_t)K * sizeof(R),
+    if constexpr (MT != 0)
+    hipLaunchKernelGGL((part_normalize_power_kernel<R, MT>), dim3(nblk(per_b, 256), B), dim3(256), (size_t)K * sizeof(R),
                        st, (Cx<R>*)W, (R*)ws, (const R*)Z, (R*)Tb, power_bins, F, K, (R)eps);
     ASSX_LAUNCH_CHECK(ctx, "part_normalize_power_kernel");
     hipError_t e = hipMemcpyAsync(Z, ws, (size_t)B * MM * K * sizeof(R), hipMemcpyDeviceToDevice, st);
@@ -709,15 +737,16 @@ int weighted_ip(assx_ctx* ctx, const void* X, const void* r, double eps, double 
   const Ws L = layout(B, M, F, T, 1, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     void* U = (char*)ws + L.u;
     int rc;
-    if (src_cov_ok(MM, F, T, sizeof(R)))
-      rc = launch_src_cov<R, MM>(ctx, X, nullptr, r, WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
+    if (src_cov_ok(MT, F, T, sizeof(R)))
+      rc = launch_src_cov<R, MT>(ctx, X, nullptr, r, WK_NFT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
     else
-      rc = launch_cov<R, MM>(ctx, X, r, RK_NFT, MM, eps, U, B, F, T, st);
+      rc = launch_cov<R, MT>(ctx, MM, X, r, RK_NFT, MM, eps, U, B, F, T, st);
     if (rc) return rc;
-    return launch_sweep<R, MM>(ctx, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status, B, F, T, st, den_floor);
+    return launch_sweep<R, MT>(ctx, MM, ASSX_SPATIAL_IP, 0, 1, U, W, nullptr, nullptr, thr, status, B, F, T, st, den_floor);
   });
 }
 
@@ -726,8 +755,9 @@ int demix_power(assx_ctx* ctx, const void* X, const void* W, void* power, void* 
   const Ws L = layout(B, M, F, T, 1, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
     if (rc) return rc;
     double* part = (double*)((char*)ws + L.lpart);
     hipLaunchKernelGGL((map_sum_kernel<R, 0>), dim3(RB, B * MM), dim3(RED_THREADS), 0, st,
@@ -744,7 +774,8 @@ int power_from_cov(assx_ctx* ctx, const void* C, const void* W, void* power, voi
                    hipStream_t st) {
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     double* part = (double*)ws;
     hipLaunchKernelGGL((power_cov_kernel<R>), dim3(nblk((size_t)B * F * MM, 256)), dim3(256), 0, st, (const Cx<R>*)C,
                        (const Cx<R>*)W, part, B, F, MM);
@@ -761,8 +792,9 @@ int auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, double
   const Ws L = layout(B, M, F, T, 1, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
-    int rc = launch_demix<R, MM>(ctx, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
+    int rc = launch_demix<R, MT>(ctx, MM, X, W, nullptr, nullptr, (char*)ws + L.map0, B, F, T, st);
     if (rc) return rc;
     const int TB = (int)nblk(T, RED_THREADS);
     const int lstride = MM * TB + F;
@@ -771,8 +803,12 @@ int auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, double
                        (R*)r, lpart, kind, (R)eps, MM, F, T, lstride);
     ASSX_LAUNCH_CHECK(ctx, "widem::aux_stat_kernel");
     if (loss) {
-      hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B,
-                         F, T, lstride, MM * TB);
+      if constexpr (MT == 0)
+        hipLaunchKernelGGL((logdet_rt_kernel<R>), dim3((unsigned)((size_t)B * F)), dim3(64), (size_t)MM * MM * sizeof(Cd), st,
+                           (const Cx<R>*)W, lpart, B, F, T, lstride, MM * TB, MM);
+      else
+        hipLaunchKernelGGL((logdet_kernel<R, MT>), dim3(nblk((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W, lpart, B,
+                           F, T, lstride, MM * TB);
       ASSX_LAUNCH_CHECK(ctx, "widem::logdet_kernel");
       hipLaunchKernelGGL((row_sum_kernel<double>), dim3(B), dim3(RED_THREADS), 0, st, (const double*)lpart, loss, lstride,
                          lstride, 1.0);
@@ -788,15 +824,16 @@ int auxiva_spatial_update(assx_ctx* ctx, int spatial, int pm, int pn, const void
   const Ws L = layout(B, M, F, T, 1, dtype);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
-    constexpr int MM = decltype(mt)::value;
+    constexpr int MT = decltype(mt)::value;
+    const int MM = MT ? MT : M;
     void* U = U_out ? U_out : (void*)((char*)ws + L.u);
     int rc;
-    if (src_cov_ok(MM, F, T, sizeof(R)))
-      rc = launch_src_cov<R, MM>(ctx, X, nullptr, r, WK_NT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
+    if (src_cov_ok(MT, F, T, sizeof(R)))
+      rc = launch_src_cov<R, MT>(ctx, X, nullptr, r, WK_NT, 1, 2.0, eps, U, (char*)ws + L.rec, B, F, T, st);
     else
-      rc = launch_cov<R, MM>(ctx, X, r, RK_NT, MM, eps, U, B, F, T, st);
+      rc = launch_cov<R, MT>(ctx, MM, X, r, RK_NT, MM, eps, U, B, F, T, st);
     if (rc) return rc;
-    return launch_sweep<R, MM>(ctx, spatial, pm, pn, U, W, nullptr, nullptr, thr, status, B, F, T, st);
+    return launch_sweep<R, MT>(ctx, MM, spatial, pm, pn, U, W, nullptr, nullptr, thr, status, B, F, T, st);
   });
 }
 
@@ -806,7 +843,7 @@ int projection_back_scale(assx_ctx* ctx, const void* X, const void* W, int ref, 
   const size_t c = dtype == ASSX_F64 ? 16 : 8, plane = (size_t)F * T;
   void* Y = (char*)ws + L.map0;  // complex map: spans map0 and map1
   int rc = dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
-    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, X, W, nullptr, Y, nullptr, B, F, T, st);
+    return launch_demix<decltype(rt), decltype(mt)::value>(ctx, M, X, W, nullptr, Y, nullptr, B, F, T, st);
   });
   if (rc) return rc;
   // scale[b,n,f] = (x_ref Y^H (Y Y^H)^{-1})[n]   (projection_back.py:13-21)

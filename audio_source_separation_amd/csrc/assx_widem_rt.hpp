@@ -1,0 +1,380 @@
+// Run-time channel count, 9 <= M <= 32: the kernels of the wide-channel path (assx_widem.hip) whose register / lane-group
+// layouts are tied to a compile-time M <= 8, restated for any M.  The reference is generic in M (src/bss/ilrma.py:61-62,
+// src/bss/iva.py:39-59); arrays with more than 8 channels are rare, so this path is FUNCTIONAL, not tuned: every kernel
+// is the simplest deterministic form (matrices in LDS, one wave or one workgroup per bin), the arithmetic contract (floors,
+// pivot rule, condition guard, Gauss-Seidel order) is the M <= 8 path's.  Everything that is already generic there (the
+// P / R maps, the matrix-core source model, the fixed-order reductions, power_cov_kernel) is shared.
+#pragma once
+#include "assx_small_linalg.hpp"
+#include "assx_stream.hpp"
+#include "assx_widem.hpp"
+
+namespace assx {
+namespace widem {
+
+// ------------------------------------------------------------------------------------------------------------------
+// y = W x per (f, t), run-time M; W_f in (dynamic) LDS.  Writes Y (optionally scaled) and / or |y|^2.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256) demix_map_rt_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
+                                                          const Cx<R>* __restrict__ scale, Cx<R>* __restrict__ Y,
+                                                          R* __restrict__ P, int F, int T, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  Cx<R>* w = reinterpret_cast<Cx<R>*>(smem_rt);
+  const int f = blockIdx.y, b = blockIdx.z;
+  for (int i = threadIdx.x; i < M * M; i += blockDim.x) w[i] = W[((size_t)b * F + f) * ((size_t)M * M) + i];
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= T) return;
+  const size_t FT = (size_t)F * T, base = (size_t)b * M * FT + (size_t)f * T + t;
+  for (int n = 0; n < M; ++n) {
+    Cx<R> s = cmake<R>(0, 0);
+    for (int m = 0; m < M; ++m) cfma(s, w[n * M + m], X[base + (size_t)m * FT]);  // x_m: an L1 hit after the first source
+    if (P) P[base + (size_t)n * FT] = cabs2(s);
+    if (Y) {
+      if (scale) s = cmul(s, scale[((size_t)b * M + n) * F + f]);
+      Y[base + (size_t)n * FT] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weighted covariance, one workgroup per (bin, source): a thread owns up to RT_PAIRS pairs (i <= j) of the Hermitian
+// matrix; frames arrive in tiles of RT_TILE, staged FRAME-MAJOR in LDS (at a given frame every thread reads two of the M
+// samples of one short row: broadcasts, no bank conflicts) together with the tile's reciprocal weights.
+// U[b,n,f] = (1/T) sum_t x x^H / max(r_n, eps); r_kind as cov_bin_kernel (0 none, 1 (N,T), 2 (N,F,T)).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int RT_TILE = 64, RT_PAIRS = 3;  // M <= 32: 528 pairs over 256 threads
+
+template <typename R>
+__global__ void __launch_bounds__(256) cov_rt_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ r, int r_kind,
+                                                    int N, R eps, Cx<R>* __restrict__ U, int F, int T, R inv_T, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  Cx<R>* xt = reinterpret_cast<Cx<R>*>(smem_rt);            // [RT_TILE][M]
+  R* wt = reinterpret_cast<R*>(xt + (size_t)RT_TILE * M);   // [RT_TILE]
+  const int f = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  const int NP = M * (M + 1) / 2;
+  const size_t FT = (size_t)F * T;
+  const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * T;
+  const R* rn = nullptr;
+  if (r_kind == 1) rn = r + ((size_t)b * N + n) * T;
+  else if (r_kind == 2) rn = r + ((size_t)b * N + n) * FT + (size_t)f * T;
+  int pi[RT_PAIRS], pj[RT_PAIRS];
+  R ar[RT_PAIRS], ai[RT_PAIRS];
+#pragma unroll
+  for (int q = 0; q < RT_PAIRS; ++q) {
+    int p = (int)threadIdx.x + q * (int)blockDim.x;
+    ar[q] = ai[q] = 0;
+    pi[q] = pj[q] = -1;
+    if (p < NP) {  // p -> (i, j >= i), rows ascending
+      int i = 0;
+      while (p >= M - i) {
+        p -= M - i;
+        ++i;
+      }
+      pi[q] = i;
+      pj[q] = i + p;
+    }
+  }
+  for (int t0 = 0; t0 < T; t0 += RT_TILE) {
+    __syncthreads();  // the previous tile is no longer read
+    for (int e = threadIdx.x; e < M * RT_TILE; e += blockDim.x) {
+      const int m = e / RT_TILE, tt = e - m * RT_TILE;  // consecutive threads: consecutive frames of one channel (coalesced)
+      xt[(size_t)tt * M + m] = (t0 + tt < T) ? xb[(size_t)m * FT + t0 + tt] : cmake<R>(0, 0);
+    }
+    if ((int)threadIdx.x < RT_TILE) {
+      const int t = t0 + (int)threadIdx.x;
+      R wv = 0;
+      if (t < T) wv = rn ? fast_rcp(floor_eps<R>(rn[t], eps)) : (R)1;
+      wt[threadIdx.x] = wv;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RT_PAIRS; ++q) {
+      if (pi[q] < 0) continue;
+      for (int tt = 0; tt < RT_TILE; ++tt) {  // frames in ascending order
+        const Cx<R> xi = xt[(size_t)tt * M + pi[q]], xj = xt[(size_t)tt * M + pj[q]];
+        const R sx = wt[tt] * xi.x, sy = wt[tt] * xi.y;
+        ar[q] = fma(sx, xj.x, ar[q]);
+        ar[q] = fma(sy, xj.y, ar[q]);
+        ai[q] = fma(sy, xj.x, ai[q]);
+        ai[q] = fma(-sx, xj.y, ai[q]);
+      }
+    }
+  }
+  Cx<R>* un = U + (((size_t)b * N + n) * F + f) * ((size_t)M * M);
+#pragma unroll
+  for (int q = 0; q < RT_PAIRS; ++q) {
+    if (pi[q] < 0) continue;
+    const R re = ar[q] * inv_T, im = pi[q] == pj[q] ? (R)0 : ai[q] * inv_T;
+    un[pi[q] * M + pj[q]] = cmake<R>(re, im);
+    if (pi[q] != pj[q]) un[pj[q] * M + pi[q]] = cmake<R>(re, -im);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One wave per bin, matrices (float64) in LDS.  Helpers: every lane of the wave calls them; `wave_sync_lds()` orders the
+// wave's LDS traffic between phases.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_allreduce_sum<double>(v); }
+
+// In-place inverse of A (M x M, row-major, LDS) by Gauss-Jordan with partial row pivoting, LAPACK's pivot rule
+// (|re| + |im|, first maximum) -- gj_inverse_rt of assx_generic.hip with the row operations spread over the wave.
+// piv: M ints in LDS.  Returns false on an exactly zero pivot.
+__device__ inline bool wave_gj_inverse(Cd* A, int* piv, int M, int lane) {
+  bool ok = true;
+  for (int c = 0; c < M; ++c) {
+    // pivot search over rows c..M-1: first row with the largest |re| + |im|
+    double best = -1.0;
+    int p = c;
+    for (int r = c + lane; r < M; r += WAVE) {
+      const double v = cabs1(A[r * M + c]);
+      if (v > best) {
+        best = v;
+        p = r;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ob = __shfl_xor(best, off, WAVE);
+      const int op = __shfl_xor(p, off, WAVE);
+      if (ob > best || (ob == best && op < p)) {
+        best = ob;
+        p = op;
+      }
+    }
+    if (lane == 0) piv[c] = p;
+    if (!(best > 0.0)) ok = false;
+    if (p != c)
+      for (int j = lane; j < M; j += WAVE) cswap(A[c * M + j], A[p * M + j]);
+    wave_sync_lds();
+    const Cd pv = A[c * M + c];
+    // eliminate with the UNSCALED pivot row and the LU multiplier (an exactly dependent row cancels to exact zeros)
+    for (int e = lane; e < M * M; e += WAVE) {
+      const int r = e / M, j = e - r * M;
+      if (r == c || j == c) continue;
+      const Cd fct = cdiv(A[r * M + c], pv);
+      const Cd a = A[c * M + j];
+      Cd v = A[e];
+      v.x = v.x - (fct.x * a.x - fct.y * a.y);
+      v.y = v.y - (fct.x * a.y + fct.y * a.x);
+      A[e] = v;
+    }
+    wave_sync_lds();
+    for (int r = lane; r < M; r += WAVE) {
+      if (r == c) continue;
+      const Cd fct = cdiv(A[r * M + c], pv);
+      A[r * M + c] = cmake<double>(-fct.x, -fct.y);
+    }
+    wave_sync_lds();
+    const Cd ipv = cdiv(cmake<double>(1.0, 0.0), pv);
+    for (int j = lane; j < M; j += WAVE) A[c * M + j] = (j == c) ? ipv : cmul(A[c * M + j], ipv);
+    wave_sync_lds();
+  }
+  for (int c = M - 1; c >= 0; --c) {
+    const int p = piv[c];
+    if (p != c)
+      for (int i = lane; i < M; i += WAVE) cswap(A[i * M + c], A[i * M + p]);
+    wave_sync_lds();
+  }
+  return ok;
+}
+
+// spectral norm of A (LDS) by squaring G = A^H A / tr: the arithmetic of group_spectral_norm (assx_group_linalg.hpp);
+// G0, G1, G2: M x M scratch in LDS
+__device__ inline double wave_spectral_norm(const Cd* A, Cd* G0, Cd* G1, Cd* G2, int M, int lane) {
+  for (int e = lane; e < M * M; e += WAVE) {
+    const int i = e / M, j = e - i * M;
+    Cd g = cmake<double>(0.0, 0.0);
+    for (int k = 0; k < M; ++k) cfma(g, cconj(A[k * M + i]), A[k * M + j]);
+    G0[e] = g;
+  }
+  wave_sync_lds();
+  double trp = 0.0;
+  for (int i = lane; i < M; i += WAVE) trp += G0[i * M + i].x;
+  const double tr = wave_sum_d(trp);
+  if (!(tr > 0.0) || !isfinite(tr)) return tr > 0.0 ? tr : 0.0;
+  for (int e = lane; e < M * M; e += WAVE) {
+    G0[e] = cscale(G0[e], 1.0 / tr);
+    G1[e] = G0[e];
+  }
+  wave_sync_lds();
+  Cd* g = G1;
+  Cd* h = G2;
+  for (int it = 0; it < 24; ++it) {
+    for (int e = lane; e < M * M; e += WAVE) {
+      const int i = e / M, j = e - i * M;
+      Cd s = cmake<double>(0.0, 0.0);
+      for (int k = 0; k < M; ++k) cfma(s, g[i * M + k], g[k * M + j]);
+      h[e] = s;
+    }
+    wave_sync_lds();
+    double t2p = 0.0;
+    for (int i = lane; i < M; i += WAVE) t2p += h[i * M + i].x;
+    const double t2 = wave_sum_d(t2p);
+    for (int e = lane; e < M * M; e += WAVE) h[e] = cscale(h[e], 1.0 / t2);
+    wave_sync_lds();
+    Cd* tmp = g;
+    g = h;
+    h = tmp;
+    if (1.0 - t2 < 1e-14) break;  // wave-uniform
+  }
+  double lp = 0.0;  // Rayleigh quotient tr(G0 Gk), tr(Gk) = 1
+  for (int e = lane; e < M * M; e += WAVE) {
+    const int i = e / M, j = e - i * M;
+    const Cd a = G0[e], bt = g[j * M + i];
+    lp += a.x * bt.x - a.y * bt.y;
+  }
+  return sqrt(wave_sum_d(lp) * tr);
+}
+
+// IP sweep (ilrma.py:512-530, iva.py:500-518) of one bin per wave, run-time M: the semantics of ip_group_kernel
+// (condition guard with the Frobenius bounds and the exact norms inside the factor-M band, singular / rejected flags,
+// den_floor, per-bin power statistic from the plain covariance C).
+template <typename R>
+__global__ void __launch_bounds__(64) ip_rt_kernel(const Cx<R>* __restrict__ U, Cx<R>* __restrict__ W,
+                                                  const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
+                                                  int32_t* __restrict__ status, int B, int F, double den_floor, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  const int MM = M * M, lane = threadIdx.x;
+  Cd* Wl = reinterpret_cast<Cd*>(smem_rt);
+  Cd* Ul = Wl + MM;
+  Cd* Al = Ul + MM;
+  Cd* Il = Al + MM;
+  Cd* G0 = Il + MM;
+  Cd* G1 = G0 + MM;
+  Cd* G2 = G1 + MM;
+  int* piv = reinterpret_cast<int*>(G2 + MM);
+  const int bf = blockIdx.x, b = bf / F, f = bf - b * F, N = M;
+  for (int e = lane; e < MM; e += WAVE) {
+    const Cx<R> v = W[(size_t)bf * MM + e];
+    Wl[e] = cmake<double>((double)v.x, (double)v.y);
+  }
+  int flags = 0;
+  for (int n = 0; n < N; ++n) {
+    for (int e = lane; e < MM; e += WAVE) {
+      const Cx<R> v = U[(((size_t)b * N + n) * F + f) * MM + e];
+      Ul[e] = cmake<double>((double)v.x, (double)v.y);
+    }
+    wave_sync_lds();
+    double nA2p = 0.0;
+    for (int e = lane; e < MM; e += WAVE) {  // A = W U_n
+      const int i = e / M, j = e - i * M;
+      Cd a = cmake<double>(0.0, 0.0);
+      for (int k = 0; k < M; ++k) cfma(a, Wl[i * M + k], Ul[k * M + j]);
+      Al[e] = a;
+      Il[e] = a;
+      nA2p += cabs2(a);
+    }
+    wave_sync_lds();
+    const bool nonsing = wave_gj_inverse(Il, piv, M, lane);
+    const bool singular = !nonsing;
+    double nI2p = 0.0;
+    for (int e = lane; e < MM; e += WAVE) nI2p += cabs2(Il[e]);
+    const double nA2 = wave_sum_d(nA2p), nI2 = wave_sum_d(nI2p);
+    // cond_2(A) < thr: Frobenius bounds, exact spectral norms only inside the factor-M band (group_cond_below)
+    double c2 = nA2 * nI2, thr2 = thr * thr, m2 = (double)M * (double)M;
+    if (!(c2 > 1e-290 && c2 < 1e290 && thr2 < 1e290)) {
+      c2 = sqrt(nA2) * sqrt(nI2);
+      thr2 = thr;
+      m2 = (double)M;
+    }
+    const bool amb = !singular && (c2 == c2) && c2 >= thr2 && c2 < thr2 * m2;
+    bool ok = !singular && (c2 == c2) && c2 < thr2;
+    if (amb) ok = wave_spectral_norm(Al, G0, G1, G2, M, lane) * wave_spectral_norm(Il, G0, G1, G2, M, lane) < thr;
+    if (singular) flags |= ASSX_STATUS_SINGULAR;
+    else if (!ok) flags |= ASSX_STATUS_COND_REJECT;
+    // w = (W U)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
+    double qx = 0.0, qy = 0.0;
+    for (int e = lane; e < MM; e += WAVE) {
+      const int i = e / M, j = e - i * M;
+      const Cd term = cmul(cmul(cconj(Il[i * M + n]), Ul[e]), Il[j * M + n]);
+      qx += term.x;
+      qy += term.y;
+    }
+    Cd den = csqrt_fast(cmake<double>(wave_sum_d(qx), wave_sum_d(qy)));
+    if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);
+    if (ok && !singular)
+      for (int j = lane; j < M; j += WAVE) Wl[n * M + j] = cdiv_fast(cconj(Il[j * M + n]), den);
+    wave_sync_lds();
+  }
+  for (int e = lane; e < MM; e += WAVE) W[(size_t)bf * MM + e] = cmake<R>((R)Wl[e].x, (R)Wl[e].y);
+  if (pw) {  // per-bin share of mean|y_n|^2 = mean_f w_n^H C_f w_n
+    for (int e = lane; e < MM; e += WAVE) {
+      const Cx<R> v = C[(size_t)bf * MM + e];
+      Ul[e] = cmake<double>((double)v.x, (double)v.y);
+    }
+    wave_sync_lds();
+    for (int n = 0; n < N; ++n) {
+      double s = 0.0;
+      for (int e = lane; e < MM; e += WAVE) {
+        const int i = e / M, j = e - i * M;
+        const Cd t1 = cmul(Wl[n * M + i], Ul[e]);
+        s += t1.x * Wl[n * M + j].x + t1.y * Wl[n * M + j].y;  // Re(W[n,i] C[i,j] conj(W[n,j]))
+      }
+      s = wave_sum_d(s);
+      if (lane == 0) pw[((size_t)b * N + n) * F + f] = s;
+    }
+  }
+  if (flags && status && lane == 0) atomicOr(&status[b], flags);
+}
+inline size_t ip_rt_lds_bytes(int M) { return (size_t)7 * M * M * sizeof(Cd) + (size_t)M * sizeof(int); }
+
+// -2 T log|det W_f| per bin (the loss's last term), run-time M: LU with partial pivoting by one wave in LDS
+template <typename R>
+__global__ void __launch_bounds__(64) logdet_rt_kernel(const Cx<R>* __restrict__ W, double* __restrict__ lpart, int B, int F,
+                                                      int T, int lstride, int offset, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  Cd* A = reinterpret_cast<Cd*>(smem_rt);
+  const int bf = blockIdx.x, b = bf / F, f = bf - b * F, lane = threadIdx.x, MM = M * M;
+  for (int e = lane; e < MM; e += WAVE) {
+    const Cx<R> v = W[(size_t)bf * MM + e];
+    A[e] = cmake<double>((double)v.x, (double)v.y);
+  }
+  wave_sync_lds();
+  double logabs = 0.0;
+  for (int c = 0; c < M; ++c) {
+    double best = -1.0;
+    int p = c;
+    for (int r = c + lane; r < M; r += WAVE) {
+      const double v = cabs1(A[r * M + c]);
+      if (v > best) {
+        best = v;
+        p = r;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double ob = __shfl_xor(best, off, WAVE);
+      const int op = __shfl_xor(p, off, WAVE);
+      if (ob > best || (ob == best && op < p)) {
+        best = ob;
+        p = op;
+      }
+    }
+    if (p != c)
+      for (int j = lane; j < M; j += WAVE) cswap(A[c * M + j], A[p * M + j]);
+    wave_sync_lds();
+    const Cd pv = A[c * M + c];
+    logabs += 0.5 * log(cabs2(pv));  // log 0 = -inf for a singular bin, as numpy.linalg.det -> log gives
+    for (int e = lane; e < (M - c - 1) * (M - c - 1); e += WAVE) {
+      const int r = c + 1 + e / (M - c - 1), j = c + 1 + e % (M - c - 1);
+      const Cd fct = cdiv(A[r * M + c], pv);
+      const Cd a = A[c * M + j];
+      Cd v = A[r * M + j];
+      v.x = v.x - (fct.x * a.x - fct.y * a.y);
+      v.y = v.y - (fct.x * a.y + fct.y * a.x);
+      A[r * M + j] = v;
+    }
+    wave_sync_lds();
+  }
+  if (lane == 0) lpart[(size_t)b * lstride + offset + f] = -2.0 * (double)T * logabs;
+}
+
+}  // namespace widem
+}  // namespace assx

@@ -24,10 +24,12 @@
  *         U  (B, N, F, M, M) complex   weighted spatial covariance  ilrma.py:511
  *         Y  (B, N, F, T) complex      separated estimate           ilrma.py:153-165
  *     complex = interleaved (re, im) of the real type selected by `dtype`.
- *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 8 -- M <= 4 on the streaming
- *     kernels (every entry point), 5 <= M <= 8 on the wide-channel path (csrc/assx_widem.hpp: materialised |W x|^2 /
- *     variance maps, one workgroup per bin; every Gauss-ILRMA / AuxIVA / t-ILRMA / projection-back entry point, IP,
- *     ISS and IP2, the partitioning function with n_basis <= 64).  One utterance must stay below
+ *     The reference is determined: N == M (ilrma.py:61-62).  Supported: 2 <= M <= 32 -- M <= 4 on the streaming
+ *     kernels (every entry point), 5 <= M <= 8 on the wide-channel path (csrc/assx_widem.hpp: |W x|^2 map for the
+ *     source model, streaming covariance; every Gauss-ILRMA / AuxIVA / t-ILRMA / projection-back entry point, IP,
+ *     ISS and IP2, the partitioning function with n_basis <= 64), 9 <= M <= 32 on the same path with a run-time
+ *     channel count (csrc/assx_widem_rt.hpp: functional, not tuned; the IP sweep only -- ISS, IP2 and the
+ *     partitioning function return ASSX_E_UNSUPPORTED there).  One utterance must stay below
  *     4 GiB in complex128 (M*F*T < 2^28: in-kernel buffer offsets are 32-bit), any number of utterances.
  *   - dtype: ASSX_F32 (float / complex64) or ASSX_F64 (double / complex128 = the reference's).
  *   - `ws` is caller-owned device scratch of at least assx_workspace_bytes() bytes.
@@ -272,7 +274,7 @@ int assx_projection_back(assx_ctx* ctx, const void* Y, const void* reference, vo
 /* ILRMAbase.compute_demix_filter / IVAbase.compute_demix_filter (src/bss/ilrma.py:167-173, src/bss/iva.py:119-125):
  * W[b,f] = (Y X^H)(X X^H)^{-1} per bin, Y (B,M,F,T) an estimate, X (B,M,F,T) the mixture, W (B,F,M,M).  This is how
  * the reference rebuilds `demix_filter` from `estimation` for callbacks / the loss / the output of its ISS loop.
- * 2 <= M <= 8.  An exactly singular X X^H sets ASSX_STATUS_SINGULAR (numpy.linalg.inv would raise LinAlgError). */
+ * 2 <= M <= 32.  An exactly singular X X^H sets ASSX_STATUS_SINGULAR (numpy.linalg.inv would raise LinAlgError). */
 int assx_compute_demix_filter(assx_ctx* ctx, const void* Y, const void* X, void* W, int32_t* status,
                               int B, int M, int F, int T, int dtype, void* stream);
 

@@ -628,7 +628,8 @@ def gen_wide_m():
     F, T = 13, 256  # enough frames for well-conditioned 8 x 8 covariances: rounding is not amplified beyond the
     WIDE_ITERS = (1, 2, 5, 10)  # M <= 4 fixtures' tolerances
     seed = 1300
-    for M, K, normalize, domain in [(5, 3, "power", 2), (6, 10, "projection-back", 1), (8, 4, "power", 2)]:
+    for M, K, normalize, domain in [(5, 3, "power", 2), (6, 10, "projection-back", 1), (8, 4, "power", 2),
+                                    (9, 3, "power", 2)]:  # M = 9: beyond the compile-time channel counts (round 3)
         seed += 1
         X = convolutive_mixture(M, F, T, seed=seed)
         np.random.seed(seed)
