@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include "assx_common.hpp"
 #include "assx_nmf_mfma.hpp"
+#include "assx_nmf_small.hpp"
 
 #include "assx_nmf_internal.hpp"
 
@@ -342,6 +343,23 @@ inline void mfma_act_split(int group, int F, int T, int* FS, int* fchunk) {
   *FS = (F + chunk - 1) / chunk;
 }
 
+// slab counts of the small-rank kernels (assx_nmf_small.hpp): one resident round of workgroups / ~4096 waves for ONE
+// problem group; a function of one problem's geometry and the group size only
+inline void small_splits(int group, int F, int T, int* TS, int* tchunk, int* FS, int* fchunk) {
+  const int fw = (F + 4 * SMALL_BPW - 1) / (4 * SMALL_BPW);  // workgroups per problem and slab (4 waves x SMALL_BPW bins)
+  int ts = (1024 + fw * group - 1) / (fw * group);  // ~4096 waves: memory-level parallelism comes from occupancy here
+  if (ts > T / 256) ts = T / 256;
+  if (ts < 1) ts = 1;
+  *tchunk = ((T + ts - 1) / ts + WAVE - 1) / WAVE * WAVE;
+  *TS = (T + *tchunk - 1) / *tchunk;
+  const int tbk = (T + WAVE - 1) / WAVE;
+  int fs = (4096 + tbk * group - 1) / (tbk * group);
+  if (fs > F / 16) fs = F / 16;
+  if (fs < 1) fs = 1;
+  *fchunk = ((F + fs - 1) / fs + 3) / 4 * 4;
+  *FS = (F + *fchunk - 1) / *fchunk;
+}
+
 inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   NmfWs w;
@@ -360,6 +378,11 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
     mfma_act_split(1, F, T, &FS, &fchunk);
     if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
     if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
+    if (K <= SMALL_K) {  // group = 1 gives the most slabs
+      small_splits(1, F, T, &TS, &tchunk, &FS, &fchunk);
+      if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
+      if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
+    }
   }
   off += align_up(pmax * r, 256);
   w.lpart = off;
@@ -413,10 +436,40 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   return 0;
 }
 
+// n_basis <= 4, IS rule, domain 2: the vector-ALU kernels of assx_nmf_small.hpp (the matrix-core kernels pad the rank to
+// 16).  Slab counts: one resident round of workgroups for ONE problem group, never more slabs than the matrix-core
+// path would use (the scratch is sized for those).
+template <typename R>
+int nmf_update_small(assx_ctx* ctx, double eps, const void* X, void* Tb, void* V, void* ws, int B, int F, int T, int K,
+                     int dtype, hipStream_t st) {
+  const NmfWs L = nmf_ws(B, F, T, K, dtype);
+  R* part = (R*)((char*)ws + L.part);
+  const PowSpec pe = update_exponent(ASSX_NMF_IS_MM, 2.0);
+  int TS, tchunk, FS, fchunk;
+  small_splits(nmf_group(ctx), F, T, &TS, &tchunk, &FS, &fchunk);
+  const int fw = (F + 4 * SMALL_BPW - 1) / (4 * SMALL_BPW), tbk = (T + WAVE - 1) / WAVE;
+  hipLaunchKernelGGL((nmf_basis_small_kernel<R>), dim3(fw, TS, B), dim3(256), 0, st, (const R*)X, (const R*)Tb, (const R*)V,
+                     part, B, F, T, K, tchunk, (R)eps);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_basis_small_kernel");
+  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 64)), dim3(256), 0, st, (const R*)part,
+                     (R*)Tb, B, (size_t)F * K, TS, (R)eps, pe);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
+  hipLaunchKernelGGL((nmf_act_small_kernel<R>), dim3(tbk, FS, B), dim3(64), 0, st, (const R*)X, (const R*)Tb, (const R*)V,
+                     part, B, F, T, K, fchunk, (R)eps);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_act_small_kernel");
+  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 64)), dim3(256), 0, st, (const R*)part,
+                     (R*)V, B, (size_t)K * T, FS, (R)eps, pe);
+  ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
+  return 0;
+}
+
 template <typename R>
 int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st) {
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
+  static const int small_rank = getenv("ASSX_NMF_SMALL") ? atoi(getenv("ASSX_NMF_SMALL")) : 1;
+  if (K <= SMALL_K && kind == ASSX_NMF_IS_MM && domain == 2.0 && small_rank && !no_mfma)
+    return nmf_update_small<R>(ctx, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
   if (K <= NMF_MFMA_MAX_K && !no_mfma) {
     switch ((K + 15) / 16) {
       case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
@@ -531,6 +584,32 @@ int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, doub
   const TermSpec ts = make_terms(kind, domain, param);
   void* p = (char*)ws + L.part;
   *part = p;
+  static const int small_rank = getenv("ASSX_NMF_SMALL") ? atoi(getenv("ASSX_NMF_SMALL")) : 1;
+  if (K <= SMALL_K && kind == ASSX_NMF_IS_MM && domain == 2.0 && small_rank && (dtype == ASSX_F64 || dtype == ASSX_F32)) {
+    // n_basis <= 4: the vector-ALU halves (assx_nmf_small.hpp), same record layout
+    int TS, tchunk, FS, fchunk;
+    small_splits(nmf_group(ctx), F, T, &TS, &tchunk, &FS, &fchunk);
+    const int fw = (F + 4 * SMALL_BPW - 1) / (4 * SMALL_BPW), tbk = (T + WAVE - 1) / WAVE;
+    if (half == NMF_HALF_BASIS) {
+      if (dtype == ASSX_F64)
+        hipLaunchKernelGGL((nmf_basis_small_kernel<double>), dim3(fw, TS, B), dim3(256), 0, st, (const double*)X,
+                           (const double*)Tb, (const double*)V, (double*)p, B, F, T, K, tchunk, eps);
+      else
+        hipLaunchKernelGGL((nmf_basis_small_kernel<float>), dim3(fw, TS, B), dim3(256), 0, st, (const float*)X,
+                           (const float*)Tb, (const float*)V, (float*)p, B, F, T, K, tchunk, (float)eps);
+      *slabs = TS;
+    } else {
+      if (dtype == ASSX_F64)
+        hipLaunchKernelGGL((nmf_act_small_kernel<double>), dim3(tbk, FS, B), dim3(64), 0, st, (const double*)X,
+                           (const double*)Tb, (const double*)V, (double*)p, B, F, T, K, fchunk, eps);
+      else
+        hipLaunchKernelGGL((nmf_act_small_kernel<float>), dim3(tbk, FS, B), dim3(64), 0, st, (const float*)X,
+                           (const float*)Tb, (const float*)V, (float*)p, B, F, T, K, fchunk, (float)eps);
+      *slabs = FS;
+    }
+    ASSX_LAUNCH_CHECK(ctx, "nmf small-rank half kernel");
+    return 0;
+  }
 #define HALF_BY_K(RT)                                                                                              \
   switch ((K + 15) / 16) {                                                                                         \
     case 1: return nmf_half_launch<RT, 1>(ctx, ts, half, X, Tb, V, (RT*)p, B, F, T, K, eps, st, slabs);            \
