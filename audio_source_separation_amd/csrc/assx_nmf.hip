@@ -345,8 +345,8 @@ inline void mfma_act_split(int group, int F, int T, int* FS, int* fchunk) {
 
 // slab counts of the small-rank kernels (assx_nmf_small.hpp): one resident round of workgroups / ~4096 waves for ONE
 // problem group; a function of one problem's geometry and the group size only
-inline void small_splits(int group, int F, int T, int* TS, int* tchunk, int* FS, int* fchunk) {
-  const int fw = (F + 4 * SMALL_BPW - 1) / (4 * SMALL_BPW);  // workgroups per problem and slab (4 waves x SMALL_BPW bins)
+inline void small_splits(int group, int KC, int F, int T, int* TS, int* tchunk, int* FS, int* fchunk) {
+  const int fw = (F + 4 * small_bpw(KC) - 1) / (4 * small_bpw(KC));  // workgroups per problem and slab (4 waves x bins per wave)
   int ts = (1024 + fw * group - 1) / (fw * group);  // ~4096 waves: memory-level parallelism comes from occupancy here
   if (ts > T / 256) ts = T / 256;
   if (ts < 1) ts = 1;
@@ -378,8 +378,8 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
     mfma_act_split(1, F, T, &FS, &fchunk);
     if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
     if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
-    if (K <= SMALL_K) {  // group = 1 gives the most slabs
-      small_splits(1, F, T, &TS, &tchunk, &FS, &fchunk);
+    if (K <= SMALL_K) {  // small-rank kernels; group = 1 gives the most slabs
+      small_splits(1, small_kc(K), F, T, &TS, &tchunk, &FS, &fchunk);
       if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
       if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
     }
@@ -439,36 +439,46 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
 // n_basis <= 4, IS rule, domain 2: the vector-ALU kernels of assx_nmf_small.hpp (the matrix-core kernels pad the rank to
 // 16).  Slab counts: one resident round of workgroups for ONE problem group, never more slabs than the matrix-core
 // path would use (the scratch is sized for those).
-template <typename R>
-int nmf_update_small(assx_ctx* ctx, double eps, const void* X, void* Tb, void* V, void* ws, int B, int F, int T, int K,
-                     int dtype, hipStream_t st) {
+template <typename R, int KC>
+int nmf_update_small_kc(assx_ctx* ctx, double eps, const void* X, void* Tb, void* V, void* ws, int B, int F, int T, int K,
+                        int dtype, hipStream_t st) {
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   R* part = (R*)((char*)ws + L.part);
   const PowSpec pe = update_exponent(ASSX_NMF_IS_MM, 2.0);
   int TS, tchunk, FS, fchunk;
-  small_splits(nmf_group(ctx), F, T, &TS, &tchunk, &FS, &fchunk);
-  const int fw = (F + 4 * SMALL_BPW - 1) / (4 * SMALL_BPW), tbk = (T + WAVE - 1) / WAVE;
-  hipLaunchKernelGGL((nmf_basis_small_kernel<R>), dim3(fw, TS, B), dim3(256), 0, st, (const R*)X, (const R*)Tb, (const R*)V,
-                     part, B, F, T, K, tchunk, (R)eps);
+  small_splits(nmf_group(ctx), KC, F, T, &TS, &tchunk, &FS, &fchunk);
+  const int fw = (F + 4 * small_bpw(KC) - 1) / (4 * small_bpw(KC)), tbk = (T + WAVE - 1) / WAVE;
+  hipLaunchKernelGGL((nmf_basis_small_kernel<R, KC>), dim3(fw, TS, B), dim3(256), 0, st, (const R*)X, (const R*)Tb,
+                     (const R*)V, part, B, F, T, K, tchunk, (R)eps);
   ASSX_LAUNCH_CHECK(ctx, "nmf_basis_small_kernel");
   hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 64)), dim3(256), 0, st, (const R*)part,
                      (R*)Tb, B, (size_t)F * K, TS, (R)eps, pe);
   ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
-  hipLaunchKernelGGL((nmf_act_small_kernel<R>), dim3(tbk, FS, B), dim3(64), 0, st, (const R*)X, (const R*)Tb, (const R*)V,
-                     part, B, F, T, K, fchunk, (R)eps);
+  hipLaunchKernelGGL((nmf_act_small_kernel<R, KC>), dim3(tbk, FS, B), dim3(64), 0, st, (const R*)X, (const R*)Tb,
+                     (const R*)V, part, B, F, T, K, fchunk, (R)eps);
   ASSX_LAUNCH_CHECK(ctx, "nmf_act_small_kernel");
   hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 64)), dim3(256), 0, st, (const R*)part,
                      (R*)V, B, (size_t)K * T, FS, (R)eps, pe);
   ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
   return 0;
 }
+// n_basis <= 4 (ASSX_NMF_SMALL=0: never), IS rule, domain 2: the vector-ALU kernels of assx_nmf_small.hpp (the
+// matrix-core kernels pad the rank to a multiple of 16)
+template <typename R>
+int nmf_update_small(assx_ctx* ctx, double eps, const void* X, void* Tb, void* V, void* ws, int B, int F, int T, int K,
+                     int dtype, hipStream_t st) {
+  return nmf_update_small_kc<R, 4>(ctx, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+}
+inline int small_rank_max() {  // largest n_basis routed to the vector-ALU kernels (0 = never)
+  static const int v = getenv("ASSX_NMF_SMALL") ? atoi(getenv("ASSX_NMF_SMALL")) : 4;
+  return v > SMALL_K ? SMALL_K : v;
+}
 
 template <typename R>
 int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st) {
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
-  static const int small_rank = getenv("ASSX_NMF_SMALL") ? atoi(getenv("ASSX_NMF_SMALL")) : 1;
-  if (K <= SMALL_K && kind == ASSX_NMF_IS_MM && domain == 2.0 && small_rank && !no_mfma)
+  if (K <= small_rank_max() && kind == ASSX_NMF_IS_MM && domain == 2.0 && !no_mfma)
     return nmf_update_small<R>(ctx, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
   if (K <= NMF_MFMA_MAX_K && !no_mfma) {
     switch ((K + 15) / 16) {
@@ -584,29 +594,28 @@ int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, doub
   const TermSpec ts = make_terms(kind, domain, param);
   void* p = (char*)ws + L.part;
   *part = p;
-  static const int small_rank = getenv("ASSX_NMF_SMALL") ? atoi(getenv("ASSX_NMF_SMALL")) : 1;
-  if (K <= SMALL_K && kind == ASSX_NMF_IS_MM && domain == 2.0 && small_rank && (dtype == ASSX_F64 || dtype == ASSX_F32)) {
-    // n_basis <= 4: the vector-ALU halves (assx_nmf_small.hpp), same record layout
+  if (K <= small_rank_max() && kind == ASSX_NMF_IS_MM && domain == 2.0 && (dtype == ASSX_F64 || dtype == ASSX_F32)) {
+    // small n_basis: the vector-ALU halves (assx_nmf_small.hpp), same record layout
+    const int kc = small_kc(K);
     int TS, tchunk, FS, fchunk;
-    small_splits(nmf_group(ctx), F, T, &TS, &tchunk, &FS, &fchunk);
-    const int fw = (F + 4 * SMALL_BPW - 1) / (4 * SMALL_BPW), tbk = (T + WAVE - 1) / WAVE;
-    if (half == NMF_HALF_BASIS) {
-      if (dtype == ASSX_F64)
-        hipLaunchKernelGGL((nmf_basis_small_kernel<double>), dim3(fw, TS, B), dim3(256), 0, st, (const double*)X,
-                           (const double*)Tb, (const double*)V, (double*)p, B, F, T, K, tchunk, eps);
-      else
-        hipLaunchKernelGGL((nmf_basis_small_kernel<float>), dim3(fw, TS, B), dim3(256), 0, st, (const float*)X,
-                           (const float*)Tb, (const float*)V, (float*)p, B, F, T, K, tchunk, (float)eps);
-      *slabs = TS;
+    small_splits(nmf_group(ctx), kc, F, T, &TS, &tchunk, &FS, &fchunk);
+    const int fw = (F + 4 * small_bpw(kc) - 1) / (4 * small_bpw(kc)), tbk = (T + WAVE - 1) / WAVE;
+#define SMALL_HALF(RT, KCV)                                                                                          \
+  if (half == NMF_HALF_BASIS)                                                                                        \
+    hipLaunchKernelGGL((nmf_basis_small_kernel<RT, KCV>), dim3(fw, TS, B), dim3(256), 0, st, (const RT*)X,            \
+                       (const RT*)Tb, (const RT*)V, (RT*)p, B, F, T, K, tchunk, (RT)eps);                            \
+  else                                                                                                               \
+    hipLaunchKernelGGL((nmf_act_small_kernel<RT, KCV>), dim3(tbk, FS, B), dim3(64), 0, st, (const RT*)X,              \
+                       (const RT*)Tb, (const RT*)V, (RT*)p, B, F, T, K, fchunk, (RT)eps)
+#define SMALL_HALF_BY_KC(RT) SMALL_HALF(RT, 4);
+    if (dtype == ASSX_F64) {
+      SMALL_HALF_BY_KC(double)
     } else {
-      if (dtype == ASSX_F64)
-        hipLaunchKernelGGL((nmf_act_small_kernel<double>), dim3(tbk, FS, B), dim3(64), 0, st, (const double*)X,
-                           (const double*)Tb, (const double*)V, (double*)p, B, F, T, K, fchunk, eps);
-      else
-        hipLaunchKernelGGL((nmf_act_small_kernel<float>), dim3(tbk, FS, B), dim3(64), 0, st, (const float*)X,
-                           (const float*)Tb, (const float*)V, (float*)p, B, F, T, K, fchunk, (float)eps);
-      *slabs = FS;
+      SMALL_HALF_BY_KC(float)
     }
+#undef SMALL_HALF_BY_KC
+#undef SMALL_HALF
+    *slabs = half == NMF_HALF_BASIS ? TS : FS;
     ASSX_LAUNCH_CHECK(ctx, "nmf small-rank half kernel");
     return 0;
   }

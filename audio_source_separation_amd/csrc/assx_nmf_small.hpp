@@ -17,111 +17,116 @@
 
 namespace assx {
 
-constexpr int SMALL_K = 4;    // largest n_basis served
-constexpr int SMALL_BPW = 4;  // bins per wave in the basis half
+constexpr int SMALL_K = 4;    // largest n_basis served.  The kernels are written for KC = 4, 8, 12 or 16 rows per lane and
+                              // were measured at all of them (profiles/r03_nmf_small_rank.txt): beyond 4 the matrix cores win
+                              // (n_basis 6: 192-194 us per ILRMA source update against 187; n_basis 10: 229 against 196;
+                              // n_basis 16: 271 against 208), so only KC = 4 is instantiated
+constexpr int small_bpw(int KC) { return KC <= 4 ? 4 : 2; }  // bins per wave in the basis half (their rows live in SGPRs)
+constexpr int small_uf(int KC) { return KC <= 4 ? 4 : 2; }   // bins in flight in the activation half
+inline int small_kc(int K) { return 4; }
 
-template <typename R>
+template <typename R, int KC>
 __global__ void __launch_bounds__(256)
     nmf_basis_small_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
                            int B, int F, int T, int K, int tchunk, R eps) {
-  constexpr int NB = SMALL_BPW, NACC = 2 * NB * SMALL_K;  // 32
+  constexpr int NB = small_bpw(KC), NACC = 2 * NB * KC, NV = next_pow2_c(NACC);  // 32 sums at KC = 4, 64 at KC = 16
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int b = blockIdx.z, ts = blockIdx.y;
   const int f0 = (blockIdx.x * 4 + wv) * NB;
   if (f0 >= F) return;  // no workgroup barriers in this kernel
   const int ta = ts * tchunk, te = min(T, ta + tchunk);
-  R tb[NB][SMALL_K];  // wave-uniform basis rows (0 beyond n_basis / beyond the last bin)
+  R tb[NB][KC];  // wave-uniform basis rows (0 beyond n_basis / beyond the last bin)
 #pragma unroll
   for (int i = 0; i < NB; ++i)
 #pragma unroll
-    for (int k = 0; k < SMALL_K; ++k)
+    for (int k = 0; k < KC; ++k)
       tb[i][k] = (f0 + i < F && k < K) ? Tb[((size_t)b * F + f0 + i) * K + k] : (R)0;
   const R* xrow[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) xrow[i] = X + ((size_t)b * F + min(f0 + i, F - 1)) * T;
   const R* vb = V + (size_t)b * K * T;
-  R acc[NACC];
+  R acc[NV];
 #pragma unroll
-  for (int q = 0; q < NACC; ++q) acc[q] = 0;
-  R xn[NB], vn[SMALL_K];
+  for (int q = 0; q < NV; ++q) acc[q] = 0;
+  R xn[NB], vn[KC];
   auto fetch = [&](int t0) {
     const int t = min(t0 + lane, T - 1);
 #pragma unroll
     for (int i = 0; i < NB; ++i) xn[i] = xrow[i][t];
 #pragma unroll
-    for (int k = 0; k < SMALL_K; ++k) vn[k] = vb[(size_t)min(k, K - 1) * T + t];  // rows past n_basis: their basis is 0
+    for (int k = 0; k < KC; ++k) vn[k] = vb[(size_t)min(k, K - 1) * T + t];  // rows past n_basis: their basis is 0
   };
   if (ta < te) fetch(ta);
   for (int t0 = ta; t0 < te; t0 += WAVE) {
-    R x[NB], v[SMALL_K];
+    R x[NB], v[KC];
 #pragma unroll
     for (int i = 0; i < NB; ++i) x[i] = xn[i];
 #pragma unroll
-    for (int k = 0; k < SMALL_K; ++k) v[k] = vn[k];
+    for (int k = 0; k < KC; ++k) v[k] = vn[k];
     if (t0 + WAVE < te) fetch(t0 + WAVE);  // the next block travels while this one is consumed
     const bool live = t0 + lane < te;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       R tv = 0;
 #pragma unroll
-      for (int k = 0; k < SMALL_K; ++k) tv = fma(tb[i][k], v[k], tv);
+      for (int k = 0; k < KC; ++k) tv = fma(tb[i][k], v[k], tv);
       const R bm = live ? fast_rcp(floor_eps<R>(tv, eps)) : (R)0;
       const R a = x[i] * bm * bm;
 #pragma unroll
-      for (int k = 0; k < SMALL_K; ++k) {
-        acc[(i * 2 + 0) * SMALL_K + k] = fma(a, v[k], acc[(i * 2 + 0) * SMALL_K + k]);
-        acc[(i * 2 + 1) * SMALL_K + k] = fma(bm, v[k], acc[(i * 2 + 1) * SMALL_K + k]);
+      for (int k = 0; k < KC; ++k) {
+        acc[(i * 2 + 0) * KC + k] = fma(a, v[k], acc[(i * 2 + 0) * KC + k]);
+        acc[(i * 2 + 1) * KC + k] = fma(bm, v[k], acc[(i * 2 + 1) * KC + k]);
       }
     }
   }
-  const R tot = wave_reduce_scatter<R, NACC>(acc);
-  const int q = scatter_index<NACC>();
-  if (scatter_leader<NACC>()) {
-    const int i = q / (2 * SMALL_K), s = (q / SMALL_K) & 1, k = q % SMALL_K;
+  const R tot = wave_reduce_scatter<R, NV>(acc);
+  const int q = scatter_index<NV>();
+  if (scatter_leader<NV>() && q < NACC) {
+    const int i = q / (2 * KC), s = (q / KC) & 1, k = q % KC;
     const size_t FK = (size_t)F * K;
     if (f0 + i < F && k < K) part[((size_t)ts * B * 2 + (size_t)b * 2 + s) * FK + (size_t)(f0 + i) * K + k] = tot;
   }
 }
 
-template <typename R>
+template <typename R, int KC>
 __global__ void __launch_bounds__(64)
     nmf_act_small_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
                          int B, int F, int T, int K, int fchunk, R eps) {
-  constexpr int UF = 4;  // bins in flight
+  constexpr int UF = small_uf(KC);  // bins in flight
   const int lane = threadIdx.x;
   const int b = blockIdx.z, fs = blockIdx.y;
   const int t = blockIdx.x * WAVE + lane;
   const bool live = t < T;
   const int tc = live ? t : T - 1;
-  R v[SMALL_K];
+  R v[KC];
 #pragma unroll
-  for (int k = 0; k < SMALL_K; ++k) v[k] = V[((size_t)b * K + min(k, K - 1)) * T + tc];
-  R num[SMALL_K], den[SMALL_K];
+  for (int k = 0; k < KC; ++k) v[k] = V[((size_t)b * K + min(k, K - 1)) * T + tc];
+  R num[KC], den[KC];
 #pragma unroll
-  for (int k = 0; k < SMALL_K; ++k) num[k] = den[k] = 0;
+  for (int k = 0; k < KC; ++k) num[k] = den[k] = 0;
   const int fa = fs * fchunk, fe = min(F, fa + fchunk);
   const R* xb = X + (size_t)b * F * T + tc;
   const R* tbb = Tb + (size_t)b * F * K;
   for (int f0 = fa; f0 < fe; f0 += UF) {
-    R x[UF], tk[UF][SMALL_K];
+    R x[UF], tk[UF][KC];
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       const int f = min(f0 + u, F - 1);
       x[u] = xb[(size_t)f * T];
 #pragma unroll
-      for (int k = 0; k < SMALL_K; ++k)  // wave-uniform addresses: scalar loads
+      for (int k = 0; k < KC; ++k)  // wave-uniform addresses: scalar loads
         tk[u][k] = (f0 + u < fe && k < K) ? tbb[(size_t)f * K + k] : (R)0;  // bins past the range contribute 0
     }
 #pragma unroll
     for (int u = 0; u < UF; ++u) {
       R tv = 0;
 #pragma unroll
-      for (int k = 0; k < SMALL_K; ++k) tv = fma(tk[u][k], v[k], tv);
+      for (int k = 0; k < KC; ++k) tv = fma(tk[u][k], v[k], tv);
       const R bm = fast_rcp(floor_eps<R>(tv, eps));
       const R a = x[u] * bm * bm;
 #pragma unroll
-      for (int k = 0; k < SMALL_K; ++k) {
+      for (int k = 0; k < KC; ++k) {
         num[k] = fma(tk[u][k], a, num[k]);
         den[k] = fma(tk[u][k], bm, den[k]);
       }
@@ -131,7 +136,7 @@ __global__ void __launch_bounds__(64)
     const size_t KTt = (size_t)K * T;
     R* pn = part + ((size_t)fs * B * 2 + (size_t)b * 2) * KTt;
 #pragma unroll
-    for (int k = 0; k < SMALL_K; ++k)
+    for (int k = 0; k < KC; ++k)
       if (k < K) {
         pn[(size_t)k * T + t] = num[k];
         pn[KTt + (size_t)k * T + t] = den[k];
