@@ -334,10 +334,16 @@ static int dispatch(assx_ctx* ctx, int dtype, int M, Fn&& fn) {
 template <typename R, int M>
 static int launch_demix(assx_ctx* ctx, int Mr, const void* X, const void* W, const void* scale, void* Y, void* P, int B,
                         int F, int T, hipStream_t st) {
-  if constexpr (M == 0)  // run-time channel count (Mr > 8)
-    hipLaunchKernelGGL((demix_map_rt_kernel<R>), dim3(nblk(T, 256), F, B), dim3(256), (size_t)Mr * Mr * sizeof(Cx<R>), st,
-                       (const Cx<R>*)X, (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T, Mr);
-  else
+  if constexpr (M == 0) {  // run-time channel count (Mr > 8): x of a frame in registers, bound 12 / 16 / 24 / 32
+#define DEMIX_RT(MCV)                                                                                                   \
+  hipLaunchKernelGGL((demix_map_rt_kernel<R, MCV>), dim3(nblk(T, 256), F, B), dim3(256), (size_t)Mr * Mr * sizeof(Cx<R>), \
+                     st, (const Cx<R>*)X, (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T, Mr)
+    if (Mr <= 12) DEMIX_RT(12);
+    else if (Mr <= 16) DEMIX_RT(16);
+    else if (Mr <= 24) DEMIX_RT(24);
+    else DEMIX_RT(32);
+#undef DEMIX_RT
+  } else
     hipLaunchKernelGGL((demix_map_kernel<R, M>), dim3(nblk(T, 256), F, B), dim3(256), 0, st, (const Cx<R>*)X,
                        (const Cx<R>*)W, (const Cx<R>*)scale, (Cx<R>*)Y, (R*)P, F, T);
   ASSX_LAUNCH_CHECK(ctx, "widem::demix_map_kernel");
@@ -347,12 +353,25 @@ static int launch_demix(assx_ctx* ctx, int Mr, const void* X, const void* W, con
 template <typename R, int M>
 static int launch_cov(assx_ctx* ctx, int Mr, const void* X, const void* r, int r_kind, int N, double eps, void* U, int B,
                       int F, int T, hipStream_t st) {
-  if constexpr (M == 0) {  // run-time channel count: one workgroup per (bin, source), a thread per pair (i <= j)
+  if constexpr (M == 0) {  // run-time channel count: one workgroup per bin (and 256 pairs), every source's sums per thread
     const int np = Mr * (Mr + 1) / 2;
     const int threads = np >= 256 ? 256 : (np + 63) / 64 * 64;
-    const size_t lds = (size_t)RT_TILE * Mr * sizeof(Cx<R>) + RT_TILE * sizeof(R);
-    hipLaunchKernelGGL((cov_rt_kernel<R>), dim3(F, N, B), dim3(threads), lds, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
-                       (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T), Mr);
+    // sources per workgroup: 4 up to 10 channels, 8 up to 14, 16 beyond (measured: profiles/r03_manychan_bench.txt;
+    // ASSX_RT_NS overrides for A/B runs)
+    static const int ns_env = env_int("ASSX_RT_NS", 0);
+    const int nsg = N <= 1 ? 1 : (ns_env > 0 ? ns_env : (Mr <= 10 ? 4 : (Mr <= 14 ? 8 : 16)));
+    const int ncv = nsg <= 1 ? 1 : (nsg <= 2 ? 2 : (nsg <= 4 ? 4 : (nsg <= 8 ? 8 : 16)));
+    const dim3 grid(F, ((np + threads - 1) / threads) * ((N + ncv - 1) / ncv), B);
+    const size_t lds = (size_t)RT_TILE * Mr * sizeof(Cx<R>) + (size_t)RT_TILE * ncv * sizeof(R);
+#define COV_RT(NCV)                                                                                                   \
+  hipLaunchKernelGGL((cov_rt_kernel<R, NCV>), grid, dim3(threads), lds, st, (const Cx<R>*)X, (const R*)r, r_kind, N,   \
+                     (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T), Mr)
+    if (ncv == 1) COV_RT(1);
+    else if (ncv == 2) COV_RT(2);
+    else if (ncv == 4) COV_RT(4);
+    else if (ncv == 8) COV_RT(8);
+    else COV_RT(16);
+#undef COV_RT
   } else
     hipLaunchKernelGGL((cov_bin_kernel<R, M>), dim3(F, B), dim3(64 * (N > 1 ? N : 4)), 0, st, (const Cx<R>*)X, (const R*)r, r_kind, N,
                        (R)eps, (Cx<R>*)U, F, T, (R)(1.0 / (double)T));

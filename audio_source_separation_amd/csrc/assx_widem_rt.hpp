@@ -15,7 +15,7 @@ namespace widem {
 // ------------------------------------------------------------------------------------------------------------------
 // y = W x per (f, t), run-time M; W_f in (dynamic) LDS.  Writes Y (optionally scaled) and / or |y|^2.
 // ------------------------------------------------------------------------------------------------------------------
-template <typename R>
+template <typename R, int MC>  // MC: compile-time bound of the channel count (x of a frame stays in registers)
 __global__ void __launch_bounds__(256) demix_map_rt_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
                                                           const Cx<R>* __restrict__ scale, Cx<R>* __restrict__ Y,
                                                           R* __restrict__ P, int F, int T, int M) {
@@ -27,9 +27,14 @@ __global__ void __launch_bounds__(256) demix_map_rt_kernel(const Cx<R>* __restri
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= T) return;
   const size_t FT = (size_t)F * T, base = (size_t)b * M * FT + (size_t)f * T + t;
+  Cx<R> x[MC];
+#pragma unroll
+  for (int m = 0; m < MC; ++m) x[m] = m < M ? X[base + (size_t)m * FT] : cmake<R>(0, 0);
   for (int n = 0; n < M; ++n) {
     Cx<R> s = cmake<R>(0, 0);
-    for (int m = 0; m < M; ++m) cfma(s, w[n * M + m], X[base + (size_t)m * FT]);  // x_m: an L1 hit after the first source
+#pragma unroll
+    for (int m = 0; m < MC; ++m)
+      if (m < M) cfma(s, w[n * M + m], x[m]);  // m ascending, as the compile-time kernel
     if (P) P[base + (size_t)n * FT] = cabs2(s);
     if (Y) {
       if (scale) s = cmul(s, scale[((size_t)b * M + n) * F + f]);
@@ -39,76 +44,86 @@ __global__ void __launch_bounds__(256) demix_map_rt_kernel(const Cx<R>* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Weighted covariance, one workgroup per (bin, source): a thread owns up to RT_PAIRS pairs (i <= j) of the Hermitian
-// matrix; frames arrive in tiles of RT_TILE, staged FRAME-MAJOR in LDS (at a given frame every thread reads two of the M
-// samples of one short row: broadcasts, no bank conflicts) together with the tile's reciprocal weights.
+// Weighted covariance of NC sources of a bin per workgroup: a thread owns ONE pair (i <= j) of the Hermitian matrix and
+// the sums of that pair for the workgroup's sources: per frame it forms x_i conj(x_j) once and fans it into the NC sums
+// with the frame's reciprocal weights.  Frames arrive in tiles of
+// RT_TILE, staged FRAME-MAJOR in LDS (at a given frame every thread reads two of the M samples of one short row:
+// broadcasts, no bank conflicts) next to the tile's weights [frame][source] (wave-uniform reads).  blockIdx.y = (source
+// group, chunk of 256 pairs).  NC trades re-staging the tile per source group against workgroups in flight and the
+// weight reads per frame (measured: profiles/r03_manychan_bench.txt).
 // U[b,n,f] = (1/T) sum_t x x^H / max(r_n, eps); r_kind as cov_bin_kernel (0 none, 1 (N,T), 2 (N,F,T)).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int RT_TILE = 64, RT_PAIRS = 3;  // M <= 32: 528 pairs over 256 threads
+constexpr int RT_TILE = 64;
 
-template <typename R>
+template <typename R, int NC>
 __global__ void __launch_bounds__(256) cov_rt_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ r, int r_kind,
                                                     int N, R eps, Cx<R>* __restrict__ U, int F, int T, R inv_T, int M) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
   Cx<R>* xt = reinterpret_cast<Cx<R>*>(smem_rt);            // [RT_TILE][M]
-  R* wt = reinterpret_cast<R*>(xt + (size_t)RT_TILE * M);   // [RT_TILE]
-  const int f = blockIdx.x, n = blockIdx.y, b = blockIdx.z;
+  R* wt = reinterpret_cast<R*>(xt + (size_t)RT_TILE * M);   // [RT_TILE][N]
+  const int f = blockIdx.x, b = blockIdx.z;
   const int NP = M * (M + 1) / 2;
+  const int pchunks = (NP + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int sg = (int)blockIdx.y / pchunks, pc = (int)blockIdx.y - sg * pchunks;  // source group, pair chunk
+  const int n0 = sg * NC, ns = min(NC, N - n0);                                   // this workgroup's sources n0 .. n0+ns-1
   const size_t FT = (size_t)F * T;
   const Cx<R>* xb = X + (size_t)b * M * FT + (size_t)f * T;
-  const R* rn = nullptr;
-  if (r_kind == 1) rn = r + ((size_t)b * N + n) * T;
-  else if (r_kind == 2) rn = r + ((size_t)b * N + n) * FT + (size_t)f * T;
-  int pi[RT_PAIRS], pj[RT_PAIRS];
-  R ar[RT_PAIRS], ai[RT_PAIRS];
-#pragma unroll
-  for (int q = 0; q < RT_PAIRS; ++q) {
-    int p = (int)threadIdx.x + q * (int)blockDim.x;
-    ar[q] = ai[q] = 0;
-    pi[q] = pj[q] = -1;
+  int pi = -1, pj = -1;
+  {
+    int p = pc * (int)blockDim.x + (int)threadIdx.x;
     if (p < NP) {  // p -> (i, j >= i), rows ascending
       int i = 0;
       while (p >= M - i) {
         p -= M - i;
         ++i;
       }
-      pi[q] = i;
-      pj[q] = i + p;
+      pi = i;
+      pj = i + p;
     }
   }
+  R ar[NC], ai[NC];
+#pragma unroll
+  for (int n = 0; n < NC; ++n) ar[n] = ai[n] = 0;
   for (int t0 = 0; t0 < T; t0 += RT_TILE) {
     __syncthreads();  // the previous tile is no longer read
     for (int e = threadIdx.x; e < M * RT_TILE; e += blockDim.x) {
       const int m = e / RT_TILE, tt = e - m * RT_TILE;  // consecutive threads: consecutive frames of one channel (coalesced)
       xt[(size_t)tt * M + m] = (t0 + tt < T) ? xb[(size_t)m * FT + t0 + tt] : cmake<R>(0, 0);
     }
-    if ((int)threadIdx.x < RT_TILE) {
-      const int t = t0 + (int)threadIdx.x;
+    for (int e = threadIdx.x; e < ns * RT_TILE; e += blockDim.x) {
+      const int q = e / RT_TILE, n = n0 + q, tt = e - q * RT_TILE, t = t0 + tt;
       R wv = 0;
-      if (t < T) wv = rn ? fast_rcp(floor_eps<R>(rn[t], eps)) : (R)1;
-      wt[threadIdx.x] = wv;
+      if (t < T) {
+        if (r_kind == 0) wv = (R)1;
+        else if (r_kind == 1) wv = fast_rcp(floor_eps<R>(r[((size_t)b * N + n) * T + t], eps));
+        else wv = fast_rcp(floor_eps<R>(r[((size_t)b * N + n) * FT + (size_t)f * T + t], eps));
+      }
+      wt[(size_t)tt * NC + q] = wv;
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < RT_PAIRS; ++q) {
-      if (pi[q] < 0) continue;
+    if (pi >= 0) {
       for (int tt = 0; tt < RT_TILE; ++tt) {  // frames in ascending order
-        const Cx<R> xi = xt[(size_t)tt * M + pi[q]], xj = xt[(size_t)tt * M + pj[q]];
-        const R sx = wt[tt] * xi.x, sy = wt[tt] * xi.y;
-        ar[q] = fma(sx, xj.x, ar[q]);
-        ar[q] = fma(sy, xj.y, ar[q]);
-        ai[q] = fma(sy, xj.x, ai[q]);
-        ai[q] = fma(-sx, xj.y, ai[q]);
+        const Cx<R> xi = xt[(size_t)tt * M + pi], xj = xt[(size_t)tt * M + pj];
+        const R pr = fma(xi.x, xj.x, xi.y * xj.y), pim = fma(xi.y, xj.x, -(xi.x * xj.y));  // x_i conj(x_j)
+        const R* wrow = wt + (size_t)tt * NC;
+#pragma unroll
+        for (int q = 0; q < NC; ++q)
+          if (q < ns) {
+            ar[q] = fma(wrow[q], pr, ar[q]);
+            ai[q] = fma(wrow[q], pim, ai[q]);
+          }
       }
     }
   }
-  Cx<R>* un = U + (((size_t)b * N + n) * F + f) * ((size_t)M * M);
+  if (pi >= 0) {
 #pragma unroll
-  for (int q = 0; q < RT_PAIRS; ++q) {
-    if (pi[q] < 0) continue;
-    const R re = ar[q] * inv_T, im = pi[q] == pj[q] ? (R)0 : ai[q] * inv_T;
-    un[pi[q] * M + pj[q]] = cmake<R>(re, im);
-    if (pi[q] != pj[q]) un[pj[q] * M + pi[q]] = cmake<R>(re, -im);
+    for (int q = 0; q < NC; ++q)
+      if (q < ns) {
+        Cx<R>* un = U + (((size_t)b * N + n0 + q) * F + f) * ((size_t)M * M);
+        const R re = ar[q] * inv_T, im = pi == pj ? (R)0 : ai[q] * inv_T;
+        un[pi * M + pj] = cmake<R>(re, im);
+        if (pi != pj) un[pj * M + pi] = cmake<R>(re, -im);
+      }
   }
 }
 
