@@ -386,12 +386,25 @@ template <typename R, int M, int WKV>
 static int launch_src_cov_as(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int K, double eps, void* rec,
                              const FlatPart& fp, int B, int F, int T, hipStream_t st) {
   using GEO = SrcCovGeom<R, M, WKV>;
-  if (GEO::lds_bytes > 64 * 1024) {  // > 64 KB of dynamic LDS needs the opt-in (per device: set on every launch)
+  static const int pairs = env_int("ASSX_WIDEM_PAIRS", 1);  // 0: one wave per source (src_cov_kernel), A/B runs
+  const Dims d{B, F, T, K};
+  if (pairs) {  // the Hermitian pairs split over the waves, weights exchanged through LDS
+    constexpr size_t lds = pair_cov_lds_bytes<R, M, WKV>();
+    if (lds > 64 * 1024) {  // > 64 KB of dynamic LDS needs the opt-in (per device: set on every launch)
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_cov_kernel<R, M, WKV>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(pair_cov_kernel)");
+    }
+    hipLaunchKernelGGL((pair_cov_kernel<R, M, WKV>), dim3(fp.G), dim3(WAVE * M), lds, st, (const Cx<R>*)X, (const R*)Tb,
+                       (const R*)V, (R*)rec, d, fp, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "widem::pair_cov_kernel");
+    return 0;
+  }
+  if (GEO::lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(src_cov_kernel<R, M, WKV>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::lds_bytes);
     if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(src_cov_kernel)");
   }
-  const Dims d{B, F, T, K};
   hipLaunchKernelGGL((src_cov_kernel<R, M, WKV>), dim3(fp.G), dim3(WAVE * M), GEO::lds_bytes, st, (const Cx<R>*)X,
                      (const R*)Tb, (const R*)V, (R*)rec, d, fp, (R)eps);
   ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_kernel");
@@ -878,3 +891,15 @@ int projection_back(assx_ctx* ctx, const void* Y, const void* reference, void* s
 
 }  // namespace widem
 }  // namespace assx
+
+#if PAIRCOV_TRACE
+// timing-experiment builds only (tools/probes/paircov_trace.py); not part of include/assx.h
+extern "C" int assx_debug_paircov_trace(unsigned long long* host, int clear) {
+  using assx::widem::g_paircov_trace;
+  if (clear) {
+    static unsigned long long zeros[1400];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_paircov_trace), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_paircov_trace), sizeof(unsigned long long) * 1400);
+}
+#endif

@@ -36,7 +36,7 @@ namespace widem {
 
 constexpr int SRC_COV_KMAX = 4;  // largest n_basis whose variance is rebuilt in the kernel
 
-template <typename R, int M, int WK>
+template <typename R, int M, int WK, int DX = 0>
 struct SrcCovGeom {
   static constexpr int RB = WAVE * 2 * (int)sizeof(R);     // bytes of one row of X: 64 complex frames
   static constexpr int LPR = RB / 16;                      // lanes that carry an X row (f64: 64, f32: the lower 32)
@@ -45,11 +45,18 @@ struct SrcCovGeom {
   static constexpr int VBYTES = VR * RBV;
   static constexpr int NVI = (VBYTES + 1023) / 1024;       // instructions that carry them (f64 ILRMA form: 2, else 1)
   static constexpr int VLANES = VBYTES >= 1024 ? WAVE : VBYTES / 16;  // active lanes of such an instruction
-  static constexpr int TBYTES = WK == WK_TV ? 4 * WAVE : 0;  // landing area of the basis row (one dword per lane)
+  static constexpr int TLANES = 8;                         // lanes that fetch the basis row: 32 bytes = n_basis <= 4 reals
+  static constexpr int TBYTES = WK == WK_TV ? 4 * TLANES : 0;  // its landing area (one dword per lane)
   static constexpr int C = 1 + NVI + (WK == WK_TV ? 1 : 0);  // VMEM instructions of one item's request, per wave
   static constexpr int WSLOT = VBYTES + TBYTES;            // wave-private bytes per slot
   static constexpr int SLOT = M * RB + M * WSLOT;          // bytes per ring slot
-  static constexpr int DXS = M <= 6 ? 4 : 5;               // slots (M = 8, f64, ILRMA form: 5 x 26 KB of the CU's 160 KB)
+#ifndef ASSX_COV_DXS
+#define ASSX_COV_DXS 0  // A/B builds: ring depth for M >= 7
+#endif
+  static constexpr int XBYTES = 2 * M * WAVE * (int)sizeof(R);  // pair_cov_kernel's weight exchange
+  static constexpr int FIT = (160 * 1024 - XBYTES) / SLOT;
+  static constexpr int DXS = DX ? DX : (M <= 6 ? 4 : (ASSX_COV_DXS ? ASSX_COV_DXS : (FIT < 6 ? FIT : 6)));  // slots (M = 8, f64, ILRMA form: 6 x 24.3 KB of the CU's 160 KB)
+  static_assert(DXS >= 3 && DXS <= FIT, "ring does not fit the CU's LDS");
   static constexpr size_t lds_bytes = (size_t)DXS * SLOT;
 };
 
@@ -141,7 +148,7 @@ __global__ void __launch_bounds__(WAVE * M)
     if (WK == WK_TV) {  // basis row: lane L's dword lands at +4L (only the first n_basis reals are used)
       const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((((size_t)n * F + c.f) * K) * sizeof(R)));
       const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + sbase + wpriv + GEO::VBYTES));
-      buf_dword_to_lds(dst, rt, (unsigned)lane * 4u, soff);
+      if (lane < GEO::TLANES) buf_dword_to_lds(dst, rt, (unsigned)lane * 4u, soff);
     }
     const size_t vrow = WK == WK_TV ? (size_t)n * K : (WK == WK_NT ? (size_t)n : (size_t)n * F + c.f);
     const unsigned vsoff = (unsigned)((vrow * T + (size_t)c.tb * WAVE) * sizeof(R));
@@ -284,6 +291,437 @@ __global__ void __launch_bounds__(WAVE * M)
     advance(c1, TBk, F);
     advance(cr, TBk, F);
   }
+  wait_vmcnt<0>();  // nothing may land in LDS after the workgroup has gone
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same pass with the PAIRS of the Hermitian matrix split over the waves instead of the sources (round 3, second
+// form).  src_cov_kernel's wave forms all M (M + 1) / 2 products of its source itself: 16 + 16 + 112 f64 instructions per
+// item at M = 8, i.e. every wave repeats x_i conj(x_j) and only the weight differs -- the pass is bound by the f64 vector
+// rate (profiles/r03_sq_src_cov_m8.txt: 198 VALU per wave and item, 0.64 of them issuing).  Here wave w owns M reals of
+// the packed matrix (a few pairs (i, j), i <= j, chosen so that it needs few rows of X: pair_list) for ALL sources:
+//   p = x_i conj(x_j)   once per item and pair       (2 instructions on the diagonal, 4 off it)
+//   acc[n][p] += weight_n p                          (1 / 2 fused multiply-adds per source)
+// = 16 + 64 instructions at M = 8 instead of 144.  The weights travel through LDS: wave n still carries row n of X and the
+// weight inputs of source n on the ring, forms weight_n of item it+1 during trip `it` (as before) and publishes its 64
+// values in wbuf[(it+1) & 1][n]; the barrier that opens trip it+1 makes all N of them readable by every wave.  Records,
+// partition and finalize kernel are src_cov_kernel's (acc index n*M + r -> packed index by pair_real_index at the flush).
+// ---------------------------------------------------------------------------------------------------------------
+struct PairList {
+  int n;         // pairs of this wave
+  int i[8], j[8];  // i <= j; the wave's reals follow in this order, 1 per diagonal entry, (re, im) per pair off it
+};
+template <int M>
+__host__ __device__ constexpr PairList pair_list(int w) {
+  PairList L{};
+  auto put = [&](int a, int b) {
+    L.i[L.n] = a < b ? a : b;
+    L.j[L.n] = a < b ? b : a;
+    ++L.n;
+  };
+  if (M % 2 == 1) {  // cyclic: (w, w), (w, w+1), ..., (w, w + (M-1)/2): every pair once, (M + 1) / 2 consecutive rows
+    for (int dlt = 0; dlt <= (M - 1) / 2; ++dlt) put(w, (w + dlt) % M);
+  } else if (M == 6) {  // five waves with three pairs off the diagonal, one with the diagonal
+    if (w == 0) put(0, 1), put(0, 2), put(1, 2);
+    else if (w == 1) put(3, 4), put(3, 5), put(4, 5);
+    else if (w < 5) put(w - 2, 3), put(w - 2, 4), put(w - 2, 5);
+    else for (int m = 0; m < 6; ++m) put(m, m);
+  } else {  // M == 8: 2 x 2 blocks of rows {0,1} {2,3} {4,5} {6,7}; the diagonal blocks two by two
+    constexpr int ba[6] = {0, 0, 0, 1, 1, 2}, bb[6] = {1, 2, 3, 2, 3, 3};
+    if (w < 6) {
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) put(2 * ba[w] + a, 2 * bb[w] + b);
+    } else {
+      for (int h = 0; h < 2; ++h) {
+        const int r0 = (w - 6) * 4 + 2 * h;
+        put(r0, r0), put(r0 + 1, r0 + 1), put(r0, r0 + 1);
+      }
+    }
+  }
+  return L;
+}
+template <int M>
+constexpr bool pair_lists_cover() {  // every (i, j), i <= j, owned by exactly one wave; M reals per wave
+  int seen[8][8] = {};
+  for (int w = 0; w < M; ++w) {
+    const PairList L = pair_list<M>(w);
+    int reals = 0;
+    for (int q = 0; q < L.n; ++q) {
+      if (L.i[q] > L.j[q] || L.j[q] >= M) return false;
+      ++seen[L.i[q]][L.j[q]];
+      reals += L.i[q] == L.j[q] ? 1 : 2;
+    }
+    if (reals != M) return false;
+  }
+  for (int i = 0; i < M; ++i)
+    for (int j = i; j < M; ++j)
+      if (seen[i][j] != 1) return false;
+  return true;
+}
+static_assert(pair_lists_cover<5>() && pair_lists_cover<6>() && pair_lists_cover<7>() && pair_lists_cover<8>(),
+              "pair_list must partition the upper triangle");
+
+template <int M, int W>
+struct WavePairs {
+  static constexpr PairList L = pair_list<M>(W);
+  static constexpr int real_offset(int s) {  // first real of pair s
+    int o = 0;
+    for (int q = 0; q < s; ++q) o += L.i[q] == L.j[q] ? 1 : 2;
+    return o;
+  }
+  static constexpr bool needs_row(int m) {
+    for (int q = 0; q < L.n; ++q)
+      if (L.i[q] == m || L.j[q] == m) return true;
+    return false;
+  }
+  static constexpr int rows() {
+    int c = 0;
+    for (int m = 0; m < M; ++m) c += needs_row(m) ? 1 : 0;
+    return c;
+  }
+  static constexpr int nth_row(int k) {  // the k-th row (ascending) this wave reads
+    for (int m = 0; m < M; ++m)
+      if (needs_row(m) && k-- == 0) return m;
+    return 0;
+  }
+  static constexpr int packed_index(int r) {  // real r of this wave -> index in the packed Hermitian record
+    for (int q = 0; q < L.n; ++q) {
+      const int o = real_offset(q);
+      if (L.i[q] == L.j[q]) {
+        if (r == o) return L.i[q];
+      } else if (r == o || r == o + 1) {
+        return herm_pair_base<M>(L.i[q], L.j[q]) + (r - o);
+      }
+    }
+    return 0;
+  }
+};
+
+__device__ __forceinline__ void lds_write_real(unsigned addr, double v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write_real(unsigned addr, float v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+
+template <typename WP, int M, typename V, int I = 0>
+__device__ __forceinline__ void fence_rows(V (&xr)[M]) {  // value fence on the rows of X a wave reads
+  if constexpr (I < M) {
+    if constexpr (WP::needs_row(I)) asm volatile("" : "+v"(xr[I]));
+    fence_rows<WP, M, V, I + 1>(xr);
+  }
+}
+
+#ifndef PAIRCOV_TRACE
+#define PAIRCOV_TRACE 0
+#endif
+#if PAIRCOV_TRACE
+__device__ unsigned long long g_paircov_trace[1400];  // timing-experiment builds only
+#endif
+
+#ifndef ASSX_PAIR_DXS_LE6
+#define ASSX_PAIR_DXS_LE6 4  // ring depth of pair_cov_kernel for M <= 6 (two workgroups per CU at M = 5; 5 and 6 measured: slower at M = 5, the same at M = 6)
+#endif
+template <typename R, int M, int WK>
+using PairCovGeom = SrcCovGeom<R, M, WK, (M <= 6 ? ASSX_PAIR_DXS_LE6 : 0)>;
+template <typename R, int M, int WK>
+constexpr size_t pair_cov_lds_bytes() {
+  return PairCovGeom<R, M, WK>::lds_bytes + (size_t)2 * M * WAVE * sizeof(R);
+}
+
+template <typename R, int M, int WK>
+__global__ void __launch_bounds__(WAVE * M)
+    pair_cov_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
+                    Dims d, FlatPart fp, R eps) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  [[maybe_unused]] int trace_n = 0;
+  auto stamp = [&]() {  // -DPAIRCOV_TRACE=1: shader-clock stamps of workgroup 100, waves 0 and 5 (tools/probes/paircov_trace.py)
+#if PAIRCOV_TRACE
+    if (blockIdx.x == 100 && (threadIdx.x == 0 || threadIdx.x == 320) && trace_n < 700)
+      g_paircov_trace[(threadIdx.x ? 700 : 0) + trace_n] = __builtin_amdgcn_s_memtime();
+#endif
+    ++trace_n;
+  };
+  constexpr int N = M, HM = M * M, NV = next_pow2_c(HM);
+  using GEO = PairCovGeom<R, M, WK>;
+  constexpr int RB = GEO::RB, DXS = GEO::DXS;
+  constexpr unsigned SLOT = (unsigned)GEO::SLOT;
+  constexpr unsigned WROW = WAVE * (unsigned)sizeof(R);                  // one source's published weights
+  const int F = d.F, T = d.T, K = WK == WK_TV ? d.K : 1, TBk = fp.len;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+  const int n = __builtin_amdgcn_readfirstlane(tid >> 6);  // this wave: row n of X, weight of source n, pairs of pair_list(n)
+  const int g = (int)blockIdx.x;
+  int b0, f0, tb0, nblk;
+  if (!flat_start(fp, g, b0, f0, tb0, nblk)) return;
+  const size_t FT = (size_t)F * T;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
+  const unsigned wpriv = (unsigned)M * RB + (unsigned)n * GEO::WSLOT;
+  const unsigned wbuf = lds0 + (unsigned)DXS * SLOT;  // [2][N][WAVE] reals
+
+  const BufRsrc rx = make_rsrc_sized(X + (size_t)b0 * M * FT, (size_t)M * FT * sizeof(Cx<R>));
+  const unsigned xlane = (unsigned)((size_t)n * FT * sizeof(Cx<R>)) + (unsigned)lane * 16u;
+  const size_t vrows = WK == WK_TV ? (size_t)N * K : (WK == WK_NT ? (size_t)N : (size_t)N * F);
+  const BufRsrc rvb = make_rsrc_sized(V + (size_t)b0 * vrows * T, vrows * T * sizeof(R));
+  constexpr int LPV = GEO::RBV / 16;
+  unsigned vlane[GEO::NVI];
+#pragma unroll
+  for (int j = 0; j < GEO::NVI; ++j) {
+    const int row = min(j * (WAVE / LPV) + lane / LPV, K - 1);
+    vlane[j] = (unsigned)((size_t)row * T * sizeof(R)) + (unsigned)(lane % LPV) * 16u;
+  }
+  buf_u4 rt = make_rsrc_words(Tb + (size_t)b0 * N * F * K, (size_t)N * F * K * sizeof(R));
+  rt.x = __builtin_amdgcn_readfirstlane(rt.x);
+  rt.y = __builtin_amdgcn_readfirstlane(rt.y);
+  rt.z = __builtin_amdgcn_readfirstlane(rt.z);
+  rt.w = __builtin_amdgcn_readfirstlane(rt.w);
+  auto request = [&](const Cursor& c, int sl) {  // as in src_cov_kernel
+    const unsigned sbase = (unsigned)sl * SLOT;
+    if (WK == WK_TV) {
+      const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((((size_t)n * F + c.f) * K) * sizeof(R)));
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + sbase + wpriv + GEO::VBYTES));
+      if (lane < GEO::TLANES) buf_dword_to_lds(dst, rt, (unsigned)lane * 4u, soff);
+    }
+    const size_t vrow = WK == WK_TV ? (size_t)n * K : (WK == WK_NT ? (size_t)n : (size_t)n * F + c.f);
+    const unsigned vsoff = (unsigned)((vrow * T + (size_t)c.tb * WAVE) * sizeof(R));
+#pragma unroll
+    for (int j = 0; j < GEO::NVI; ++j)
+      if (GEO::VLANES == WAVE || lane < GEO::VLANES)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            rvb, (__attribute__((address_space(3))) void*)(smem + sbase + wpriv + (unsigned)j * 1024u), 16, (int)vlane[j],
+            (int)vsoff, 0, 0);
+    const unsigned xoff = xlane + (unsigned)(((size_t)c.f * T + (size_t)c.tb * WAVE) * sizeof(Cx<R>));
+    if (GEO::LPR == WAVE || lane < GEO::LPR)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(
+          rx, (__attribute__((address_space(3))) void*)(smem + sbase + (unsigned)n * RB), 16, (int)xoff, 0, 0, 0);
+  };
+  struct WIn {
+    Vec2<R> v01, v23;
+    R t[4];
+    R r;
+  };
+  auto read_w = [&](int sl, WIn& w) {  // WIN_READS instructions
+    const unsigned base = lds0 + (unsigned)sl * SLOT + wpriv;
+    if (WK == WK_TV) {
+      const unsigned va = base + (unsigned)lane * (unsigned)sizeof(R);
+      lds_read_rows2<0>(va, w.v01);
+      lds_read_rows2<1>(va, w.v23);
+      lds_read_row4(base + GEO::VBYTES, w.t);
+    } else {
+      lds_read_real(base + (unsigned)lane * (unsigned)sizeof(R), w.r);
+    }
+  };
+  auto fence_w = [&](WIn& w) {
+    if (WK == WK_TV) asm volatile("" : "+v"(w.v01), "+v"(w.v23), "+v"(w.t[0]), "+v"(w.t[1]), "+v"(w.t[2]), "+v"(w.t[3]));
+    else asm volatile("" : "+v"(w.r));
+  };
+  auto weight = [&](int tb, const WIn& w) -> R {  // src_cov_kernel's chain, bit for bit
+    R tv;
+    if (WK == WK_TV) {
+      tv = fma(w.t[0], w.v01.x, (R)0);
+      tv = fma(K > 1 ? w.t[1] : (R)0, w.v01.y, tv);
+      tv = fma(K > 2 ? w.t[2] : (R)0, w.v23.x, tv);
+      tv = fma(K > 3 ? w.t[3] : (R)0, w.v23.y, tv);
+    } else {
+      tv = w.r;
+    }
+    const R rr = floor_eps<R>(tv, eps);
+    return tb * WAVE + lane < T ? fast_rcp(rr) : (R)0;
+  };
+  // the N published weights of one item: sources 2q, 2q+1 per instruction (rows are WAVE reals apart)
+  constexpr int WALL_READS = (N + 1) / 2;
+  auto read_wall = [&](int par, Vec2<R> (&wl)[WALL_READS]) {
+    const unsigned a = wbuf + (unsigned)par * (unsigned)N * WROW + (unsigned)lane * (unsigned)sizeof(R);
+    static_for<N / 2>([&](auto qc) { lds_read_rows2<decltype(qc)::value>(a, wl[decltype(qc)::value]); });
+  };
+
+  // Pipeline: trip `it` runs the arithmetic of item `it` from registers (x: read during trip it-1; wl: the N weights,
+  // read during trip it-1 as well), reads the rows of X and the published weights of item it+1, forms this wave's weight of
+  // item it+2 and publishes it in wbuf[it & 1] (whose previous content, the weights of item `it`, every wave holds in
+  // registers since the barrier that opened this trip), and requests item it+DXS into the slot item `it` has left.  Nothing
+  // a trip reads from LDS is needed before its end: no wait stands between the barrier and the arithmetic.
+  Cursor first;
+  first.b = b0;
+  first.f = f0;
+  first.tb = tb0;
+  Cursor cr = first;  // item it + DXS, the next one to request
+#pragma unroll
+  for (int i = 0; i < DXS; ++i) {
+    request(i < nblk ? cr : first, i);
+    advance(cr, TBk, F);
+  }
+  int tb1 = tb0 + 1 == TBk ? 0 : tb0 + 1;  // frame block of item it+1 ...
+  int tb2 = tb1 + 1 == TBk ? 0 : tb1 + 1;  // ... and of item it+2
+  wait_vmcnt<(DXS - 3) * GEO::C>();  // items 0, 1 and 2 have landed (this wave's share: the barriers publish the rest)
+  asm volatile("s_barrier" ::: "memory");
+  {  // weights of items 0 and 1 -> wbuf[0][n], wbuf[1][n]
+    WIn w0, w1;
+    read_w(0, w0);
+    read_w(1, w1);
+    lds_wait<0>();
+    fence_w(w0);
+    fence_w(w1);
+    const unsigned wa = wbuf + (unsigned)n * WROW + (unsigned)lane * (unsigned)sizeof(R);
+    lds_write_real(wa, weight(tb0, w0));
+    lds_write_real(wa + (unsigned)N * WROW, weight(tb1, w1));
+    lds_wait<0>();
+  }
+  asm volatile("s_barrier" ::: "memory");
+
+  auto run = [&](auto wc) {
+    constexpr int W = decltype(wc)::value;
+    using WP = WavePairs<M, W>;
+    static_assert(WP::real_offset(WP::L.n) == M, "every wave owns M reals");
+    constexpr int NXR = WP::rows();
+    // what a trip issues besides its arithmetic, placed BETWEEN the slices of the fan-out (one slice = one source): issued
+    // together after the barrier, the 8 waves' LDS reads (12 x 1 KB each) filled the LDS queue and every wave stood at its
+    // reads until they were accepted (profiles/r03_paircov_trace.txt)
+    constexpr int E_WALL = 0, E_WIN = 1, E_REQ = 2, E_X = 3, NE = 3 + NXR;
+    auto event_slice = [](int e) constexpr { return e * N / NE; };  // the slice after which event e is issued
+    constexpr int CHAIN_AT = N / 2 + 1;  // the slice in front of which the weight chain (item it+2) starts
+    constexpr int WRITE_AT = N - 1;      // ... and in front of which its result is published
+    auto x_reads_before = [=](int sl_) constexpr {
+      int c = 0;
+      for (int e = E_X; e < NE; ++e) c += event_slice(e) < sl_ ? 1 : 0;
+      return c;
+    };
+    static_assert(event_slice(E_WIN) < CHAIN_AT && CHAIN_AT < WRITE_AT, "the weight inputs are read before the chain starts");
+    auto fence_x = [&](Vec2<R> (&xr)[M]) { fence_rows<WP, M>(xr); };
+    // two register sets (rows of X, weights), alternating from trip to trip: the loop is unrolled by two so that no trip
+    // ends with copies
+    Vec2<R> xs[2][M];
+    Vec2<R> wls[2][WALL_READS];
+    R wlasts[2] = {0, 0};  // N odd: the last source's weights on their own
+    {
+      const unsigned xa = lds0 + (unsigned)lane * (unsigned)sizeof(Cx<R>);
+      static_for<M>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        if constexpr (WP::needs_row(m)) lds_read_cx<m * RB>(xa, xs[0][m]);
+      });
+      read_wall(0, wls[0]);
+      if (N % 2) lds_read_real(wbuf + (unsigned)(N - 1) * WROW + (unsigned)lane * (unsigned)sizeof(R), wlasts[0]);
+      lds_wait<0>();
+      fence_x(xs[0]);
+    }
+    R acc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) acc[q] = 0;
+    int sl = 0, slot = 0, it = 0;
+    auto trip = [&](auto hc) {
+      constexpr int H = decltype(hc)::value;
+      Vec2<R>(&x)[M] = xs[H];
+      Vec2<R>(&xn)[M] = xs[1 - H];
+      Vec2<R>(&wl)[WALL_READS] = wls[H];
+      Vec2<R>(&wln)[WALL_READS] = wls[1 - H];
+      R& wlast = wlasts[H];
+      R& wlastn = wlasts[1 - H];
+      const bool more = it + 1 < nblk;
+      stamp();
+      asm volatile("s_barrier" ::: "memory");  // items it+1 (rows of X) and it+2 (weight inputs) have landed for every wave;
+                                                // the weights of item it+1 are published
+      stamp();
+      const int sl1 = sl + 1 == DXS ? 0 : sl + 1;
+      const int sl2 = sl1 + 1 == DXS ? 0 : sl1 + 1;
+      WIn wn;
+      // x_i conj(x_j) of the wave's pairs
+      R p[M];
+      static_for<WP::L.n>([&](auto sc) {
+        constexpr int s = decltype(sc)::value, i = WP::L.i[s], j = WP::L.j[s], o = WP::real_offset(s);
+        if constexpr (i == j) {
+          p[o] = fma(x[i].y, x[i].y, x[i].x * x[i].x);
+        } else {
+          p[o] = fma(x[i].y, x[j].y, x[i].x * x[j].x);
+          p[o + 1] = fma(-x[i].x, x[j].y, x[i].y * x[j].x);
+        }
+      });
+#pragma unroll
+      for (int r = 0; r < M; ++r) asm volatile("" : "+v"(p[r]));
+      stamp();
+      R wgt_n = 0;
+      int tb1n = tb1, tb2n = tb2;
+      Cursor crn = cr;
+      const unsigned xa1 = lds0 + (unsigned)sl1 * SLOT + (unsigned)lane * (unsigned)sizeof(Cx<R>);
+      static_for<N>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        if constexpr (s == CHAIN_AT) {
+          lds_wait<x_reads_before(CHAIN_AT)>();  // LDS returns in order: the weight inputs (issued before any row of X) are here
+          fence_w(wn);
+          wgt_n = weight(tb2, wn);
+        }
+        if constexpr (s == WRITE_AT) {
+          asm volatile("" : "+v"(wgt_n));
+          lds_write_real(wbuf + (unsigned)(it & 1) * (unsigned)N * WROW + (unsigned)n * WROW +
+                             (unsigned)lane * (unsigned)sizeof(R),
+                         wgt_n);
+        }
+        const R ws = (N % 2 && s == N - 1) ? wlast : ((s & 1) ? wl[s >> 1].y : wl[s >> 1].x);
+#pragma unroll
+        for (int r = 0; r < M; ++r) acc[s * M + r] = fma(ws, p[r], acc[s * M + r]);
+#pragma unroll
+        for (int r = 0; r < M; ++r) asm volatile("" : "+v"(acc[s * M + r]));
+        static_for<NE>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          if constexpr (event_slice(e) == s) {
+            if constexpr (e == E_WALL) {
+              read_wall((it + 1) & 1, wln);
+              if (N % 2)
+                lds_read_real(wbuf + (unsigned)(((it + 1) & 1) * N + N - 1) * WROW + (unsigned)lane * (unsigned)sizeof(R), wlastn);
+            } else if constexpr (e == E_WIN) {
+              read_w(sl2, wn);
+            } else if constexpr (e == E_REQ) {
+              request(it + DXS < nblk ? cr : first, sl);
+              // the cursors of the next trip, here where the scalar unit is idle
+              advance(crn, TBk, F);
+              tb1n = tb1 + 1 == TBk ? 0 : tb1 + 1;
+              tb2n = tb2 + 1 == TBk ? 0 : tb2 + 1;
+            } else {
+              lds_read_cx<WP::nth_row(e - E_X) * RB>(xa1, xn[WP::nth_row(e - E_X)]);
+            }
+          }
+        });
+#pragma unroll
+        for (int r = 0; r < M; ++r) asm volatile("" : "+v"(p[r]));
+      });
+      stamp();
+      lds_wait<0>();
+      fence_x(xn);
+#pragma unroll
+      for (int q = 0; q < N / 2; ++q) asm volatile("" : "+v"(wln[q]));
+      asm volatile("" : "+v"(wlastn));
+      stamp();
+      wait_vmcnt<(DXS - 3) * GEO::C>();  // this wave's share of item it+3 has landed
+      stamp();
+      if (tb1 == 0 || !more) {  // the bin is complete (or the range ends): flush
+        const R tot = wave_reduce_scatter<R, NV>(acc);
+        const int q = scatter_index<NV>();
+        if (scatter_leader<NV>() && q < HM) {
+          const int s = q / M, r = q - s * M;
+          int hm = 0;
+          static_for<M>([&](auto rc) {
+            if (r == decltype(rc)::value) hm = WP::packed_index(decltype(rc)::value);
+          });
+          part[(((size_t)g * fp.S + slot) * N + s) * HM + hm] = tot;
+        }
+        ++slot;
+#pragma unroll
+        for (int q2 = 0; q2 < NV; ++q2) acc[q2] = 0;
+      }
+      sl = sl1;
+      tb1 = tb1n;
+      tb2 = tb2n;
+      cr = crn;
+      ++it;
+    };
+    while (it < nblk) {
+      trip(IntC<0>());
+      if (it >= nblk) break;
+      trip(IntC<1>());
+    }
+  };
+  static_for<M>([&](auto wc) {
+    if (n == decltype(wc)::value) run(wc);
+  });
   wait_vmcnt<0>();  // nothing may land in LDS after the workgroup has gone
 #endif
 }

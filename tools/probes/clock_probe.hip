@@ -118,6 +118,13 @@ int main() {
   }
   RUN("s_sleep (idle chip)", k_sleep, 1, 1, 20000, 0.0)
   RUN("v_mfma_f64_16x16x4", (k_mfma64<1>), 1, 1, 40000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<1>), 1, 2, 40000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<1>), 1, 3, 40000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<1>), 1, 4, 40000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<1>), 1, 6, 40000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<1>), 1, 8, 40000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<2>), 2, 1, 20000, 2048.0)
+  RUN("v_mfma_f64_16x16x4", (k_mfma64<2>), 2, 2, 20000, 2048.0)
   RUN("v_mfma_f64_16x16x4", (k_mfma64<4>), 4, 1, 20000, 2048.0)
   RUN("v_mfma_f64_16x16x4", (k_mfma64<4>), 4, 2, 20000, 2048.0)
   RUN("v_mfma_f64_16x16x4", (k_mfma64<2>), 2, 3, 20000, 2048.0)
