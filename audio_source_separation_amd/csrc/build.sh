@@ -21,7 +21,12 @@ for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfe
     [ "$dep" -nt "$OBJ/$src.o" ] && stale=1
   done
   if [ "$stale" = 1 ]; then
-    $HIPCC $FLAGS -c "$src.hip" -o "$OBJ/$src.o" &
+    # the matrix-core NMF kernels: accumulators in VGPRs.  Left to its heuristics the compiler keeps the loop-carried
+    # accumulators in VGPRs but runs the MFMA chains on AGPRs: 16 v_accvgpr_write + 16 v_accvgpr_read + ~30 wait states per
+    # 16 x 16 sub-tile (config 2: 65 -> 61 us per update).  Not for assx_bss.hip: two cov_mfma_kernel variants spill with it.
+    SRCFLAGS=""
+    [ "$src" = assx_nmf ] && SRCFLAGS="-mllvm -amdgpu-mfma-vgpr-form"
+    $HIPCC $FLAGS $SRCFLAGS -c "$src.hip" -o "$OBJ/$src.o" &
     pids+=($!)
   fi
 done

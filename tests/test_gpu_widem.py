@@ -223,13 +223,14 @@ def test_batched_equals_single_and_unsupported_entry_points(eng):
 
 
 @pytest.mark.parametrize("M,K,domain,G", [(5, 3, 2, 1), (6, 10, 1, 3), (7, 4, 2, 7), (8, 4, 2, 2), (8, 10, 2, 5), (8, 16, 1.5, 3),
-                                          (8, 20, 2, 3)])
+                                          (8, 20, 2, 3), (8, 4, 2, 234), (5, 3, 2, 150), (7, 4, 2, 117), (6, 4, 2, 78)])
 def test_src_cov_long_ranges(eng, M, K, domain, G):
-    """src_cov_kernel (csrc/assx_widem_cov.hpp) on partitions forced down to a handful of workgroups (ASSX_G), so that a
-    small input drives what a full-size utterance does: prologue, steady trips of the three-slot X ring, ranges that
-    start / end inside a bin and flush several records, basis-row reloads at bin boundaries, ragged T, every weight form
-    (rebuilt from (Tb, V) for n_basis <= 16, map given beyond / for t-ILRMA and IDLMA, (N,T) for AuxIVA); two utterances
-    in one call == one at a time, bit for bit."""
+    """pair_cov_kernel (csrc/assx_widem_cov.hpp) on partitions forced down to a handful of workgroups (ASSX_G), so that a
+    small input drives what a full-size utterance does: prologue, steady trips of the ring, ranges that start / end inside
+    a bin and flush several records, basis-row reloads at bin boundaries, ragged T, every weight form (rebuilt from
+    (Tb, V) for n_basis <= 4, map given beyond / for t-ILRMA and IDLMA, (N,T) for AuxIVA) -- and forced UP to ranges of
+    one, two or three items (the pipeline runs two items ahead: its prologue and its last trips are then all there is);
+    two utterances in one call == one at a time, bit for bit."""
     import os
     F, T = 9, 777
     rng = np.random.default_rng(300 + M + K)
@@ -291,3 +292,40 @@ def test_source_model_without_loss(eng, M, K, G):
             assert torch.equal(t1[0], Td[b]) and torch.equal(v1[0], Vd[b])
     finally:
         os.environ.pop("ASSX_G", None)
+
+
+
+def test_pair_and_source_forms_of_the_covariance_agree():
+    """The two streaming forms of the wide-channel covariance (pairs split over the waves: default; one wave per source:
+    ASSX_WIDEM_PAIRS=0, read once per process) give the same U up to the rounding of their different product order."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from audio_source_separation_amd.ops import Engine\n"
+        "eng = Engine(dtype='float64')\n"
+        "g = torch.Generator(device=eng.dev).manual_seed(5)\n"
+        "out = {}\n"
+        "for M in (5, 6, 7, 8):\n"
+        "    F, T, K = 7, 500, 3\n"
+        "    X = torch.view_as_complex(torch.randn((1, M, F, T, 2), dtype=torch.float64, device=eng.dev, generator=g)).contiguous()\n"
+        "    W = (torch.eye(M, dtype=torch.complex128, device=eng.dev).expand(1, F, M, M) + 0).contiguous()\n"
+        "    Tb = torch.rand((1, M, F, K), dtype=torch.float64, device=eng.dev, generator=g) + 0.1\n"
+        "    V = torch.rand((1, M, K, T), dtype=torch.float64, device=eng.dev, generator=g) + 0.1\n"
+        "    U = eng.empty((1, M, F, M, M), complex_=True)\n"
+        "    eng.ilrma_spatial_update(X, W, Tb, V, domain=2, status=eng.new_status(1), U_out=U)\n"
+        "    out['U%%d' %% M] = U.cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % root)
+    res = {}
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("1", "0"):
+            env = dict(os.environ, ASSX_WIDEM_PAIRS=mode)
+            path = os.path.join(d, "u%s.npz" % mode)
+            subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=600)
+            res[mode] = dict(np.load(path))
+    for k in res["1"]:
+        assert rel_err(res["1"][k], res["0"][k]) < 1e-13

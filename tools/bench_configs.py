@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Secondary measurements for DESIGN.md: BASELINE.json configs 1-4 through the drop-in classes (device-resident
-inputs unless stated), plus the PCIe-inclusive ILRMA rate when the boundary is handed host NumPy buffers."""
+inputs unless stated), plus the PCIe-inclusive ILRMA rate when the boundary is handed host NumPy buffers.
+One PROCESS per dtype (the parent only merges): measured in one process, the second dtype's section inherited the
+allocator / staging state of the first and its small configs and NumPy call read 10-100 % slow
+(profiles/r03_f32_call_probe.txt)."""
 import json
 import os
 import sys
@@ -13,6 +16,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from audio_source_separation_amd.algorithm.nmf import EUCNMF, ISNMF  # noqa: E402
 from audio_source_separation_amd.bss.ilrma import GaussILRMA  # noqa: E402
 from audio_source_separation_amd.bss.iva import AuxGaussIVA, AuxLaplaceIVA  # noqa: E402
+
+if "--dtype" not in sys.argv:  # parent: one child per dtype
+    import subprocess
+    merged = {}
+    for d in ("float64", "float32"):
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dtype", d], capture_output=True, text=True, check=True)
+        merged.update(json.loads(r.stdout[r.stdout.index("{"):]))
+    print(json.dumps(merged, indent=1))
+    sys.exit(0)
 
 dev = torch.device("cuda", 0)
 out = {}
@@ -38,7 +50,7 @@ def time_updates(model, steps, warmup=3):
     return steps / (time.perf_counter() - t0)
 
 
-for dtype in ("float64", "float32"):
+for dtype in (sys.argv[sys.argv.index("--dtype") + 1],):
     res = {}
     # cfg1: EUC-NMF F=513 T=256 K=8 ; cfg2: IS-NMF F=1025 T=4096 K=32
     for name, cls, (F, T, K) in (("cfg1_eucnmf_513x256_k8", EUCNMF, (513, 256, 8)),
@@ -48,7 +60,7 @@ for dtype in ("float64", "float32"):
         m = cls(n_basis=K, dtype=dtype)
         m.target = X
         m._reset()
-        ups = time_updates(m, 30)
+        ups = time_updates(m, 300 if F < 1000 else 60, warmup=20)
         r = 8 if dtype == "float64" else 4
         res[name] = {"update_once_per_s": round(ups, 1), "gflops": round(12 * F * T * K * ups / 1e9, 1),
                      "algorithmic_GBps": round(2 * F * T * r * ups / 1e9, 1)}
@@ -58,7 +70,7 @@ for dtype in ("float64", "float32"):
         m = cls(recordable_loss=False, dtype=dtype)
         m.input = X.to(torch.complex128 if dtype == "float64" else torch.complex64)
         m._reset()
-        its = time_updates(m, 50)
+        its = time_updates(m, 300, warmup=20)
         c = 16 if dtype == "float64" else 8
         res[name] = {"iterations_per_s": round(its, 1), "algorithmic_GBps": round(2 * 2 * 1025 * 2048 * c * its / 1e9, 1)}
     # cfg4 via the class, device-resident

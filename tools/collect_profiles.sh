@@ -32,12 +32,12 @@ for t in cfg4 f32 k10 nmf m8 m5; do py $ROOT/tools/rocprof_summary.py $OUT/prof_
 # SQ counters
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_stream $TAG/sq_cov_k4 > $OUT/sq_cov_k4.txt 2>&1
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_mfma $TAG/sq_cov_k10 --K 10 > $OUT/sq_cov_k10.txt 2>&1
-bash $ROOT/tools/pmc_kernel.sh "ilrma_spatial_update" src_cov $TAG/sq_src_cov_m8 --M 8 > $OUT/sq_src_cov_m8.txt 2>&1
+bash $ROOT/tools/pmc_kernel.sh "ilrma_spatial_update" pair_cov $TAG/sq_pair_cov_m8 --M 8 > $OUT/sq_pair_cov_m8.txt 2>&1
 # HBM traffic
 py $ROOT/tools/pmc_traffic.py collect > /dev/null 2>&1
 py $ROOT/tools/pmc_traffic.py report > $OUT/cov_traffic.json 2>&1
 cp $ROOT/profiles/cov_traffic.json $OUT/cov_traffic.json 2>/dev/null
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > $OUT/clock_probe.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -mllvm -amdgpu-mfma-vgpr-form $ROOT/tools/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > $OUT/clock_probe.txt; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/mfma_valu_share_probe.hip -o /tmp/share_probe && /tmp/share_probe > $OUT/mfma_valu_share_probe.txt
 cd $ROOT && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $OUT/gpu_tests.log
 rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] $ROOT/gpurun_out/pmc_fetch_* $ROOT/gpurun_out/pmc_write_* 2>/dev/null
 ls -la $OUT

@@ -25,9 +25,9 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 # (tag, n_basis, kernel-name substring, channels, microbench entry).  k10: cov_mfma_kernel since round 3 (the records'
 # finalize is a separate kernel and not part of the figure); m8: the wide-channel streaming covariance inside one spatial
-# update (src_cov_kernel; contract bytes M F T c + (N F K + N K T) r + N F M^2 c with M = N = 8)
+# update (pair_cov_kernel; contract bytes M F T c + (N F K + N K T) r + N F M^2 c with M = N = 8)
 CASES = (("k4", 4, "cov_stream_kernel", 4, "cov TV"), ("k10", 10, "cov_mfma_kernel", 4, "cov TV"),
-         ("m8", 4, "src_cov_kernel", 8, "ilrma_spatial_update"))
+         ("m8", 4, "pair_cov_kernel", 8, "ilrma_spatial_update"))
 
 
 def collect():
