@@ -45,7 +45,10 @@ struct SrcCovGeom {
   static constexpr int VBYTES = VR * RBV;
   static constexpr int NVI = (VBYTES + 1023) / 1024;       // instructions that carry them (f64 ILRMA form: 2, else 1)
   static constexpr int VLANES = VBYTES >= 1024 ? WAVE : VBYTES / 16;  // active lanes of such an instruction
-  static constexpr int TLANES = 8;                         // lanes that fetch the basis row: 32 bytes = n_basis <= 4 reals
+#ifndef ASSX_COV_TLANES
+#define ASSX_COV_TLANES 8
+#endif
+  static constexpr int TLANES = ASSX_COV_TLANES;           // lanes that fetch the basis row: 32 bytes = n_basis <= 4 reals
   static constexpr int TBYTES = WK == WK_TV ? 4 * TLANES : 0;  // its landing area (one dword per lane)
   static constexpr int C = 1 + NVI + (WK == WK_TV ? 1 : 0);  // VMEM instructions of one item's request, per wave
   static constexpr int WSLOT = VBYTES + TBYTES;            // wave-private bytes per slot
@@ -423,11 +426,32 @@ __device__ unsigned long long g_paircov_trace[1400];  // timing-experiment build
 #ifndef ASSX_PAIR_DXS_LE6
 #define ASSX_PAIR_DXS_LE6 4  // ring depth of pair_cov_kernel for M <= 6 (two workgroups per CU at M = 5; 5 and 6 measured: slower at M = 5, the same at M = 6)
 #endif
+// Ring geometry of pair_cov_kernel.  A slot is M blocks of WBLK bytes, one per wave: [row of X][weight-input rows][basis row]
+// -- everything wave n requests for an item is CONTIGUOUS, so that all LDS-direct loads of a request use ONE value of M0
+// and select their landing place with the instruction's immediate offset (which is added to the LDS address AND to the
+// buffer offset: each load goes through a descriptor whose base is moved back by its immediate).  This layout was built
+// while hunting the failure described at launch_src_cov_as (csrc/assx_widem.hip): <double, 5, WK_TV> with two workgroups on
+// a CU.  Rewriting M0 between the loads of a request turned out NOT to be the cause (the failure is the same with one
+// M0), but the layout is kept: one M0 write per request instead of four, nothing else changed in time or results.
 template <typename R, int M, int WK>
-using PairCovGeom = SrcCovGeom<R, M, WK, (M <= 6 ? ASSX_PAIR_DXS_LE6 : 0)>;
+struct PairCovGeom {
+  using G0 = SrcCovGeom<R, M, WK>;
+  static constexpr int RB = G0::RB, LPR = G0::LPR, RBV = G0::RBV, VBYTES = G0::VBYTES, NVI = G0::NVI, VLANES = G0::VLANES;
+  static constexpr int TBYTES = WK == WK_TV ? 32 : 0;  // n_basis <= 4 reals: two lanes of a dwordx4 load
+  static constexpr int C = G0::C;
+  static constexpr int OFF_V = RB, OFF_T = RB + VBYTES;  // immediates of the weight-input and basis-row loads
+  static constexpr int WBLK = RB + VBYTES + TBYTES;
+  static_assert(OFF_T + 32 <= 4096, "immediate offsets are 12 bits");
+  static constexpr int SLOT = M * WBLK;
+  static constexpr int XBYTES = 2 * M * WAVE * (int)sizeof(R);  // the weight exchange
+  static constexpr int FIT = (160 * 1024 - XBYTES) / SLOT;
+  static constexpr int DXS = M <= 6 ? ASSX_PAIR_DXS_LE6 : (ASSX_COV_DXS ? ASSX_COV_DXS : (FIT < 6 ? FIT : 6));
+  static_assert(DXS >= 4 && DXS <= FIT, "ring does not fit the CU's LDS");
+  static constexpr size_t lds_bytes = (size_t)DXS * SLOT;
+};
 template <typename R, int M, int WK>
 constexpr size_t pair_cov_lds_bytes() {
-  return PairCovGeom<R, M, WK>::lds_bytes + (size_t)2 * M * WAVE * sizeof(R);
+  return PairCovGeom<R, M, WK>::lds_bytes + (size_t)PairCovGeom<R, M, WK>::XBYTES;
 }
 
 template <typename R, int M, int WK>
@@ -445,7 +469,7 @@ __global__ void __launch_bounds__(WAVE * M)
   };
   constexpr int N = M, HM = M * M, NV = next_pow2_c(HM);
   using GEO = PairCovGeom<R, M, WK>;
-  constexpr int RB = GEO::RB, DXS = GEO::DXS;
+  constexpr int DXS = GEO::DXS;
   constexpr unsigned SLOT = (unsigned)GEO::SLOT;
   constexpr unsigned WROW = WAVE * (unsigned)sizeof(R);                  // one source's published weights
   const int F = d.F, T = d.T, K = WK == WK_TV ? d.K : 1, TBk = fp.len;
@@ -457,13 +481,20 @@ __global__ void __launch_bounds__(WAVE * M)
   if (!flat_start(fp, g, b0, f0, tb0, nblk)) return;
   const size_t FT = (size_t)F * T;
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem;
-  const unsigned wpriv = (unsigned)M * RB + (unsigned)n * GEO::WSLOT;
+  constexpr unsigned WBLK = (unsigned)GEO::WBLK;
+  const unsigned wblk = (unsigned)n * WBLK;           // this wave's block of a slot
   const unsigned wbuf = lds0 + (unsigned)DXS * SLOT;  // [2][N][WAVE] reals
 
   const BufRsrc rx = make_rsrc_sized(X + (size_t)b0 * M * FT, (size_t)M * FT * sizeof(Cx<R>));
   const unsigned xlane = (unsigned)((size_t)n * FT * sizeof(Cx<R>)) + (unsigned)lane * 16u;
   const size_t vrows = WK == WK_TV ? (size_t)N * K : (WK == WK_NT ? (size_t)N : (size_t)N * F);
-  const BufRsrc rvb = make_rsrc_sized(V + (size_t)b0 * vrows * T, vrows * T * sizeof(R));
+  // descriptors moved back by the immediate offset their load carries (the bytes in front of the arrays are never
+  // addressed: every offset is >= the immediate)
+  const char* vbase = reinterpret_cast<const char*>(V + (size_t)b0 * vrows * T);
+  BufRsrc rvb[GEO::NVI];
+#pragma unroll
+  for (int j = 0; j < GEO::NVI; ++j)
+    rvb[j] = make_rsrc_sized(vbase - (GEO::OFF_V + j * 1024), vrows * T * sizeof(R) + (size_t)(GEO::OFF_V + j * 1024));
   constexpr int LPV = GEO::RBV / 16;
   unsigned vlane[GEO::NVI];
 #pragma unroll
@@ -471,30 +502,26 @@ __global__ void __launch_bounds__(WAVE * M)
     const int row = min(j * (WAVE / LPV) + lane / LPV, K - 1);
     vlane[j] = (unsigned)((size_t)row * T * sizeof(R)) + (unsigned)(lane % LPV) * 16u;
   }
-  buf_u4 rt = make_rsrc_words(Tb + (size_t)b0 * N * F * K, (size_t)N * F * K * sizeof(R));
-  rt.x = __builtin_amdgcn_readfirstlane(rt.x);
-  rt.y = __builtin_amdgcn_readfirstlane(rt.y);
-  rt.z = __builtin_amdgcn_readfirstlane(rt.z);
-  rt.w = __builtin_amdgcn_readfirstlane(rt.w);
-  auto request = [&](const Cursor& c, int sl) {  // as in src_cov_kernel
-    const unsigned sbase = (unsigned)sl * SLOT;
-    if (WK == WK_TV) {
+  const BufRsrc rtb = make_rsrc_sized(reinterpret_cast<const char*>(Tb + (size_t)b0 * N * F * K) - GEO::OFF_T,
+                                      (size_t)N * F * K * sizeof(R) + (size_t)GEO::OFF_T);
+  // one item's inputs into ring slot sl: C instructions, the same for every wave, ONE LDS base (M0) for all of them.
+  // Frames past T read into the next row (zeros past the end of the array): their weight is 0.
+  auto request = [&](const Cursor& c, int sl) {
+    __attribute__((address_space(3))) void* const blk =
+        (__attribute__((address_space(3))) void*)(smem + (unsigned)sl * SLOT + wblk);
+    if (WK == WK_TV) {  // basis row: 32 bytes = the first n_basis <= 4 reals (and what follows them)
       const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((int)((((size_t)n * F + c.f) * K) * sizeof(R)));
-      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + sbase + wpriv + GEO::VBYTES));
-      if (lane < GEO::TLANES) buf_dword_to_lds(dst, rt, (unsigned)lane * 4u, soff);
+      if (lane < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rtb, blk, 16, (int)((unsigned)lane * 16u), (int)soff, GEO::OFF_T, 0);
     }
     const size_t vrow = WK == WK_TV ? (size_t)n * K : (WK == WK_NT ? (size_t)n : (size_t)n * F + c.f);
     const unsigned vsoff = (unsigned)((vrow * T + (size_t)c.tb * WAVE) * sizeof(R));
-#pragma unroll
-    for (int j = 0; j < GEO::NVI; ++j)
+    static_for<GEO::NVI>([&](auto jc) {
+      constexpr int j = decltype(jc)::value;
       if (GEO::VLANES == WAVE || lane < GEO::VLANES)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(
-            rvb, (__attribute__((address_space(3))) void*)(smem + sbase + wpriv + (unsigned)j * 1024u), 16, (int)vlane[j],
-            (int)vsoff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rvb[j], blk, 16, (int)vlane[j], (int)vsoff, GEO::OFF_V + j * 1024, 0);
+    });
     const unsigned xoff = xlane + (unsigned)(((size_t)c.f * T + (size_t)c.tb * WAVE) * sizeof(Cx<R>));
-    if (GEO::LPR == WAVE || lane < GEO::LPR)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(
-          rx, (__attribute__((address_space(3))) void*)(smem + sbase + (unsigned)n * RB), 16, (int)xoff, 0, 0, 0);
+    if (GEO::LPR == WAVE || lane < GEO::LPR) __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, blk, 16, (int)xoff, 0, 0, 0);
   };
   struct WIn {
     Vec2<R> v01, v23;
@@ -502,7 +529,7 @@ __global__ void __launch_bounds__(WAVE * M)
     R r;
   };
   auto read_w = [&](int sl, WIn& w) {  // WIN_READS instructions
-    const unsigned base = lds0 + (unsigned)sl * SLOT + wpriv;
+    const unsigned base = lds0 + (unsigned)sl * SLOT + wblk + (unsigned)GEO::OFF_V;
     if (WK == WK_TV) {
       const unsigned va = base + (unsigned)lane * (unsigned)sizeof(R);
       lds_read_rows2<0>(va, w.v01);
@@ -597,7 +624,7 @@ __global__ void __launch_bounds__(WAVE * M)
       const unsigned xa = lds0 + (unsigned)lane * (unsigned)sizeof(Cx<R>);
       static_for<M>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
-        if constexpr (WP::needs_row(m)) lds_read_cx<m * RB>(xa, xs[0][m]);
+        if constexpr (WP::needs_row(m)) lds_read_cx<m * (int)WBLK>(xa, xs[0][m]);
       });
       read_wall(0, wls[0]);
       if (N % 2) lds_read_real(wbuf + (unsigned)(N - 1) * WROW + (unsigned)lane * (unsigned)sizeof(R), wlasts[0]);
@@ -676,7 +703,7 @@ __global__ void __launch_bounds__(WAVE * M)
               tb1n = tb1 + 1 == TBk ? 0 : tb1 + 1;
               tb2n = tb2 + 1 == TBk ? 0 : tb2 + 1;
             } else {
-              lds_read_cx<WP::nth_row(e - E_X) * RB>(xa1, xn[WP::nth_row(e - E_X)]);
+              lds_read_cx<WP::nth_row(e - E_X) * (int)WBLK>(xa1, xn[WP::nth_row(e - E_X)]);
             }
           }
         });
@@ -690,7 +717,11 @@ __global__ void __launch_bounds__(WAVE * M)
       for (int q = 0; q < N / 2; ++q) asm volatile("" : "+v"(wln[q]));
       asm volatile("" : "+v"(wlastn));
       stamp();
+#ifdef ASSX_PAIR_WAIT0
+      wait_vmcnt<0>();
+#else
       wait_vmcnt<(DXS - 3) * GEO::C>();  // this wave's share of item it+3 has landed
+#endif
       stamp();
       if (tb1 == 0 || !more) {  // the bin is complete (or the range ends): flush
         const R tot = wave_reduce_scatter<R, NV>(acc);

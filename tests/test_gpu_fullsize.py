@@ -329,3 +329,29 @@ def test_wide_channel_full_size_oracle_step(M, K):
     assert mask.all()
     assert rel_err(m.basis, Tr) < 1e-10 and rel_err(m.activation, Vr) < 1e-10 and rel_err(m.demix_filter, W) < 1e-8
     np.testing.assert_allclose(m.compute_negative_loglikelihood(), orc.ilrma_loss(X, W, Tr, Vr), rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_wide_channel_covariance_forms_agree_at_full_size(dtype):
+    """pair_cov_kernel against src_cov_kernel (ASSX_WIDEM_PAIRS=0; the switch is read once per process) at config-4 bins /
+    frames with the real 512 ranges, M = 5..8, every weight form (rebuilt from (Tb, V), (N,T), (N,F,T)), each twice: the
+    occupancies of the benchmark size (several workgroups per CU in float32 and at M = 5) are not reached by the small
+    cases of test_gpu_widem.py, and a landing race shows as garbage in SOME bins of SOME runs
+    (tools/probes/paircov_check.py is the body)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "probes", "paircov_check.py")
+    with tempfile.TemporaryDirectory() as d:
+        paths = {}
+        for mode in ("1", "0"):
+            paths[mode] = os.path.join(d, "u%s.npz" % mode)
+            subprocess.run([sys.executable, script, "run", paths[mode], dtype], check=True, timeout=900,
+                           env=dict(os.environ, ASSX_WIDEM_PAIRS=mode), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        a, b = np.load(paths["1"]), np.load(paths["0"])
+        tol = 1e-10 if dtype == "float64" else 1e-3
+        for k in a.files:
+            dd = np.abs(a[k] - b[k]).max(axis=(-1, -2)) / np.abs(b[k]).max(axis=(-1, -2))
+            assert dd.max() < tol, (k, float(dd.max()), int((dd > tol).sum()))
