@@ -581,6 +581,9 @@ __global__ void __launch_bounds__(WAVE * M)
   int tb1 = tb0 + 1 == TBk ? 0 : tb0 + 1;  // frame block of item it+1 ...
   int tb2 = tb1 + 1 == TBk ? 0 : tb1 + 1;  // ... and of item it+2
   wait_vmcnt<(DXS - 3) * GEO::C>();  // items 0, 1 and 2 have landed (this wave's share: the barriers publish the rest)
+#ifdef ASSX_PAIR_WAIT0
+  asm volatile("s_sleep 64" ::: "memory");  // experiment: time between the counted wait and the first reads
+#endif
   asm volatile("s_barrier" ::: "memory");
   {  // weights of items 0 and 1 -> wbuf[0][n], wbuf[1][n]
     WIn w0, w1;

@@ -1,5 +1,8 @@
-O=gpurun_out/s3p; mkdir -p $O; rm -f $O/*
-timeout 2400 python -m pytest tests/test_gpu_widem.py tests/test_gpu_fullsize.py -x -q 2>&1 | tail -4 > $O/tests.log
-timeout 600 python tools/widem_bench.py 5:4 6:4 7:4 8:4 8:10 2>/dev/null > $O/bench.txt
-timeout 600 python tools/widem_bench.py --dtype float32 5:4 8:4 2>/dev/null >> $O/bench.txt
-ASSX_WIDEM_PAIRS_M5=1 ASSX_PAIR_LDS_PAD=20000 timeout 600 python tools/widem_bench.py 5:4 2>/dev/null >> $O/bench.txt
+O=gpurun_out/s3q; mkdir -p $O; rm -f $O/*
+C=audio_source_separation_amd/csrc
+ASSX_WIDEM_PAIRS=0 python tools/probes/paircov_check.py run /tmp/p0.npz 2>/dev/null
+cp $C/libassx.so /tmp/main.so; cp $C/libassx_wait0.so $C/libassx.so
+ASSX_WIDEM_PAIRS_M5=1 python tools/probes/paircov_check.py run /tmp/p1.npz 2>/dev/null
+echo "== vmcnt(0) every trip + s_sleep in the prologue" >> $O/cmp.txt
+python tools/probes/paircov_check.py cmp /tmp/p1.npz /tmp/p0.npz 2>&1 | grep -v "^   " >> $O/cmp.txt
+cp /tmp/main.so $C/libassx.so
