@@ -388,13 +388,7 @@ static int launch_src_cov_as(assx_ctx* ctx, const void* X, const void* Tb, const
   using GEO = SrcCovGeom<R, M, WKV>;
   static const int pairs = env_int("ASSX_WIDEM_PAIRS", 1);  // 0: one wave per source (src_cov_kernel), A/B runs
   const Dims d{B, F, T, K};
-  // <double, 5, WK_TV> stays on src_cov_kernel: it is the one float64 instantiation of pair_cov_kernel of which TWO
-  // workgroups fit a CU, and exactly then (never with one per CU, never in float32, never with given weights) ~35-55 % of
-  // the bins came out with garbage weights, differently on every run; 64 wait states after each LDS-direct load of a
-  // request cured it, one LDS base per request did not -- unexplained at the end of round 3 (DESIGN §4.7,
-  // tools/probes/paircov_check.py, profiles/r03_paircov_m5_f64_coresidency.txt).
-  const bool excluded = M == 5 && WKV == WK_TV && sizeof(R) == 8 && env_int("ASSX_WIDEM_PAIRS_M5", 0) == 0;
-  if (pairs && !excluded) {  // the Hermitian pairs split over the waves, weights exchanged through LDS
+  if (pairs) {  // the Hermitian pairs split over the waves, weights exchanged through LDS
     static const int lds_pad = env_int("ASSX_PAIR_LDS_PAD", 0);  // experiments: extra dynamic LDS
     const size_t lds = pair_cov_lds_bytes<R, M, WKV>() + (size_t)lds_pad;
     if (lds > 64 * 1024) {  // > 64 KB of dynamic LDS needs the opt-in (per device: set on every launch)

@@ -87,17 +87,38 @@ __device__ __forceinline__ void lds_read_real(unsigned addr, double& v) {
 __device__ __forceinline__ void lds_read_real(unsigned addr, float& v) {
   asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
 }
-// the first four reals of the basis row (every lane reads the same address: a broadcast)
-__device__ __forceinline__ void lds_read_row4(unsigned addr, double (&t)[4]) {
+// the first four reals of the basis row (every lane reads the same address: a broadcast), as the RAW registers the reads
+// fill: nothing may touch them before the matching lds_wait -- not even a copy.  (Until the end of round 3 this helper
+// unpacked into a scalar array right after the asm; where the register allocator could not coalesce that, the unpacking
+// became v_mov_b64 instructions executed BEFORE the wait -- copies of registers the LDS had not written yet.  They
+// sat ~100 cycles after the reads, so the data was usually there: every test passed until two workgroups shared a CU at
+// M = 5 in float64 and the LDS got slower, see launch_src_cov_as in csrc/assx_widem.hip.)
+template <typename R>
+struct Row4Raw;
+template <>
+struct Row4Raw<double> {
   Vec2<double> a, b;
-  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(a), "=&v"(b) : "v"(addr) : "memory");
-  t[0] = a.x, t[1] = a.y, t[2] = b.x, t[3] = b.y;
-}
-__device__ __forceinline__ void lds_read_row4(unsigned addr, float (&t)[4]) {
+};
+template <>
+struct Row4Raw<float> {
   typedef float f4 __attribute__((ext_vector_type(4)));
   f4 q;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(q) : "v"(addr) : "memory");
-  t[0] = q.x, t[1] = q.y, t[2] = q.z, t[3] = q.w;
+};
+__device__ __forceinline__ void lds_read_row4(unsigned addr, Row4Raw<double>& t) {
+  asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16" : "=&v"(t.a), "=&v"(t.b) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void lds_read_row4(unsigned addr, Row4Raw<float>& t) {
+  asm volatile("ds_read_b128 %0, %1" : "=v"(t.q) : "v"(addr) : "memory");
+}
+__device__ __forceinline__ void row4_fence(Row4Raw<double>& t) { asm volatile("" : "+v"(t.a), "+v"(t.b)); }
+__device__ __forceinline__ void row4_fence(Row4Raw<float>& t) { asm volatile("" : "+v"(t.q)); }
+template <int I>
+__device__ __forceinline__ double row4_get(const Row4Raw<double>& t) {
+  return I == 0 ? t.a.x : (I == 1 ? t.a.y : (I == 2 ? t.b.x : t.b.y));
+}
+template <int I>
+__device__ __forceinline__ float row4_get(const Row4Raw<float>& t) {
+  return I == 0 ? t.q.x : (I == 1 ? t.q.y : (I == 2 ? t.q.z : t.q.w));
 }
 template <int N>
 __device__ __forceinline__ void lds_wait() {
@@ -169,7 +190,7 @@ __global__ void __launch_bounds__(WAVE * M)
   // ---- LDS reads of a landed item: weight inputs first (their wait leaves the M X reads in flight), then X
   struct WIn {
     Vec2<R> v01, v23;  // ILRMA form: activation rows 0..3 at this lane's frame ...
-    R t[4];            // ... and the basis row (broadcast)
+    Row4Raw<R> t;      // ... and the basis row (broadcast), raw
     R r;               // weights given: this lane's value
   };
   auto read_w = [&](int sl, WIn& w) {
@@ -188,16 +209,19 @@ __global__ void __launch_bounds__(WAVE * M)
     static_for<M>([&](auto mc) { lds_read_cx<decltype(mc)::value * RB>(xa, xr[decltype(mc)::value]); });
   };
   auto fence_w = [&](WIn& w) {
-    if (WK == WK_TV) asm volatile("" : "+v"(w.v01), "+v"(w.v23), "+v"(w.t[0]), "+v"(w.t[1]), "+v"(w.t[2]), "+v"(w.t[3]));
+    if (WK == WK_TV) {
+      asm volatile("" : "+v"(w.v01), "+v"(w.v23));
+      row4_fence(w.t);
+    }
     else asm volatile("" : "+v"(w.r));
   };
   auto weight = [&](const Cursor& c, const WIn& w) -> R {  // 1 / max(r, eps) of this lane's frame, 0 past T
     R tv;
     if (WK == WK_TV) {  // k ascending from 0 (variance_map_kernel's order); entries past n_basis contribute 0 * finite
-      tv = fma(w.t[0], w.v01.x, (R)0);
-      tv = fma(K > 1 ? w.t[1] : (R)0, w.v01.y, tv);
-      tv = fma(K > 2 ? w.t[2] : (R)0, w.v23.x, tv);
-      tv = fma(K > 3 ? w.t[3] : (R)0, w.v23.y, tv);
+      tv = fma(row4_get<0>(w.t), w.v01.x, (R)0);
+      tv = fma(K > 1 ? row4_get<1>(w.t) : (R)0, w.v01.y, tv);
+      tv = fma(K > 2 ? row4_get<2>(w.t) : (R)0, w.v23.x, tv);
+      tv = fma(K > 3 ? row4_get<3>(w.t) : (R)0, w.v23.y, tv);
     } else {
       tv = w.r;
     }
@@ -430,9 +454,9 @@ __device__ unsigned long long g_paircov_trace[1400];  // timing-experiment build
 // -- everything wave n requests for an item is CONTIGUOUS, so that all LDS-direct loads of a request use ONE value of M0
 // and select their landing place with the instruction's immediate offset (which is added to the LDS address AND to the
 // buffer offset: each load goes through a descriptor whose base is moved back by its immediate).  This layout was built
-// while hunting the failure described at launch_src_cov_as (csrc/assx_widem.hip): <double, 5, WK_TV> with two workgroups on
-// a CU.  Rewriting M0 between the loads of a request turned out NOT to be the cause (the failure is the same with one
-// M0), but the layout is kept: one M0 write per request instead of four, nothing else changed in time or results.
+// while hunting a failure of <double, 5, WK_TV> with two workgroups on a CU, whose cause turned out to be elsewhere
+// (lds_read_row4 above: registers copied before their wait); it is kept: one M0 write per request instead of four,
+// nothing else changed in time or results.
 template <typename R, int M, int WK>
 struct PairCovGeom {
   using G0 = SrcCovGeom<R, M, WK>;
@@ -525,7 +549,7 @@ __global__ void __launch_bounds__(WAVE * M)
   };
   struct WIn {
     Vec2<R> v01, v23;
-    R t[4];
+    Row4Raw<R> t;
     R r;
   };
   auto read_w = [&](int sl, WIn& w) {  // WIN_READS instructions
@@ -540,16 +564,19 @@ __global__ void __launch_bounds__(WAVE * M)
     }
   };
   auto fence_w = [&](WIn& w) {
-    if (WK == WK_TV) asm volatile("" : "+v"(w.v01), "+v"(w.v23), "+v"(w.t[0]), "+v"(w.t[1]), "+v"(w.t[2]), "+v"(w.t[3]));
+    if (WK == WK_TV) {
+      asm volatile("" : "+v"(w.v01), "+v"(w.v23));
+      row4_fence(w.t);
+    }
     else asm volatile("" : "+v"(w.r));
   };
   auto weight = [&](int tb, const WIn& w) -> R {  // src_cov_kernel's chain, bit for bit
     R tv;
     if (WK == WK_TV) {
-      tv = fma(w.t[0], w.v01.x, (R)0);
-      tv = fma(K > 1 ? w.t[1] : (R)0, w.v01.y, tv);
-      tv = fma(K > 2 ? w.t[2] : (R)0, w.v23.x, tv);
-      tv = fma(K > 3 ? w.t[3] : (R)0, w.v23.y, tv);
+      tv = fma(row4_get<0>(w.t), w.v01.x, (R)0);
+      tv = fma(K > 1 ? row4_get<1>(w.t) : (R)0, w.v01.y, tv);
+      tv = fma(K > 2 ? row4_get<2>(w.t) : (R)0, w.v23.x, tv);
+      tv = fma(K > 3 ? row4_get<3>(w.t) : (R)0, w.v23.y, tv);
     } else {
       tv = w.r;
     }

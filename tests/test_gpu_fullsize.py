@@ -336,8 +336,8 @@ def test_wide_channel_covariance_forms_agree_at_full_size(dtype):
     """pair_cov_kernel against src_cov_kernel (ASSX_WIDEM_PAIRS=0; the switch is read once per process) at config-4 bins /
     frames with the real 512 ranges, M = 5..8, every weight form (rebuilt from (Tb, V), (N,T), (N,F,T)), each twice: the
     occupancies of the benchmark size (several workgroups per CU in float32 and at M = 5) are not reached by the small
-    cases of test_gpu_widem.py, and a landing race shows as garbage in SOME bins of SOME runs
-    (tools/probes/paircov_check.py is the body)."""
+    cases of test_gpu_widem.py, and a timing-dependent error shows as garbage in SOME bins of SOME runs (round 3: registers
+    of an inline-asm LDS read copied before their wait; tools/probes/paircov_check.py is the body)."""
     import os
     import subprocess
     import sys
