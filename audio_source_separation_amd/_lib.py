@@ -68,6 +68,10 @@ SIGNATURES = {
     "assx_nmf_loss": (_i, [_vp, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_update_ex": (_i, [_vp, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_loss_ex": (_i, [_vp, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_nmf_iterate": (_i, [_vp, _i, _i, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_auxiva_iterate": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _d, _d, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "assx_ilrma_iterate": (_i, [_vp, _i, _i, _i, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _d, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp,
+                                _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ilrma_power_map": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_half_sums": (_i, [_vp, _i, _d, _d, _d, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_nmf_apply_sums": (_i, [_vp, _i, _d, _d, _vp, _vp, _i, _ll, _i, _vp]),

@@ -16,6 +16,7 @@ class LazyLossList(list):
     def __init__(self, iterable=()):
         super().__init__(iterable)
         self._pending = {}  # index -> (device tensor, batched)
+        self._blocks = []   # (first index, (n, B) device tensor, batched): n entries written by one iterate call
         self.before_flush = None  # set by the model: fills device scalars whose computation was deferred
 
     # ---- producers
@@ -23,15 +24,28 @@ class LazyLossList(list):
         self._pending[len(self)] = (tensor, batched)
         super().append(None)
 
+    def append_device_block(self, block, batched):
+        """`block` (n, B) float64 on the device: n consecutive entries written by ONE call that ran n iterations
+        (assx_*_iterate); downloaded in one piece when the list is read."""
+        n = int(block.shape[0])
+        if n:
+            self._blocks.append((len(self), block, batched))
+            super().extend([None] * n)
+
     # ---- materialisation
     def _flush(self):
-        if self._pending:
+        if self._pending or self._blocks:
             if self.before_flush is not None:
                 self.before_flush()
             for idx, (t, batched) in self._pending.items():
                 a = t.detach().cpu().numpy().astype(np.float64)
                 super().__setitem__(idx, a if batched else np.float64(a.reshape(-1)[0]))
             self._pending.clear()
+            for start, block, batched in self._blocks:
+                a = block.detach().cpu().numpy().astype(np.float64)
+                for i in range(a.shape[0]):
+                    super().__setitem__(start + i, a[i].copy() if batched else np.float64(a[i].reshape(-1)[0]))
+            self._blocks = []
 
     def _wrap(name):  # noqa: N805
         def method(self, *args, **kwargs):

@@ -24,14 +24,17 @@ class NMFbase(DeviceState):
 
     _KIND = None
 
-    def __init__(self, n_basis=2, eps=EPS, *, dtype='float64', device=None):
+    def __init__(self, n_basis=2, eps=EPS, *, dtype='float64', device=None, recordable_loss=True):
         """
         Args:
             n_basis: number of basis
+            recordable_loss: extension (the reference always evaluates the criterion after every update,
+                nmf.py:48-53): False skips that pass, `loss` then stays empty.
         """
 
         self.n_basis = n_basis
         self.loss = LazyLossList()  # a list; entries are materialised from HBM on first read
+        self.recordable_loss = recordable_loss
 
         self.eps = eps
         self.domain = 2
@@ -86,16 +89,42 @@ class NMFbase(DeviceState):
     def _kind_param(self):
         return 0.0
 
+    def _fast_loop_ok(self):
+        """The loop of update() as ONE library call (assx_nmf_iterate): the steps are this module's own (a subclass
+        overriding update_once keeps the Python loop) and `loss` is still the list the constructor made."""
+        fn = getattr(type(self).update_once, "__func__", type(self).update_once)
+        return getattr(fn, "__module__", None) == __name__ and type(self).update is NMFbase.update \
+            and isinstance(self.loss, LazyLossList)
+
+    def _record_loss(self):
+        loss = self._engine.nmf_loss(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
+                                     domain=self.domain, eps=self.eps, param=self._kind_param())
+        if isinstance(self.loss, LazyLossList):
+            self.loss.append_device(loss, self._batched)  # no host sync inside the loop
+        else:
+            self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
+
     def update(self, iteration=100):
+        if iteration > 1 and self._fast_loop_ok():
+            # the first update through update_once(): it validates `algorithm` / `domain` and raises exactly what the
+            # reference raises; the remaining ones are enqueued by the library (same entry points, same order)
+            self.update_once()
+            if self.recordable_loss:
+                self._record_loss()
+            eng, n = self._engine, iteration - 1
+            loss = eng.empty((n, int(self._X.shape[0])), dtype=torch.float64) if self.recordable_loss else None
+            eng.nmf_iterate(n, self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
+                            domain=self.domain, eps=self.eps, param=self._kind_param(), loss=loss)
+            self._touch("T", "V")
+            if loss is not None:
+                self.loss.append_device_block(loss, self._batched)
+            return
+
         for idx in range(iteration):
             self.update_once()
 
-            loss = self._engine.nmf_loss(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
-                                         domain=self.domain, eps=self.eps, param=self._kind_param())
-            if isinstance(self.loss, LazyLossList):
-                self.loss.append_device(loss, self._batched)  # no host sync inside the loop
-            else:
-                self.loss.append(to_numpy(loss, np.float64) if self._batched else np.float64(loss.item()))
+            if self.recordable_loss:
+                self._record_loss()
 
     def update_once(self):
         self._engine.nmf_update(self._kind_code(), self._X, self._dev("T", False), self._dev("V", False),
@@ -107,12 +136,12 @@ class EUCNMF(NMFbase):
     """reference: nmf.py:150-207"""
     _KIND = _lib.NMF_EUC
 
-    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None, recordable_loss=True):
         """
         Args:
             n_basis: number of basis
         """
-        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device, recordable_loss=recordable_loss)
 
         assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
         assert algorithm == 'mm', "algorithm must be 'mm'."
@@ -134,12 +163,12 @@ class KLNMF(NMFbase):
     """reference: nmf.py:209-266"""
     _KIND = _lib.NMF_KL
 
-    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None, recordable_loss=True):
         """
         Args:
             K: number of basis
         """
-        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device, recordable_loss=recordable_loss)
 
         assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
         assert algorithm == 'mm', "algorithm must be 'mm'."
@@ -161,13 +190,13 @@ class ISNMF(NMFbase):
     """reference: nmf.py:268-356"""
     _KIND = _lib.NMF_IS_MM
 
-    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+    def __init__(self, n_basis=2, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None, recordable_loss=True):
         """
         Args:
             K: number of basis
             algorithm: 'mm': MM algorithm based update
         """
-        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device, recordable_loss=recordable_loss)
 
         assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
 
@@ -197,13 +226,14 @@ class tNMF(NMFbase):
     """reference: nmf.py:358-429 (Student's t NMF, MM update; domain 2 only)"""
     _KIND = _lib.NMF_T
 
-    def __init__(self, n_basis=2, nu=1e+3, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None):
+    def __init__(self, n_basis=2, nu=1e+3, domain=2, algorithm='mm', eps=EPS, *, dtype='float64', device=None,
+                 recordable_loss=True):
         """
         Args:
             K: number of basis
             algorithm: 'mm': MM algorithm based update
         """
-        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device, recordable_loss=recordable_loss)
 
         assert 1 <= domain <= 2, "1 <= `domain` <= 2 is not satisfied."
 
@@ -230,8 +260,9 @@ class CauchyNMF(NMFbase):
     _ALGORITHMS = {'naive-multipricative': _lib.NMF_CAUCHY_NAIVE, 'mm': _lib.NMF_CAUCHY_MM,
                    'me': _lib.NMF_CAUCHY_ME, 'mm_fast': _lib.NMF_CAUCHY_MM_FAST}
 
-    def __init__(self, n_basis, domain=2, algorithm='naive-multipricative', eps=EPS, *, dtype='float64', device=None):
-        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device)
+    def __init__(self, n_basis, domain=2, algorithm='naive-multipricative', eps=EPS, *, dtype='float64', device=None,
+                 recordable_loss=True):
+        super().__init__(n_basis=n_basis, eps=eps, dtype=dtype, device=device, recordable_loss=recordable_loss)
 
         assert domain == 2, "Only `domain` = 2 is supported."
 

@@ -302,23 +302,29 @@ class GaussILRMA(ILRMAbase):
 
         self._reset(**kwargs)
 
-        if self.recordable_loss:
-            self._record_loss()
-
-        self._run_callbacks()
-
-        for idx in range(iteration):
-            if self.algorithm_spatial in ['pairwise', 'IP2']:
-                self._select_update_pair()
-
-            self.update_once()
-
+        plan = self._fast_loop_plan() if iteration > 0 else None
+        if plan is not None:
+            # no callback has to see the model between iterations: the whole loop is ONE call into the library
+            # (assx_ilrma_iterate enqueues the same entry points in the same order: bit-identical to the loop below)
+            self._run_fast_loop(iteration, plan)
+        else:
             if self.recordable_loss:
                 self._record_loss()
 
             self._run_callbacks()
 
-        self._resolve_deferred_loss()  # the loss of the last iteration has no next pass to ride on
+            for idx in range(iteration):
+                if self.algorithm_spatial in ['pairwise', 'IP2']:
+                    self._select_update_pair()
+
+                self.update_once()
+
+                if self.recordable_loss:
+                    self._record_loss()
+
+                self._run_callbacks()
+
+            self._resolve_deferred_loss()  # the loss of the last iteration has no next pass to ride on
 
         # final projection back (ilrma.py:258-273); scale and y = W x in two small passes over X
         eng = self._engine
@@ -334,6 +340,63 @@ class GaussILRMA(ILRMAbase):
         self.estimation = output
 
         return output
+
+    # ---- the loop of __call__ as one library call (ilrma.py:233-256) ------------------------------------------
+    _OWN_STEPS = ("update_once", "update_source_model", "update_spatial_model", "_record_loss", "_select_update_pair")
+
+    def _fast_loop_plan(self):
+        """dict(normalize=, pb_exponent=) when assx_ilrma_iterate can stand in for the Python loop, else None: nothing
+        observes the model between iterations (no callbacks), the steps are this class's own (a subclass that
+        overrides one keeps the loop), no partitioning function, and a normalisation the entry point knows."""
+        if self.callbacks is not None or self.partitioning:
+            return None
+        if any(getattr(type(self), name) is not getattr(GaussILRMA, name) for name in self._OWN_STEPS):
+            return None
+        if self.recordable_loss and not isinstance(self.loss, LazyLossList):
+            return None
+        if not self.normalize:
+            return dict(normalize=0, pb_exponent=2.0)
+        if self.normalize == 'power' and self.power_statistic == 'covariance':
+            return dict(normalize=1, pb_exponent=2.0)
+        if self.normalize == 'projection-back':
+            return dict(normalize=2, pb_exponent=float(getattr(self, "_pb_basis_exponent", None) or self.domain))
+        return None  # 'direct' power statistic, unknown names (the loop raises what the reference raises)
+
+    def _ensure_plain_covariance(self):
+        """C_f = mean_t x x^H: constant over the iterations, one pass per call; with it the IP kernel emits the per-bin
+        power statistic of the updated filters."""
+        if self._C is None:
+            eng = self._engine
+            B, M, F, _ = self._X.shape
+            self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
+            self._pbins = eng.empty((B, M, F), dtype=torch.float64)
+        return self._C, self._pbins
+
+    def _run_fast_loop(self, iteration, plan):
+        eng = self._engine
+        B, N = int(self._X.shape[0]), self.n_sources
+        spatial, pair = _lib.SPATIAL_IP, (0, 1)
+        if self.algorithm_spatial == 'ISS':
+            spatial = _lib.SPATIAL_ISS
+        elif self.algorithm_spatial in ['pairwise', 'IP2']:
+            self._select_update_pair()  # the pair of the first iteration; the library advances it like ilrma.py:635-646
+            spatial, pair = _lib.SPATIAL_IP2, self.update_pair
+        C = pbins = scale = None
+        if plan["normalize"] == 1:
+            C, pbins = self._ensure_plain_covariance()
+        elif plan["normalize"] == 2:
+            scale = eng.empty((B, N, self.n_bins), complex_=True)
+        loss = eng.empty((iteration + 1, B), dtype=torch.float64) if self.recordable_loss else None
+        eng.ilrma_iterate(iteration, self._X, self._Wd, self._Td, self._Vd, domain=self.domain, eps=self.eps,
+                          threshold=self.threshold, status=self._status, loss=loss, spatial=spatial, pair=pair,
+                          normalize=plan["normalize"], C=C, power_bins=pbins, scale=scale, ref=self.reference_id,
+                          pb_exponent=plan["pb_exponent"])
+        if spatial == _lib.SPATIAL_IP2:
+            self.update_pair = ((pair[0] + iteration - 1) % N, (pair[1] + iteration - 1) % N)
+        self._touch("W", "T", "V")
+        self._estimation = None
+        if loss is not None:
+            self.loss.append_device_block(loss, self._batched)
 
     def _reset(self, **kwargs):
         self._resolve_deferred_loss()
@@ -429,11 +492,7 @@ class GaussILRMA(ILRMAbase):
         eng = self._engine
         C = pbins = None
         if self.normalize == 'power' and (self.power_statistic == 'covariance' or self.partitioning):
-            if self._C is None:  # plain covariance of X: constant over the iterations, one pass per call
-                B, M, F, _ = self._X.shape
-                self._C = eng.cov_accumulate(self._X).reshape(B, F, M, M)
-                self._pbins = eng.empty((B, M, F), dtype=torch.float64)
-            C, pbins = self._C, self._pbins
+            C, pbins = self._ensure_plain_covariance()
         spatial, pair = _lib.SPATIAL_IP, (0, 1)
         if self.algorithm_spatial == 'ISS':
             spatial = _lib.SPATIAL_ISS
@@ -521,6 +580,15 @@ class ConsistentGaussILRMA(GaussILRMA):
         s += ")"
 
         return s.format(**self.__dict__)
+
+    def _fast_loop_plan(self):
+        if type(self) is not ConsistentGaussILRMA or self.callbacks is not None or self.partitioning:
+            return None
+        if self.n_bins != self.fft_size // 2 + 1 or self.normalize:
+            return None  # the loop raises / does whatever update_once does
+        if self.recordable_loss and not isinstance(self.loss, LazyLossList):
+            return None
+        return dict(normalize=2, pb_exponent=2.0)  # update_once below, every iteration
 
     def update_once(self):
         if self.n_bins != self.fft_size // 2 + 1:

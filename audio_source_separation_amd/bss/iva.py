@@ -212,25 +212,30 @@ class AuxIVAbase(IVAbase):
 
         self._reset(**kwargs)
 
-        if self.recordable_loss:
-            self._record_loss()
-
-        if self.callbacks is not None:
-            for callback in self.callbacks:
-                callback(self)
-
-        for idx in range(iteration):
-            if self.algorithm_spatial in ['pairwise', 'IP2']:
-                self._select_update_pair()
-
-            self.update_once()
-
+        if iteration > 0 and self._fast_loop_ok():
+            # nothing observes the model between iterations: the whole loop is ONE call into the library
+            # (assx_auxiva_iterate enqueues the same entry points in the same order: bit-identical to the loop below)
+            self._run_fast_loop(iteration)
+        else:
             if self.recordable_loss:
                 self._record_loss()
 
             if self.callbacks is not None:
                 for callback in self.callbacks:
                     callback(self)
+
+            for idx in range(iteration):
+                if self.algorithm_spatial in ['pairwise', 'IP2']:
+                    self._select_update_pair()
+
+                self.update_once()
+
+                if self.recordable_loss:
+                    self._record_loss()
+
+                if self.callbacks is not None:
+                    for callback in self.callbacks:
+                        callback(self)
 
         eng = self._engine
         scale = None
@@ -247,6 +252,43 @@ class AuxIVAbase(IVAbase):
         self.estimation = output
 
         return output
+
+    # ---- the loop of __call__ as one library call (iva.py:420-441) ---------------------------------------------
+    _OWN_STEPS = ("update_once", "update_once_ip", "update_once_iss", "update_once_pairwise", "_spatial_update",
+                  "_record_loss", "_refresh_weights", "_select_update_pair")
+
+    def _fast_loop_ok(self):
+        if self.callbacks is not None or self._KIND is None:
+            return False
+        if any(getattr(type(self), name) is not getattr(AuxIVAbase, name) for name in self._OWN_STEPS):
+            return False
+        if self.recordable_loss and not isinstance(self.loss, LazyLossList):
+            return False
+        return self.algorithm_spatial in ('IP', 'IP1', 'ISS', 'pairwise', 'IP2')
+
+    def _run_fast_loop(self, iteration):
+        eng = self._engine
+        B, N, T = int(self._X.shape[0]), self.n_sources, self.n_frames
+        spatial, pair = _lib.SPATIAL_IP, (0, 1)
+        if self.algorithm_spatial == 'ISS':
+            spatial = _lib.SPATIAL_ISS
+        elif self.algorithm_spatial in ['pairwise', 'IP2']:
+            self._require_supported()
+            self._select_update_pair()  # the pair of the first iteration; the library advances it like iva.py:370-382
+            spatial, pair = _lib.SPATIAL_IP2, self.update_pair
+        r = eng.empty((B, N, T))
+        loss = eng.empty((iteration + 1, B), dtype=torch.float64) if self.recordable_loss else None
+        eng.auxiva_iterate(iteration, self._KIND, self._X, self._Wd, r, eps=self.eps, threshold=self.threshold,
+                           status=self._status, loss=loss, spatial=spatial, pair=pair)
+        if spatial == _lib.SPATIAL_IP2:
+            self.update_pair = ((pair[0] + iteration - 1) % N, (pair[1] + iteration - 1) % N)
+        self._touch("W")
+        self._estimation = None
+        if loss is not None:  # r and the last loss entry belong to the final filters
+            self._r, self._r_src, self._loss_dev = r, self._Wd, loss[iteration]
+            self.loss.append_device_block(loss, self._batched)
+        else:
+            self._r = self._loss_dev = None
 
     def __repr__(self):
         s = self._NAME + "("

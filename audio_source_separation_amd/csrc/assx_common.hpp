@@ -22,11 +22,22 @@ struct assx_ctx {
   unsigned stream_pass;
   // pinned staging ring + host thread pool of assx_upload / assx_download (csrc/assx_xfer.hip), created on first use
   void* xfer;
+  // zeroed device words for the "last workgroup done" tickets of kernels that fold their finalize step (assx_common.hpp:
+  // take_ticket); grown on demand by ensure_tickets(), outgrown buffers are kept until the context is destroyed
+  // (launches that still use them may be in flight)
+  int* tickets;
+  size_t n_tickets;
+  void* old_tickets[16];
+  int n_old_tickets;
 };
 
 namespace assx {
 
 void xfer_destroy(assx_ctx* ctx);  // csrc/assx_xfer.hip
+// at least n zeroed ticket words, zeroing ordered on `st` before the caller's launch (csrc/assx_api.hip); nullptr + error
+// message on failure.  Kernels leave the words zero, so the buffer is only ever cleared when it is (re)allocated.
+int* ensure_tickets(assx_ctx* ctx, size_t n, hipStream_t st);
+void tickets_destroy(assx_ctx* ctx);
 
 struct NmfGroupScope {  // sets assx_ctx::nmf_group for the NMF calls made inside the scope
   assx_ctx* c;
@@ -397,6 +408,37 @@ __device__ __forceinline__ float uniform_value(float v) {
 template <typename R>
 __device__ __forceinline__ R floor_eps(R v, R eps) {  // numpy: v[v < eps] = eps (NaN stays NaN)
   return (v < eps) ? eps : v;
+}
+
+// ------------------------------------------------------------------------------------------
+// "last workgroup done": folding a finalize step into the kernel that produces its partial records.
+// The workgroups of a group publish their records with agent-scope (sc1, write-through) stores, wait for them
+// (s_waitcnt vmcnt(0)), take a ticket with an agent-scope atomic; the holder of the last ticket reads every record of
+// the group back with agent-scope loads, in a fixed order, and applies the update.  No L2-wide fence is involved (an
+// agent-scope __threadfence() on gfx950 writes back and invalidates the XCD's whole L2); protocol probed across XCDs in
+// tools/probes/ticket_probe.hip (mode 2).  Tickets live in a zeroed buffer owned by the context (assx_ctx::tickets) and
+// are reset by the last holder, so the buffer is all zeros again when the kernel ends.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__device__ __forceinline__ void st_agent(R* p, R v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename R>
+__device__ __forceinline__ R ld_agent(const R* p) {
+  return __hip_atomic_load(const_cast<R*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Called by every lane of the wave that stored the records; returns (to every lane) whether this workgroup holds the
+// last of `members` tickets.
+__device__ __forceinline__ bool take_ticket(int* ticket, int members) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  int last = 0;
+  if ((threadIdx.x & (WAVE - 1)) == 0) {
+    last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1;
+    if (last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return __builtin_amdgcn_readfirstlane(last) != 0;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -10,6 +10,8 @@
 //                      activ. num|den = Tb^T [A|Bm]  (reduce over f)
 //   (3) finalize     : sum the split-K slabs, floor the denominator, multiply-update in place.
 // The GEMM is an LDS-tiled 64x64x16 register-blocked kernel in the storage precision.
+// That three-step form is the fallback for n_basis > 64; up to 64 a half-update is ONE matrix-core kernel
+// (assx_nmf_mfma.hpp) that also finalizes its output behind a "last workgroup done" ticket.
 #include <cstdlib>
 #include "assx_common.hpp"
 #include "assx_nmf_mfma.hpp"
@@ -318,22 +320,23 @@ inline int nmf_env_int(const char* name, int dflt) {
 // split counts of the MFMA path (deterministic: no device query)
 inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ? ctx->nmf_group : 1; }
 
-// `group` = matrices per independent problem (assx_ctx::nmf_group), NOT the batch size: the slab count must not
-// depend on how many problems share the launch
-inline void mfma_basis_split(int group, int F, int T, int* TS, int* tchunk) {
-  const int fg = (F + 63) / 64;
-  const int wgs = nmf_env_int("ASSX_NMF_BASIS_WGS", 512);
-  int ts = (wgs + fg * group - 1) / (fg * group);  // one resident round; fewer slabs for the finalize
-  const int max_ts = (T + 63) / 64;
-  if (ts > max_ts) ts = max_ts;
-  if (ts < 1) ts = 1;
-  int chunk = ((T + ts - 1) / ts + 15) / 16 * 16;
-  *tchunk = chunk;
-  *TS = (T + chunk - 1) / chunk;
+// Work partitions of the two matrix-core half kernels (assx_nmf_mfma.hpp: NmfPart).  `group` = matrices per independent
+// problem (assx_ctx::nmf_group), NOT the batch size: the partition must not depend on how many problems share the
+// launch.  The workgroup budget is a constant of the MI355X geometry (256 CUs), so that no summation order depends
+// on a runtime occupancy query.
+constexpr int MFMA_WG_BUDGET = 512;  // two workgroups per CU (profiles/r04_nmf_wgs_sweep.txt)
+template <typename R>
+inline NmfPart mfma_basis_part(int group, int F, int T, int KT) {
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET));
 }
-inline void mfma_act_split(int group, int F, int T, int* FS, int* fchunk) {
+template <typename R>
+inline NmfPart mfma_act_part(int group, int F, int T, int KT) {
+  return make_nmf_part((T + 15) / 16, (F + 15) / 16, group, nmf_env_int("ASSX_NMF_ACT_WGS", MFMA_WG_BUDGET));
+}
+// split-F slabs of the loss kernel
+inline void mfma_loss_split(int group, int F, int T, int* FS, int* fchunk) {
   const int tg = (T + 15) / 16;
-  const int wgs = nmf_env_int("ASSX_NMF_ACT_WGS", 1024);
+  const int wgs = 1024;
   int fs = (wgs + tg * group - 1) / (tg * group);
   const int max_fs = (F + 63) / 64;
   if (fs > max_fs) fs = max_fs;
@@ -373,12 +376,14 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   size_t pmax = sb * 2 * B * F * K;
   if (sa * 2 * B * K * T > pmax) pmax = sa * 2 * B * K * T;
   {
-    int TS, tchunk, FS, fchunk;
-    mfma_basis_split(1, F, T, &TS, &tchunk);
-    mfma_act_split(1, F, T, &FS, &fchunk);
-    if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
-    if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
+    // matrix-core halves: group = 1 has the most workgroups per matrix, hence the most slabs per block
+    const int KTv = (K + 15) / 16;
+    const NmfPart pb = dtype == ASSX_F64 ? mfma_basis_part<double>(1, F, T, KTv) : mfma_basis_part<float>(1, F, T, KTv);
+    const NmfPart pa = dtype == ASSX_F64 ? mfma_act_part<double>(1, F, T, KTv) : mfma_act_part<float>(1, F, T, KTv);
+    if ((size_t)pb.maxslots * 2 * B * F * K > pmax) pmax = (size_t)pb.maxslots * 2 * B * F * K;
+    if ((size_t)pa.maxslots * 2 * B * K * T > pmax) pmax = (size_t)pa.maxslots * 2 * B * K * T;
     if (K <= SMALL_K) {  // small-rank kernels; group = 1 gives the most slabs
+      int TS, tchunk, FS, fchunk;
       small_splits(1, small_kc(K), F, T, &TS, &tchunk, &FS, &fchunk);
       if ((size_t)TS * 2 * B * F * K > pmax) pmax = (size_t)TS * 2 * B * F * K;
       if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
@@ -388,7 +393,7 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   w.lpart = off;
   {
     int FS, fchunk;
-    mfma_act_split(1, F, T, &FS, &fchunk);
+    mfma_loss_split(1, F, T, &FS, &fchunk);
     size_t nl = (size_t)B * F * ((T + 255) / 256);
     if ((size_t)B * FS * ((T + 15) / 16) > nl) nl = (size_t)B * FS * ((T + 15) / 16);
     off += align_up(nl * 8, 256);
@@ -397,7 +402,8 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   return w;
 }
 
-// matrix-core path (n_basis <= 64): two chained-MFMA kernels + the split finalize
+// matrix-core path (n_basis <= 64): two chained-MFMA kernels, each finalizing its own output behind a ticket
+// (assx_nmf_mfma.hpp) -- one update is 2 launches (4 until round 3)
 template <typename R, int KT>
 int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st) {
@@ -405,24 +411,21 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   R* part = (R*)((char*)ws + L.part);
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
-  int TS, tchunk, FS, fchunk;
-  mfma_basis_split(nmf_group(ctx), F, T, &TS, &tchunk);
-  mfma_act_split(nmf_group(ctx), F, T, &FS, &fchunk);
+  const NmfPart pb = mfma_basis_part<R>(nmf_group(ctx), F, T, KT), pa = mfma_act_part<R>(nmf_group(ctx), F, T, KT);
+  int* tickets = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st);
+  if (!tickets) return ASSX_E_UNSUPPORTED;
   const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
-  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X, \
-                     (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts)
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X,      \
+                     (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe)
 #define NMF_ACT(D2K)                                                                                           \
-  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3((T + 15) / 16, FS, B), dim3(256), 0, st, (const R*)X,   \
-                     (const R*)Tb, (const R*)V, part, B, F, T, K, fchunk, (R)eps, ts)
+  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pa.G, 1, B), dim3(256), 0, st, (const R*)X,         \
+                     (const R*)Tb, (R*)V, part, tickets, 1, pa, B, F, T, K, (R)eps, ts, pe)
   if (d2 && kind == ASSX_NMF_EUC) NMF_BASIS(ASSX_NMF_EUC);
   else if (d2 && kind == ASSX_NMF_KL) NMF_BASIS(ASSX_NMF_KL);
   else if (d2) NMF_BASIS(ASSX_NMF_IS_MM);
   else NMF_BASIS(-1);
   ASSX_LAUNCH_CHECK(ctx, "nmf_basis_mfma_kernel");
-  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * F * K, 64)), dim3(256), 0, st, (const R*)part,
-                     (R*)Tb, B, (size_t)F * K, TS, (R)eps, pe);
-  ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(basis)");
   if (d2 && kind == ASSX_NMF_EUC) NMF_ACT(ASSX_NMF_EUC);
   else if (d2 && kind == ASSX_NMF_KL) NMF_ACT(ASSX_NMF_KL);
   else if (d2) NMF_ACT(ASSX_NMF_IS_MM);
@@ -430,9 +433,6 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
 #undef NMF_BASIS
 #undef NMF_ACT
   ASSX_LAUNCH_CHECK(ctx, "nmf_act_mfma_kernel");
-  hipLaunchKernelGGL((nmf_finalize_kernel<R>), dim3(nblocks((size_t)B * K * T, 64)), dim3(256), 0, st, (const R*)part,
-                     (R*)V, B, (size_t)K * T, FS, (R)eps, pe);
-  ASSX_LAUNCH_CHECK(ctx, "nmf_finalize_kernel(activation)");
   return 0;
 }
 
@@ -480,7 +480,9 @@ int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
   if (K <= small_rank_max() && kind == ASSX_NMF_IS_MM && domain == 2.0 && !no_mfma)
     return nmf_update_small<R>(ctx, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-  if (K <= NMF_MFMA_MAX_K && !no_mfma) {
+  // the matrix-core kernels address a matrix with 32-bit byte offsets
+  const bool fits32 = (unsigned long long)F * T * sizeof(R) < (1ull << 32) && (unsigned long long)K * T * sizeof(R) < (1ull << 32);
+  if (K <= NMF_MFMA_MAX_K && !no_mfma && fits32) {
     switch ((K + 15) / 16) {
       case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
       case 2: return nmf_update_mfma<R, 2>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
@@ -570,17 +572,18 @@ namespace assx {
 template <typename R, int KT>
 static int nmf_half_launch(assx_ctx* ctx, const TermSpec& ts, int half, const void* X, const void* Tb, const void* V,
                            R* part, int B, int F, int T, int K, double eps, hipStream_t st, int* slabs) {
-  int TS, tchunk, FS, fchunk;
-  mfma_basis_split(nmf_group(ctx), F, T, &TS, &tchunk);
-  mfma_act_split(nmf_group(ctx), F, T, &FS, &fchunk);
   if (half == NMF_HALF_BASIS) {
-    hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, -1>), dim3((F + 63) / 64, TS, B), dim3(256), 0, st, (const R*)X,
-                       (const R*)Tb, (const R*)V, part, B, F, T, K, tchunk, (R)eps, ts);
-    *slabs = TS;
+    const NmfPart pb = mfma_basis_part<R>(nmf_group(ctx), F, T, KT);
+    hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, -1>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X,
+                       (R*)const_cast<void*>(Tb), (const R*)V, part, (int*)nullptr, 0, pb, B, F, T, K, (R)eps, ts,
+                       make_pow(1.0));
+    *slabs = pb.maxslots;  // unused slabs of a block are cleared by the kernel
   } else {
-    hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, -1>), dim3((T + 15) / 16, FS, B), dim3(256), 0, st, (const R*)X,
-                       (const R*)Tb, (const R*)V, part, B, F, T, K, fchunk, (R)eps, ts);
-    *slabs = FS;
+    const NmfPart pa = mfma_act_part<R>(nmf_group(ctx), F, T, KT);
+    hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, -1>), dim3(pa.G, 1, B), dim3(256), 0, st, (const R*)X,
+                       (const R*)Tb, (R*)const_cast<void*>(V), part, (int*)nullptr, 0, pa, B, F, T, K, (R)eps, ts,
+                       make_pow(1.0));
+    *slabs = pa.maxslots;
   }
   ASSX_LAUNCH_CHECK(ctx, "nmf half kernel");
   return 0;
@@ -590,6 +593,8 @@ int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, doub
                       const void* Tb, const void* V, void* ws, int B, int F, int T, int K, int dtype, hipStream_t st,
                       const void** part, int* slabs) {
   if (K > NMF_MFMA_MAX_K) return fail(ctx, ASSX_E_UNSUPPORTED, "nmf_half_partials: n_basis %d > %d", K, NMF_MFMA_MAX_K);
+  if ((unsigned long long)F * T * 8 >= (1ull << 32) || (unsigned long long)K * T * 8 >= (1ull << 32))
+    return fail(ctx, ASSX_E_UNSUPPORTED, "nmf_half_partials: one matrix must stay below 4 GiB (F = %d, T = %d)", F, T);
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   const TermSpec ts = make_terms(kind, domain, param);
   void* p = (char*)ws + L.part;
@@ -735,7 +740,7 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
   if (K <= NMF_MFMA_MAX_K && !no_mfma) {
     int FS, fchunk;
-    mfma_act_split(nmf_group(ctx), F, T, &FS, &fchunk);
+    mfma_loss_split(nmf_group(ctx), F, T, &FS, &fchunk);
     const dim3 g2((T + 15) / 16, FS, B);
 #define NMF_LOSS_LAUNCH(RT, KTV)                                                                                 \
   hipLaunchKernelGGL((nmf_loss_mfma_kernel<RT, KTV>), g2, dim3(256), 0, st, (const RT*)X, (const RT*)Tb,          \

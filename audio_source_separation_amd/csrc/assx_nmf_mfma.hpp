@@ -14,11 +14,6 @@
 #pragma once
 #include "assx_common.hpp"
 
-#ifndef NMF_SKIP
-#define NMF_SKIP 0  // timing experiments only (tools/probes/nmf_parts.sh; results are wrong by construction): 1 product (1),
-                    // 2 element terms, 4 product (3), 8 X loads, 16 operand-tile loads and staging
-#endif
-
 namespace assx {
 
 typedef double v4d_t __attribute__((ext_vector_type(4)));
@@ -32,7 +27,7 @@ struct Mfma16<double> {
   static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
     return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
   }
-  static __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) + 4 * r; }
+  static constexpr __host__ __device__ __forceinline__ int crow(int r, int lane) { return (lane >> 4) + 4 * r; }
 };
 template <>
 struct Mfma16<float> {
@@ -40,7 +35,7 @@ struct Mfma16<float> {
   static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
   }
-  static __device__ __forceinline__ int crow(int r, int lane) { return 4 * (lane >> 4) + r; }
+  static constexpr __host__ __device__ __forceinline__ int crow(int r, int lane) { return 4 * (lane >> 4) + r; }
 };
 
 struct TermSpec {
@@ -112,349 +107,509 @@ __device__ __forceinline__ void nmf_terms(const TermSpec& s, R x, R tv, R eps, R
   }
 }
 
+// the multiplicative step of one element (nmf.py:317, 325 etc.); same arithmetic as nmf_finalize_kernel
+template <typename R, int D2K>
+__device__ __forceinline__ R nmf_apply(R old, R num, R den, R eps, PowSpec p) {
+  if (D2K < 0 && p.mode == POW_CAUCHY_ME) {  // num = B, den = A  (nmf.py:550-552)
+    const R d2 = floor_eps<R>(den + sqrt(fma(den, den, (R)2 * num * den)), eps);
+    return old * (num / d2);
+  }
+  den = floor_eps<R>(den, eps);
+  const R q = num / den;
+  // domain 2, EUC / KL / IS: the exponent is 1 or 1/2 -- keeps pow() (and its ~70 VGPRs) out of those instantiations
+  if (D2K >= 0) return old * (p.mode == POW_SQRT ? sqrt(q) : q);
+  return old * powspec<R>(q, p);
+}
+
+// sum of S slab entries `stride` apart, in the strand order of nmf_finalize_kernel: strand q adds s = q, q + 4, ...;
+// the strands are combined as (0 + 1) + (2 + 3).  Agent-scope loads: the slabs were written by other workgroups of
+// this launch (assx_common.hpp: take_ticket).
+template <typename R>
+__device__ __forceinline__ R slab_sum4(const R* p, size_t stride, int S) {
+  R q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+  int s = 0;
+  for (; s + 4 <= S; s += 4) {
+    const R a = ld_agent(p + (size_t)s * stride), b = ld_agent(p + (size_t)(s + 1) * stride),
+            c = ld_agent(p + (size_t)(s + 2) * stride), d = ld_agent(p + (size_t)(s + 3) * stride);
+    q0 += a;
+    q1 += b;
+    q2 += c;
+    q3 += d;
+  }
+  if (s < S) q0 += ld_agent(p + (size_t)s * stride);
+  if (s + 1 < S) q1 += ld_agent(p + (size_t)(s + 1) * stride);
+  if (s + 2 < S) q2 += ld_agent(p + (size_t)(s + 2) * stride);
+  return (q0 + q1) + (q2 + q3);
+}
+
 // ---------------------------------------------------------------------------------------------------------
-// basis half: num|den (F,K) = [A|Bm] (F,T) . V^T, reduced over this workgroup's frame range.
-//   grid (ceil(F/64), TS, B), 4 waves, wave w owns bins f0 = (4*blockIdx.x + w)*16 .. +15.
-//   part[ts][b*2 + s][f*K + k]
-// NS sub-tiles (of 16 frames) may advance TOGETHER through the three products (sub-tile s accumulates into its own
-// num/den set, the sets are added in ascending s at the end).  Measured in round 3 and NOT used (NS = 1 everywhere): the
-// parts of a trip add up -- tools/probes/nmf_parts.sh: compiling out any one part saves only its own share,
-// profiles/r03_nmf_parts.txt -- and a dependent v_mfma_f64_16x16x4 issues ~184 cycles after its predecessor while the pipe
-// takes one every 64-80, so twin chains looked like the cure; but NS = 2 costs 288 registers at n_basis 32 (176 at
-// n_basis <= 16): one wave per SIMD, one workgroup per CU, i.e. a second round of workgroups -- config 2 took 123 us
-// instead of 66, the n_basis 10 ILRMA source update 232 us instead of 200.
+// Work partition of the two half kernels (round 4).  One matrix = nblk output blocks (basis half: 16 bins; activation
+// half: 16 frames) x nstep wave-steps (16-frame / 16-bin sub-tiles the block's sums run over).  The nblk * nstep steps
+// are cut into G contiguous ranges of equal length (+-1), one per workgroup; the 4 waves of a workgroup take the steps
+// of its range in turn.  F = 1025 against 256 CUs quantises badly in any (block, slab) grid -- round 3: 17 x 30 = 510
+// workgroups of 9 steps per wave, 18 steps per SIMD where 16.25 is the mean -- and the matrix-core kernels are bound by
+// the issue slots of a SIMD, so what a SIMD gets beyond the mean is the kernel's tail.
+// Measured (profiles/r04_nmf_wgs_sweep.txt): the update takes the same 61 us at config 2 for every budget that is a
+// multiple of the 256 CUs, 256 to 1024 workgroups, i.e. one to four waves per SIMD -- a SIMD spends ~3700 cycles per
+// step whoever issues it, and the fixed part of a launch (prologue, combine, ticket round trips) replaces what the
+// finalize launches cost; budgets that leave some CUs a workgroup more than others lose 5-10 %.
+// A range that crosses a block boundary finishes one block and starts the next; the workgroups whose ranges meet a
+// block are its GROUP: member i writes slab i of the block's records, and (apply != 0) the member that takes the last
+// ticket sums the slabs in ascending order and applies the multiplicative step -- the finalize launches of rounds 1-3
+// are gone.  G, hence every summation order, is a function of one matrix's geometry and the group size (assx_ctx::
+// nmf_group) only, never of the batch.
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT, int D2K = -1, int NS = 1>
+struct NmfPart {
+  int nblk, nstep, G, maxslots;
+};
+// 32-bit arithmetic: make_nmf_part guarantees (nblk * nstep + 1) * G < 2^32 (a matrix below 4 GiB has < 2^22 steps)
+__host__ __device__ inline unsigned nmf_part_lo(const NmfPart& p, int g) {
+  return (unsigned)g * ((unsigned)p.nblk * (unsigned)p.nstep) / (unsigned)p.G;
+}
+// the workgroup whose range holds step x (inverse of nmf_part_lo)
+__host__ __device__ inline int nmf_part_owner(const NmfPart& p, unsigned x) {
+  return (int)(((x + 1u) * (unsigned)p.G - 1u) / ((unsigned)p.nblk * (unsigned)p.nstep));
+}
+inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
+  NmfPart p;
+  p.nblk = nblk;
+  p.nstep = nstep;
+  const long long wt = (long long)nblk * nstep;
+  long long G = target_wgs / (group < 1 ? 1 : group);
+  if (G > (long long)nblk * 16) G = (long long)nblk * 16;  // at most ~16 slabs for the holder of the last ticket to sum
+  if (G > wt / 4) G = wt / 4;  // every wave gets a step (a 513 x 256 matrix: 132 workgroups of one step per wave; one
+                               // workgroup per block with 4 steps per wave and no tickets at all measured slower)
+  if (G > wt) G = wt;
+  while (G > 1 && (wt + 1) * G >= (1ll << 32)) G /= 2;  // 32-bit partition arithmetic in the kernels
+  if (G < 1) G = 1;
+  p.G = (int)G;
+  const long long per = wt / G;  // shortest range
+  p.maxslots = (int)((nstep + per - 1) / per) + 1;
+  return p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// basis half: num|den (F,K) = [A|Bm] (F,T) . V^T.   grid (G, 1, B), 4 waves; block = 16 bins, step = 16 frames.
+//   part[slab][b*2 + s][f*K + k]
+// ---------------------------------------------------------------------------------------------------------
+template <typename R, int KT, int D2K = -1>
 __global__ void __launch_bounds__(256)
-    nmf_basis_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
-                          R* __restrict__ part, int B, int F, int T, int K, int tchunk, R eps, TermSpec s) {
+    nmf_basis_mfma_kernel(const R* __restrict__ X, R* Tb, const R* __restrict__ V, R* part, int* tickets, int apply,
+                          NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe) {
   using MM = Mfma16<R>;
   using acc_t = typename MM::acc_t;
   constexpr int KS = KT * 4;      // k-slices of 4 in product (1)
   constexpr int KP = KT * 16;     // n_basis padded to the tile
   constexpr int LD = 17;          // padded row of the staged tile (bank-conflict-free column reads)
   constexpr int NLD = KP * 16 / 64;  // staged elements per lane and sub-tile
-  // The V tile (KP x 16 frames) is read in two layouts -- as A operand of (1) and as B operand of (3).  Each wave
-  // stages it once through its private LDS slice with coalesced 128-byte row reads instead of issuing 16 narrow
-  // global loads per sub-tile (the CU's single L1 pipe made the first version load-issue bound).
-  __shared__ R vt[4][NS][KP][LD];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // The V tile (KP x 16 frames) of a sub-tile is read in two layouts -- as A operand of (1) and as B operand of (3).
+  // Each wave stages it once through its private LDS slice with coalesced 128-byte row reads.  At the end of a block
+  // the same memory carries the cross-wave combine.
+  constexpr int VT_ELEMS = 4 * KP * LD, RED_ELEMS = 3 * KT * 8 * 64;
+  __shared__ R smem[VT_ELEMS > RED_ELEMS ? VT_ELEMS : RED_ELEMS];
+  __shared__ int s_last;
+  // wave index as a scalar: loop counters, base pointers and the fast-path tests below then live on the scalar unit
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int b = blockIdx.z, ts = blockIdx.y;
-  const int f0 = (blockIdx.x * 4 + wv) * 16;
-  if (f0 >= F) return;  // no workgroup barriers in this kernel (LDS slices are wave-private)
-  const bool fvalid = f0 + li < F;
-  const int f = fvalid ? f0 + li : F - 1;
-  const R* xrow = X + ((size_t)b * F + f) * T;
+  const int b = blockIdx.z, g = blockIdx.x;
+  R(*vt)[LD] = reinterpret_cast<R(*)[LD]>(smem + wv * KP * LD);
+  R(*red)[KT * 8][64] = reinterpret_cast<R(*)[KT * 8][64]>(smem);
   const R* vb = V + (size_t)b * K * T;
+  const R* xb = X + (size_t)b * F * T;
+  const size_t FK = (size_t)F * K;
+  // staged element e = i*64 + lane -> row k = 4 i + lk, frame t0 + li (16 lanes cover one 128-byte row segment).
+  // Rows K .. KP-1 read row K-1 instead: they meet zeros of tb in (1) and output columns that are never written in
+  // (3), so neither a select nor a branch is needed (until round 3 every k-slice sat behind a wave-uniform
+  // `4 j < n_basis` test: a chain of scalar branches that serialised read - wait - MFMA per slice).  Addresses =
+  // descriptor + wave-uniform offset (advances with t0) + a per-lane byte offset fixed for the whole kernel (raw buffer
+  // loads): no address arithmetic on the vector ALU inside the loop.  One matrix stays below 4 GiB (checked by the host).
+  unsigned voff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) voff[i] = (unsigned)((min(4 * i + lk, K - 1) * (size_t)T + li) * sizeof(R));
+  constexpr int XSTEP = MM::crow(1, 0) - MM::crow(0, 0);  // frames between consecutive accumulator registers
+  const BufRsrc vrs = make_rsrc(vb), xrs = make_rsrc(xb);
 
-  R tb[KS];  // B operand of product (1): Tb^T[k = 4j + lk][f]
+  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
+    const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
+    const int s0 = lo > base ? (int)(lo - base) : 0;
+    const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
+    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int slot = g - gf;
+    const int f0 = blk * 16;
+    const int f = min(f0 + li, F - 1);  // rows past F feed only output rows that are never written
+    const unsigned xoff = (unsigned)(((size_t)f * T + MM::crow(0, lane)) * sizeof(R));
+
+    R tb[KS];  // B operand of product (1): Tb^T[k = 4j + lk][f]
 #pragma unroll
-  for (int j = 0; j < KS; ++j) {
-    const int k = 4 * j + lk;
-    tb[j] = (k < K) ? Tb[((size_t)b * F + f) * K + k] : (R)0;
-  }
-  acc_t num[NS][KT], den[NS][KT];
-#pragma unroll
-  for (int q = 0; q < NS; ++q)
+    for (int j = 0; j < KS; ++j) {
+      const int k = 4 * j + lk;
+      tb[j] = (k < K) ? Tb[((size_t)b * F + f) * K + k] : (R)0;
+    }
+    acc_t num[KT], den[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        num[q][c][r] = 0;
-        den[q][c][r] = 0;
+        num[c][r] = 0;
+        den[c][r] = 0;
       }
-
-  const int ta = ts * tchunk;
-  const int te = min(T, ta + tchunk);
-  // staged element e = i*64 + lane  ->  row k = e / 16, frame t0 + e % 16 (16 lanes cover one 128-byte row segment)
-  R stage[NS][NLD];
-  R xq[NS][4];  // X of the next sub-tiles, in the accumulator layout (HBM latency hidden behind the current ones)
-  auto fetch = [&](int t0) {
+    const int te = min(T, s1 * 16);
+    R stage[NLD];
+    R xq[4];  // X of the next sub-tile, in the accumulator layout (HBM latency hidden behind the current one)
+    auto fetch = [&](int t0) {
+      if (t0 + 16 <= T) {  // whole sub-tile inside the matrix (wave-uniform)
+        const unsigned soff = (unsigned)t0 * (unsigned)sizeof(R);
 #pragma unroll
-    for (int q = 0; q < NS; ++q) {
+        for (int i = 0; i < NLD; ++i) stage[i] = buf_ld<R>(vrs, voff[i], soff);
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int e = i * 64 + lane;
-        const int k = e >> 4, tt = min(t0 + 16 * q + (e & 15), T - 1);
-        stage[q][i] = (NMF_SKIP & 16) ? (R)0.5 : ((k < K) ? vb[(size_t)k * T + tt] : (R)0);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        xq[q][r] = (NMF_SKIP & 8) ? (R)1 : xrow[min(t0 + 16 * q + MM::crow(r, lane), T - 1)];
-    }
-  };
-  fetch(ta);
-  for (int t0 = ta; t0 < te; t0 += 16 * NS) {
-    R xc[NS][4];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xc[q][r] = xq[q][r];
-    if (!(NMF_SKIP & 16)) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
+        for (int r = 0; r < 4; ++r) xq[r] = buf_ld<R>(xrs, xoff + r * XSTEP * (unsigned)sizeof(R), soff);
+      } else {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
           const int e = i * 64 + lane;
-          vt[wv][q][e >> 4][e & 15] = stage[q][i];
+          const int k = min(e >> 4, K - 1), tt = min(t0 + (e & 15), T - 1);
+          stage[i] = vb[(size_t)k * T + tt];
         }
-    }
-    if (t0 + 16 * NS < te) fetch(t0 + 16 * NS);  // the next tiles travel while these are consumed
-    __builtin_amdgcn_wave_barrier();
-    // (1) TV^T sub-tiles: rows = frames t0 + 16 q + crow, columns = bins f0 + li; the NS chains alternate
-    acc_t tv[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
+        for (int r = 0; r < 4; ++r) xq[r] = xb[(size_t)f * T + min(t0 + MM::crow(r, lane), T - 1)];
+      }
+    };
+    auto compute = [&](auto masked, int t0, const R (&xc)[4]) {
+      // (1) TV^T sub-tile: rows = frames t0 + crow, columns = bins f0 + li
+      acc_t tv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tv[q][r] = 0;
+      for (int r = 0; r < 4; ++r) tv[r] = 0;
 #pragma unroll
-    for (int j = 0; j < KS; ++j)
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
-        if (4 * j < K && !(NMF_SKIP & 1))
-          tv[q] = MM::mma(vt[wv][q][4 * j + lk][li], tb[j], tv[q]);  // A operand: V^T[t = li][k]; all-padding k-slices skipped
-    if (NMF_SKIP & 1)
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tv[q][r] = xc[q][r] + (R)1;
-    // (2) elementwise in the accumulator layout
-    R a[NS][4], bm[NS][4];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
+      for (int j = 0; j < KS; ++j) tv = MM::mma(vt[4 * j + lk][li], tb[j], tv);  // A operand: V^T[t = li][k]
+      // (2) elementwise in the accumulator layout
+      R a[4], bm[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int t = t0 + 16 * q + MM::crow(r, lane);
-        if (NMF_SKIP & 2) {
-          a[q][r] = xc[q][r];
-          bm[q][r] = tv[q][r];
-        } else
-          nmf_terms<R, D2K>(s, xc[q][r], tv[q][r], eps, a[q][r], bm[q][r]);
-        if (!(fvalid && t < te)) {
-          a[q][r] = 0;
-          bm[q][r] = 0;
+        nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
+        if (decltype(masked)::value && t0 + MM::crow(r, lane) >= T) {  // ragged last sub-tile of the matrix only
+          a[r] = 0;
+          bm[r] = 0;
         }
       }
-    // (3) num[f, kb] += sum_t a[f,t] V[kb,t]: accumulator register r is k-slice r of the A operand
+      // (3) num[f, kb] += sum_t a[f,t] V[kb,t]: accumulator register r is k-slice r of the A operand
 #pragma unroll
-    for (int c = 0; c < KT; ++c) {
+      for (int c = 0; c < KT; ++c) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
+          const R vv = vt[16 * c + li][MM::crow(r, lane)];  // B operand: V^T[t-pos of slice r][kb]
+          num[c] = MM::mma(a[r], vv, num[c]);
+          den[c] = MM::mma(bm[r], vv, den[c]);
+        }
+      }
+    };
+    auto step = [&](auto masked, int t0) {
+      R xc[4];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          if (NMF_SKIP & 4) {
-            num[q][c][r] += a[q][r];
-            den[q][c][r] += bm[q][r];
-            continue;
+      for (int r = 0; r < 4; ++r) xc[r] = xq[r];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) vt[(i * 64 + lane) >> 4][lane & 15] = stage[i];
+      if (t0 + 64 < te) fetch(t0 + 64);  // the next tile travels while this one is consumed
+      __builtin_amdgcn_wave_barrier();
+      compute(masked, t0, xc);
+      __builtin_amdgcn_wave_barrier();
+    };
+    // whole sub-tiles in the loop, the (at most one) ragged sub-tile of the matrix after it: one loop body with both
+    // forms made the accumulators of the two paths meet in copies at the back-edge (16 v_mov_b64 behind the last MFMA)
+    int t0 = (s0 + wv) * 16;
+    if (t0 < te) fetch(t0);
+    for (; t0 + 16 <= te; t0 += 64) step(IntC<0>(), t0);
+    if (t0 < te) step(IntC<1>(), t0);
+
+    // ---- end of the block's share of this workgroup: the 4 waves in ascending order (wave 0 holds the total)
+    __syncthreads();  // every wave is done with its staging slice: the memory now carries the combine
+    if (wv > 0) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[c][r];
+          red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[c][r];
+        }
+    }
+    __syncthreads();
+    R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * FK;
+    const bool direct = apply && members == 1;
+    if (wv == 0) {
+      // D[row = f0 + crow][col = kb]
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+        const int kb = 16 * c + li;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          R n = num[c][r], d = den[c][r];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            n += red[w][(c * 2 + 0) * 4 + r][lane];
+            d += red[w][(c * 2 + 1) * 4 + r][lane];
           }
-          const R vv = vt[wv][q][16 * c + li][MM::crow(r, lane)];  // B operand: V^T[t-pos of slice r][kb]; rows >= K are 0
-          num[q][c] = MM::mma(a[q][r], vv, num[q][c]);
-          den[q][c] = MM::mma(bm[q][r], vv, den[q][c]);
+          const int fo = f0 + MM::crow(r, lane);
+          if (fo < F && kb < K) {
+            const size_t o = (size_t)fo * K + kb;
+            if (direct) {
+              R* tp = Tb + (size_t)b * FK + o;
+              *tp = nmf_apply<R, D2K>(*tp, n, d, eps, pe);
+            } else if (apply) {
+              st_agent(pn + o, n);
+              st_agent(pn + FK + o, d);
+            } else {
+              pn[o] = n;
+              pn[FK + o] = d;
+            }
+          }
+        }
+      }
+      if (apply && !direct) {
+        const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
+        if (lane == 0) s_last = last;
+      }
+    }
+    const size_t slab = (size_t)B * 2 * FK;
+    if (!apply) {
+      // callers that combine the slabs themselves sum maxslots of them: the last member clears the unused ones
+      if (slot == members - 1)
+        for (int sl = members; sl < pt.maxslots; ++sl)
+          for (int o = threadIdx.x; o < 16 * K; o += 256) {
+            const int fo = f0 + o / K;
+            if (fo >= F) break;
+            R* q = part + (size_t)sl * slab + (size_t)b * 2 * FK + (size_t)fo * K + o % K;
+            q[0] = 0;
+            q[FK] = 0;
+          }
+    } else if (!direct) {
+      __syncthreads();
+      if (s_last) {
+        // ---- holder of the last ticket: sum the slabs of this 16 x K block and update Tb in place.  Every member
+        // read its rows of Tb at the top of the block, i.e. before it took its ticket.
+        const R* p0 = part + (size_t)b * 2 * FK;
+        for (int o = threadIdx.x; o < 16 * K; o += 256) {
+          const int fo = f0 + o / K;
+          if (fo >= F) break;
+          const size_t idx = (size_t)fo * K + o % K;
+          R* tp = Tb + (size_t)b * FK + idx;
+          const R old = *tp;
+          const R n = slab_sum4(p0 + idx, slab, members), d = slab_sum4(p0 + FK + idx, slab, members);
+          *tp = nmf_apply<R, D2K>(old, n, d, eps, pe);
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // D[row = f0 + crow][col = kb]; the NS sets in ascending order
-  const size_t FK = (size_t)F * K;
-  R* pn = part + ((size_t)ts * B * 2 + (size_t)b * 2) * FK;
-#pragma unroll
-  for (int c = 0; c < KT; ++c) {
-    const int kb = 16 * c + li;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int fo = f0 + MM::crow(r, lane);
-      R n = num[0][c][r], dd = den[0][c][r];
-#pragma unroll
-      for (int q = 1; q < NS; ++q) {
-        n += num[q][c][r];
-        dd += den[q][c][r];
-      }
-      if (fo < F && kb < K) {
-        pn[(size_t)fo * K + kb] = n;
-        pn[FK + (size_t)fo * K + kb] = dd;
-      }
-    }
+    __syncthreads();  // the combine memory becomes staging memory again (next block of this range)
   }
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// activation half: num|den (K,T) = Tb^T (K,F) . [A|Bm] (F,T), reduced over this workgroup's bin range.
-//   grid (ceil(T/16), FS, B); the 4 waves stride over the bin range in sub-tiles of 16 and are combined through LDS.
-//   part[fs][b*2 + s][k*T + t]
-// NS sub-tiles of 16 bins (64 bins apart: a wave's consecutive sub-tiles) advance together, as in the basis half.
+// activation half: num|den (K,T) = Tb^T (K,F) . [A|Bm] (F,T).   grid (G, 1, B), 4 waves; block = 16 frames,
+// step = 16 bins.   part[slab][b*2 + s][k*T + t]
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT, int D2K = -1, int NS = 1>
+template <typename R, int KT, int D2K = -1>
 __global__ void __launch_bounds__(256)
-    nmf_act_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V, R* __restrict__ part,
-                        int B, int F, int T, int K, int fchunk, R eps, TermSpec s) {
+    nmf_act_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, R* V, R* part, int* tickets, int apply,
+                        NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe) {
   using MM = Mfma16<R>;
   using acc_t = typename MM::acc_t;
   constexpr int KS = KT * 4;
   constexpr int KP = KT * 16;
   constexpr int LD = KP + 4;          // padded row of the staged 16 x KP basis tile
   constexpr int NLD = KP * 16 / 64;   // staged elements per lane and sub-tile
-  __shared__ R tt_[4][NS][16][LD];    // wave-private basis tiles (read as A operand of (1) and of (3))
-  __shared__ R red[3][KT * 2 * 4][64];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  constexpr int TT_ELEMS = 4 * 16 * LD, RED_ELEMS = 3 * KT * 8 * 64;
+  __shared__ R smem[TT_ELEMS > RED_ELEMS ? TT_ELEMS : RED_ELEMS];  // wave-private basis tiles, then the combine
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lk = lane >> 4;
-  const int b = blockIdx.z, fs = blockIdx.y;
-  const int t0 = blockIdx.x * 16;
-  const bool tvalid = t0 + li < T;
-  const int t = tvalid ? t0 + li : T - 1;
+  const int b = blockIdx.z, g = blockIdx.x;
   const R* tbb = Tb + (size_t)b * F * K;
   const R* xb = X + (size_t)b * F * T;
-
-  R vbr[KS];  // B operand of product (1): V[k = 4j + lk][t]
+  R(*tt_)[LD] = reinterpret_cast<R(*)[LD]>(smem + wv * 16 * LD);
+  R(*red)[KT * 8][64] = reinterpret_cast<R(*)[KT * 8][64]>(smem);
+  const size_t KTt = (size_t)K * T;
+  // staged element e = i*64 + lane -> bin f0 + e / KP, basis e % KP: consecutive lanes read consecutive k of a row.
+  // Columns K .. KP-1 read column K-1 instead (they meet zeros of vbr in (1) and output rows never written in (3)).
+  // KP = 16 / 32 / 64: element i of a lane sits 64 / KP whole rows below element i - 1, i.e. a wave-uniform step that
+  // rides in the scalar offset of the load (one VGPR of addresses instead of NLD); KP = 48 keeps the per-element table
+  constexpr bool TUNI = (64 % KP) == 0;
+  unsigned toff[TUNI ? 1 : NLD];
 #pragma unroll
-  for (int j = 0; j < KS; ++j) {
-    const int k = 4 * j + lk;
-    vbr[j] = (k < K) ? V[((size_t)b * K + k) * T + t] : (R)0;
+  for (int i = 0; i < (TUNI ? 1 : NLD); ++i) {
+    const int e = i * 64 + lane;
+    toff[i] = (unsigned)(((size_t)(e / KP) * K + min(e % KP, K - 1)) * sizeof(R));
   }
-  acc_t num[NS][KT], den[NS][KT];
+  const unsigned tstep = (unsigned)(64 / KP) * (unsigned)K * (unsigned)sizeof(R);
+  const BufRsrc trs = make_rsrc(tbb), xrs = make_rsrc(xb);  // buffer addressing, as in the basis half
+
+  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
+    const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
+    const int s0 = lo > base ? (int)(lo - base) : 0;
+    const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
+    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int slot = g - gf;
+    const int t0 = blk * 16;
+    const int t = min(t0 + li, T - 1);  // columns past T feed only output columns that are never written
+    const bool tvalid = t0 + li < T;
+    const unsigned xoff = (unsigned)(((size_t)MM::crow(0, lane) * T + t) * sizeof(R));
+    const unsigned xstep = (unsigned)(MM::crow(1, 0) - MM::crow(0, 0)) * (unsigned)T * (unsigned)sizeof(R);  // rows between accumulator registers
+
+    R vbr[KS];  // B operand of product (1): V[k = 4j + lk][t]
 #pragma unroll
-  for (int q = 0; q < NS; ++q)
+    for (int j = 0; j < KS; ++j) {
+      const int k = 4 * j + lk;
+      vbr[j] = (k < K) ? V[((size_t)b * K + k) * T + t] : (R)0;
+    }
+    acc_t num[KT], den[KT];
 #pragma unroll
     for (int c = 0; c < KT; ++c)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        num[q][c][r] = 0;
-        den[q][c][r] = 0;
+        num[c][r] = 0;
+        den[c][r] = 0;
       }
-
-  const int fa = fs * fchunk;
-  const int fe = min(F, fa + fchunk);
-  // staged element e = i*64 + lane -> bin f0 + e / KP, basis e % KP: consecutive lanes read consecutive k of a row
-  R stage[NS][NLD];
-  R xq[NS][4];  // X of the next sub-tiles, in the accumulator layout
-  auto fetch = [&](int f0) {
+    const int fe = min(F, s1 * 16);
+    R stage[NLD];
+    R xq[4];  // X of the next sub-tile, in the accumulator layout
+    auto fetch = [&](int f0) {
+      if (f0 + 16 <= fe) {  // whole sub-tile inside the bin range (wave-uniform)
+        const unsigned tso = (unsigned)f0 * (unsigned)K * (unsigned)sizeof(R), xso = (unsigned)f0 * (unsigned)T * (unsigned)sizeof(R);
 #pragma unroll
-    for (int q = 0; q < NS; ++q) {
-      const int fq = f0 + 64 * q;
+        for (int i = 0; i < NLD; ++i) stage[i] = TUNI ? buf_ld<R>(trs, toff[0], tso + i * tstep) : buf_ld<R>(trs, toff[TUNI ? 0 : i], tso);
 #pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        const int e = i * 64 + lane;
-        const int fr = fq + e / KP, k = e % KP;
-        stage[q][i] = (NMF_SKIP & 16) ? (R)0.5 : ((k < K && fr < fe) ? tbb[(size_t)fr * K + k] : (R)0);  // bins beyond the range contribute 0
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        xq[q][r] = (NMF_SKIP & 8) ? (R)1 : xb[(size_t)min(fq + MM::crow(r, lane), F - 1) * T + t];
-    }
-  };
-  int f0 = fa + 16 * wv;
-  if (f0 < fe) fetch(f0);
-  for (; f0 < fe; f0 += 64 * NS) {
-    R xc[NS][4];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xc[q][r] = xq[q][r];
-    if (!(NMF_SKIP & 16)) {
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
+        for (int r = 0; r < 4; ++r) xq[r] = buf_ld<R>(xrs, xoff, xso + r * xstep);
+      } else {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
           const int e = i * 64 + lane;
-          tt_[wv][q][e / KP][e % KP] = stage[q][i];
+          const int fr = f0 + e / KP, k = min(e % KP, K - 1);
+          stage[i] = (fr < fe) ? tbb[(size_t)fr * K + k] : (R)0;  // bins beyond the range contribute 0
         }
-    }
-    if (f0 + 64 * NS < fe) fetch(f0 + 64 * NS);
-    __builtin_amdgcn_wave_barrier();
-    // (1) TV sub-tiles: rows = bins f0 + 64 q + crow, columns = frames t0 + li; the NS chains alternate
-    acc_t tv[NS];
 #pragma unroll
-    for (int q = 0; q < NS; ++q)
+        for (int r = 0; r < 4; ++r) xq[r] = xb[(size_t)min(f0 + MM::crow(r, lane), F - 1) * T + t];
+      }
+    };
+    auto compute = [&](auto masked, int f0, const R (&xc)[4]) {
+      // (1) TV sub-tile: rows = bins f0 + crow, columns = frames t0 + li
+      acc_t tv;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) tv[q][r] = 0;
+      for (int r = 0; r < 4; ++r) tv[r] = 0;
 #pragma unroll
-    for (int j = 0; j < KS; ++j)
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
-        if (4 * j < K && !(NMF_SKIP & 1))
-          tv[q] = MM::mma(tt_[wv][q][li][4 * j + lk], vbr[j], tv[q]);  // A operand: Tb[f = li][k]; padding slices skipped
-    if (NMF_SKIP & 1)
-#pragma unroll
-      for (int q = 0; q < NS; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) tv[q][r] = xc[q][r] + (R)1;
-    // (2)
-    R a[NS][4], bm[NS][4];
-#pragma unroll
-    for (int q = 0; q < NS; ++q)
+      for (int j = 0; j < KS; ++j) tv = MM::mma(tt_[li][4 * j + lk], vbr[j], tv);  // A operand: Tb[f = li][k]
+      // (2)
+      R a[4], bm[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int fr = f0 + 64 * q + MM::crow(r, lane);
-        if (NMF_SKIP & 2) {
-          a[q][r] = xc[q][r];
-          bm[q][r] = tv[q][r];
-        } else
-          nmf_terms<R, D2K>(s, xc[q][r], tv[q][r], eps, a[q][r], bm[q][r]);
-        if (!(tvalid && fr < fe)) {
-          a[q][r] = 0;
-          bm[q][r] = 0;
+        nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
+        if (decltype(masked)::value && f0 + MM::crow(r, lane) >= fe) {  // ragged last sub-tile of the matrix only
+          a[r] = 0;
+          bm[r] = 0;
         }
       }
-    // (3) num[kb, t] += sum_f Tb[f,kb] a[f,t]: accumulator register r is k-slice r of the B operand
+      // (3) num[kb, t] += sum_f Tb[f,kb] a[f,t]: accumulator register r is k-slice r of the B operand
 #pragma unroll
-    for (int c = 0; c < KT; ++c) {
+      for (int c = 0; c < KT; ++c) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
+          const R tv3 = tt_[MM::crow(r, lane)][16 * c + li];  // A operand: Tb^T[kb][f-pos of slice r]
+          num[c] = MM::mma(tv3, a[r], num[c]);
+          den[c] = MM::mma(tv3, bm[r], den[c]);
+        }
+      }
+    };
+    auto step = [&](auto masked, int f0) {
+      R xc[4];
 #pragma unroll
-        for (int q = 0; q < NS; ++q) {
-          if (NMF_SKIP & 4) {
-            num[q][c][r] += a[q][r];
-            den[q][c][r] += bm[q][r];
-            continue;
+      for (int r = 0; r < 4; ++r) xc[r] = xq[r];
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int e = i * 64 + lane;
+        tt_[e / KP][e % KP] = stage[i];
+      }
+      if (f0 + 64 < fe) fetch(f0 + 64);
+      __builtin_amdgcn_wave_barrier();
+      compute(masked, f0, xc);
+      __builtin_amdgcn_wave_barrier();
+    };
+    int f0 = (s0 + wv) * 16;
+    if (f0 < fe) fetch(f0);
+    for (; f0 + 16 <= fe; f0 += 64) step(IntC<0>(), f0);  // whole sub-tiles; the ragged one (at most) after the loop
+    if (f0 < fe) step(IntC<1>(), f0);
+
+    // ---- end of the block's share of this workgroup: the 4 waves in ascending order
+    __syncthreads();
+    if (wv > 0) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[c][r];
+          red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[c][r];
+        }
+    }
+    __syncthreads();
+    R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * KTt;
+    const bool direct = apply && members == 1;
+    if (wv == 0) {
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          R n = num[c][r], d = den[c][r];
+#pragma unroll
+          for (int w = 0; w < 3; ++w) {
+            n += red[w][(c * 2 + 0) * 4 + r][lane];
+            d += red[w][(c * 2 + 1) * 4 + r][lane];
           }
-          const R tv3 = tt_[wv][q][MM::crow(r, lane)][16 * c + li];  // A operand: Tb^T[kb][f-pos of slice r]
-          num[q][c] = MM::mma(tv3, a[q][r], num[q][c]);
-          den[q][c] = MM::mma(tv3, bm[q][r], den[q][c]);
+          const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
+          if (kb < K && tvalid) {
+            const size_t o = (size_t)kb * T + t;
+            if (direct) {
+              R* vp = V + (size_t)b * KTt + o;
+              *vp = nmf_apply<R, D2K>(*vp, n, d, eps, pe);
+            } else if (apply) {
+              st_agent(pn + o, n);
+              st_agent(pn + KTt + o, d);
+            } else {
+              pn[o] = n;
+              pn[KTt + o] = d;
+            }
+          }
+        }
+      if (apply && !direct) {
+        const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
+        if (lane == 0) s_last = last;
+      }
+    }
+    const size_t slab = (size_t)B * 2 * KTt;
+    if (!apply) {
+      if (slot == members - 1)
+        for (int sl = members; sl < pt.maxslots; ++sl)
+          for (int o = threadIdx.x; o < 16 * K; o += 256) {
+            const int tc = t0 + (o & 15);
+            if (tc >= T) continue;
+            R* q = part + (size_t)sl * slab + (size_t)b * 2 * KTt + (size_t)(o >> 4) * T + tc;
+            q[0] = 0;
+            q[KTt] = 0;
+          }
+    } else if (!direct) {
+      __syncthreads();
+      if (s_last) {
+        // ---- holder of the last ticket: sum the slabs of this K x 16 block and update V in place (every member read
+        // its columns of V at the top of the block, before it took its ticket)
+        const R* p0 = part + (size_t)b * 2 * KTt;
+        for (int o = threadIdx.x; o < 16 * K; o += 256) {
+          const int tc = t0 + (o & 15);
+          if (tc >= T) continue;
+          const size_t idx = (size_t)(o >> 4) * T + tc;
+          R* vp = V + (size_t)b * KTt + idx;
+          const R old = *vp;
+          const R n = slab_sum4(p0 + idx, slab, members), d = slab_sum4(p0 + KTt + idx, slab, members);
+          *vp = nmf_apply<R, D2K>(old, n, d, eps, pe);
         }
       }
     }
-    __builtin_amdgcn_wave_barrier();
-  }
-  // the NS sets in ascending order, then the 4 waves
-#pragma unroll
-  for (int c = 0; c < KT; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int q = 1; q < NS; ++q) {
-        num[0][c][r] += num[q][c][r];
-        den[0][c][r] += den[q][c][r];
-      }
-  if (wv > 0) {
-#pragma unroll
-    for (int c = 0; c < KT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[0][c][r];
-        red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[0][c][r];
-      }
-  }
-  __syncthreads();
-  if (wv == 0 && tvalid) {
-    const size_t KTt = (size_t)K * T;
-    R* pn = part + ((size_t)fs * B * 2 + (size_t)b * 2) * KTt;
-#pragma unroll
-    for (int c = 0; c < KT; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        R n = num[0][c][r], d = den[0][c][r];
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          n += red[w][(c * 2 + 0) * 4 + r][lane];
-          d += red[w][(c * 2 + 1) * 4 + r][lane];
-        }
-        const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
-        if (kb < K) {
-          pn[(size_t)kb * T + t] = n;
-          pn[KTt + (size_t)kb * T + t] = d;
-        }
-      }
+    __syncthreads();
   }
 }
 

@@ -13,10 +13,19 @@ if [ "${ASSX_DEV:-0}" = 32 ]; then FLAGS="$FLAGS -DASSX_DEV_ONLY_M4_F32"; OBJ=de
 FLAGS="$FLAGS ${ASSX_EXTRA_FLAGS:-}"
 OBJ=${ASSX_OBJ:-$OBJ}; mkdir -p "$OBJ"
 OUT=${ASSX_OUT:-libassx.so}
+# ASSX_CHECK (default 1): every translation unit is compiled with -save-temps and tools/asm_wait_check.py walks its DEVICE
+# assembly -- no instruction may touch the destination of an inline-asm load that no s_waitcnt has covered yet (the
+# round-3 bug: registers of an asm LDS read copied before their wait, wrong only with two workgroups per CU at full
+# size).  A report fails the build.  ASSX_CHECK=0 skips it (kernel-tuning loops); an object built that way is rebuilt
+# and checked by the next checking build ($OBJ/<src>.checked is the stamp).
+CHECK=${ASSX_CHECK:-1}
+CHECKER="$(cd ../.. && pwd)/tools/asm_wait_check.py"
 pids=()
-for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfer; do
+built=()
+for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfer assx_iterate; do
   stale=0
   [ -f "$OBJ/$src.o" ] || stale=1
+  [ "$CHECK" = 1 ] && [ ! -f "$OBJ/$src.checked" ] && stale=1
   for dep in "$src.hip" *.hpp ../../include/assx.h build.sh; do
     [ "$dep" -nt "$OBJ/$src.o" ] && stale=1
   done
@@ -26,10 +35,35 @@ for src in assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfe
     # 16 x 16 sub-tile (config 2: 65 -> 61 us per update).  Not for assx_bss.hip: two cov_mfma_kernel variants spill with it.
     SRCFLAGS=""
     [ "$src" = assx_nmf ] && SRCFLAGS="-mllvm -amdgpu-mfma-vgpr-form"
-    $HIPCC $FLAGS $SRCFLAGS -c "$src.hip" -o "$OBJ/$src.o" &
+    rm -f "$OBJ/$src.checked"
+    if [ "$CHECK" = 1 ]; then
+      rm -rf "$OBJ/temps_$src"; mkdir -p "$OBJ/temps_$src"
+      $HIPCC $FLAGS $SRCFLAGS -save-temps=obj -c "$src.hip" -o "$OBJ/temps_$src/$src.o" &
+    else
+      $HIPCC $FLAGS $SRCFLAGS -c "$src.hip" -o "$OBJ/$src.o" &
+    fi
     pids+=($!)
+    built+=($src)
   fi
 done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o $OBJ/assx_xfer.o -lpthread
+fail=0
+for p in "${pids[@]:-}"; do [ -n "$p" ] && { wait "$p" || fail=1; }; done
+[ "$fail" = 0 ] || { echo "build.sh: compilation failed" >&2; exit 1; }
+if [ "$CHECK" = 1 ]; then
+  for src in "${built[@]:-}"; do
+    [ -n "$src" ] || continue
+    asm="$OBJ/temps_$src/$src-hip-amdgcn-amd-amdhsa-gfx950.s"
+    [ -f "$asm" ] || { echo "build.sh: no device assembly for $src ($asm)" >&2; exit 1; }
+    if ! python3 "$CHECKER" "$asm" > "$OBJ/temps_$src/check.log" 2>&1; then
+      echo "build.sh: asm_wait_check FAILED for $src.hip -- an instruction touches an inline-asm load before its wait:" >&2
+      tail -n 40 "$OBJ/temps_$src/check.log" >&2
+      exit 1
+    fi
+    echo "asm_wait_check $src: $(tail -n 1 "$OBJ/temps_$src/check.log") ($(grep -c ASMSTART "$asm") asm blocks)"
+    mv "$OBJ/temps_$src/$src.o" "$OBJ/$src.o"
+    rm -rf "$OBJ/temps_$src"
+    touch "$OBJ/$src.checked"
+  done
+fi
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o $OBJ/assx_xfer.o $OBJ/assx_iterate.o -lpthread
 echo "built $(pwd)/$OUT"

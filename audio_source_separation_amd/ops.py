@@ -221,6 +221,40 @@ class Engine:
                                       ptr(ws), B, M, F, T, K, self.prec.code, self._st()), "assx_ilrma_loss")
         return loss
 
+    # ------------------------------------------------------------------ whole loops in one call
+    def nmf_iterate(self, n_iter, kind, X, Tb, V, domain=2, eps=1e-12, param=0.0, loss=None):
+        """n_iter x (update, loss[i]); loss: (n_iter, B) float64 device tensor or None (criterion not evaluated)."""
+        B, F, T = (int(s) for s in X.shape)
+        K = int(Tb.shape[-1])
+        ws = self._nmf_scratch(B, F, T, K)
+        self._check(self._L.assx_nmf_iterate(self.ctx, int(n_iter), int(kind), float(domain), float(param), float(eps),
+                                             ptr(X), ptr(Tb), ptr(V), ptr(loss), ptr(ws), B, F, T, K, self.prec.code,
+                                             self._st()), "assx_nmf_iterate")
+
+    def auxiva_iterate(self, n_iter, kind, X, W, r, eps=1e-12, threshold=1e12, status=None, loss=None,
+                       spatial=_lib.SPATIAL_IP, pair=(0, 1)):
+        """n_iter x (weights [+ loss[i]], covariance + sweep), then loss[n_iter]; loss: (n_iter + 1, B) float64 or None."""
+        B, M, F, T = self._dims(X)
+        ws = self._scratch(B, M, F, T, 1)
+        self._check(self._L.assx_auxiva_iterate(self.ctx, int(n_iter), int(kind), int(spatial), int(pair[0]), int(pair[1]),
+                                                ptr(X), ptr(W), float(eps), float(threshold), ptr(r), ptr(loss),
+                                                ptr(status), ptr(ws), B, M, F, T, self.prec.code, self._st()),
+                    "assx_auxiva_iterate")
+
+    def ilrma_iterate(self, n_iter, X, W, Tb, V, domain=2, eps=1e-12, threshold=1e12, status=None, loss=None,
+                      spatial=_lib.SPATIAL_IP, pair=(0, 1), normalize=0, C=None, power_bins=None, scale=None, ref=0,
+                      pb_exponent=2.0):
+        """n_iter x (source model, spatial model, normalisation); loss: (n_iter + 1, B) float64 or None.
+        normalize: 0 none, 1 'power' (C + power_bins), 2 'projection-back' (scale scratch, ref, pb_exponent)."""
+        B, M, F, T = self._dims(X)
+        K = int(Tb.shape[-1])
+        ws = self._scratch(B, M, F, T, K)
+        self._check(self._L.assx_ilrma_iterate(self.ctx, int(n_iter), int(spatial), int(pair[0]), int(pair[1]),
+                                               int(normalize), int(ref), float(pb_exponent), ptr(X), ptr(W), ptr(Tb),
+                                               ptr(V), float(domain), float(eps), float(threshold), ptr(C),
+                                               ptr(power_bins), ptr(scale), ptr(loss), ptr(status), ptr(ws), B, M, F,
+                                               T, K, self.prec.code, self._st()), "assx_ilrma_iterate")
+
     # ------------------------------------------------------------------ STFT / iSTFT (row f3)
     def stft(self, x, window, fft_size, hop):
         """x (C, L) real -> X (C, fft_size//2+1, n_frames) complex; scipy.signal.stft semantics (include/assx.h)."""

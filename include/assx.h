@@ -296,6 +296,43 @@ int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, dou
 int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* Tb,
                      const void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
 
+/* ---- whole loops in ONE call ------------------------------------------------------------------------------------
+ * The reference's drivers are Python loops around update_once() (src/algorithm/nmf.py:45-53, src/bss/iva.py:420-441,
+ * src/bss/ilrma.py:233-256).  With kernels of 5-50 us a host-language loop -- one FFI call per stage, 4-7 per
+ * iteration -- is the ceiling of the small configurations, so the loop itself is offered behind the boundary: these
+ * calls enqueue every launch of `n_iter` iterations on `stream` and return; nothing is synchronised.  They run exactly
+ * the entry points above in the order the classes call them, so model(X, iteration=k) equals k x update_once() bit
+ * for bit.  The host classes use them when no callback has to run between iterations.
+ *
+ * assx_nmf_iterate: n_iter x { assx_nmf_update_ex ; loss[i] = assx_nmf_loss_ex } (NMFbase.update, nmf.py:45-53).
+ *   loss: device float64 (n_iter, B), or NULL = the criterion is not evaluated (an extension: the reference always
+ *   records it). */
+int assx_nmf_iterate(assx_ctx* ctx, int n_iter, int kind, double domain, double param, double eps, const void* X,
+                     void* Tb, void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
+/* assx_auxiva_iterate: the loop of AuxIVAbase.__call__ (iva.py:420-441) for one contrast `kind`:
+ *   n_iter x { r, loss[i] = assx_auxiva_weights(W) ; assx_auxiva_spatial_update(spatial, pair, r) },
+ *   then loss[n_iter] of the final filters.  loss: device float64 (n_iter + 1, B) -- entry 0 is the loss before the
+ *   first iteration, as the reference records it -- or NULL.  r: caller-owned (B,N,T) reals; on return it holds the
+ *   weights of the final filters when loss != NULL, those of the last iteration's input filters otherwise.
+ *   spatial = ASSX_SPATIAL_IP2: (pair_m, pair_n) is the pair of the FIRST iteration; every iteration advances both
+ *   by one modulo N (iva.py:370-382).  Ignored otherwise. */
+int assx_auxiva_iterate(assx_ctx* ctx, int n_iter, int kind, int spatial, int pair_m, int pair_n, const void* X,
+                        void* W, double eps, double threshold, void* r, double* loss, int32_t* status, void* ws,
+                        int B, int M, int F, int T, int dtype, void* stream);
+/* assx_ilrma_iterate: the loop of GaussILRMA.__call__ (ilrma.py:233-256) without a partitioning function:
+ *   n_iter x { assx_ilrma_source_update (all sources; the two of the pair for IP2) ; assx_ilrma_spatial_update ;
+ *              normalisation },  normalize = 0: none; 1: 'power' with the statistic from the plain covariance
+ *   (C (B,F,M,M) given, power_bins (B,N,F) scratch: assx_ilrma_normalize_power_bins, ilrma.py:304-322); 2:
+ *   'projection-back' (assx_projection_back_scale with reference channel `ref` into `scale` (B,N,F) complex scratch +
+ *   assx_ilrma_normalize_pb with basis exponent `pb_exponent`, ilrma.py:323-330).
+ *   loss: device float64 (n_iter + 1, B) or NULL: entry i is compute_negative_loglikelihood (ilrma.py:648-677) of the
+ *   model after i iterations; entries 0 .. n_iter-1 ride on the basis pass of the following iteration (loss_prev of
+ *   assx_ilrma_source_update), the last one costs a pass of its own. */
+int assx_ilrma_iterate(assx_ctx* ctx, int n_iter, int spatial, int pair_m, int pair_n, int normalize, int ref,
+                       double pb_exponent, const void* X, void* W, void* Tb, void* V, double domain, double eps,
+                       double threshold, const void* C, double* power_bins, void* scale, double* loss,
+                       int32_t* status, void* ws, int B, int M, int F, int T, int K, int dtype, void* stream);
+
 /* ---- (f2) pieces of an iteration for the F-SHARDED single-utterance mode ------------------------------------------
  * Bins are independent in every step of GaussILRMA.update_once except the activation update, which reduces over f
  * (src/bss/ilrma.py:421-428), and the power / loss statistics, which reduce over (f, t) (ilrma.py:304-307, 648-677).

@@ -187,6 +187,37 @@ def test_lazy_loss_list_defers_and_resolves():
     assert isinstance(ll, LazyLossList) and list(ll) == [3.0, 9.0, 1.0]
 
 
+def test_lazy_loss_list_blocks_of_a_one_call_loop():
+    """assx_*_iterate writes n loss values into one device array: they enter `loss` as a block (one download)."""
+    from audio_source_separation_amd._loss import LazyLossList
+
+    class FakeBlock:
+        def __init__(self, v):
+            self.v = np.asarray(v, dtype=np.float64)
+            self.shape = self.v.shape
+
+        def detach(self):
+            return self
+
+        def cpu(self):
+            return self
+
+        def numpy(self):
+            return self.v
+
+    ll = LazyLossList([1.0])
+    ll.append_device_block(FakeBlock([[2.0], [3.0], [4.0]]), batched=False)
+    assert len(ll) == 4
+    ll.append(5.0)
+    ll.append_device_block(FakeBlock(np.zeros((0, 1))), batched=False)   # zero iterations: nothing
+    assert list(ll) == [1.0, 2.0, 3.0, 4.0, 5.0] and all(isinstance(v, float) for v in ll)
+    ll = LazyLossList()
+    ll.append_device_block(FakeBlock([[1.0, 2.0], [3.0, 4.0]]), batched=True)  # utterance axis kept per entry
+    ll.clear()                                                                    # mutators materialise first
+    ll.append_device_block(FakeBlock([[1.0, 2.0], [3.0, 4.0]]), batched=True)
+    assert len(ll) == 2 and np.array_equal(ll[1], [3.0, 4.0]) and np.asarray(ll).shape == (2, 2)
+
+
 def test_stft_geometry_matches_scipy_semantics():
     """assx_stft_num_frames / assx_istft_num_samples (host arithmetic, no GPU) against the oracle's restatement of
     scipy.signal.stft / istft (boundary + padding rules) over many lengths, frame sizes and hops."""

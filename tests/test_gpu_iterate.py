@@ -1,0 +1,194 @@
+"""The one-call loops (include/assx.h: assx_nmf_iterate / assx_auxiva_iterate / assx_ilrma_iterate) against the Python
+loops they replace: `model(X, iteration=k)` without callbacks runs the whole loop inside the library and must equal
+k x update_once() driven from Python BIT FOR BIT (same entry points, same order) -- filters, source model, loss curve
+and output; float64 and float32, loss on and off, every spatial algorithm / normalisation the entry points take.
+The Python loops themselves are pinned on the reference's fixtures in test_gpu_models.py (their callbacks keep them on
+the loop); here the fast path is additionally checked against the same fixtures where no callback is needed.
+(reference loops: src/algorithm/nmf.py:45-53, src/bss/iva.py:420-441, src/bss/ilrma.py:233-256)"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _mixture(M, F, T, seed=0):
+    rng = np.random.default_rng(seed)
+    S = (rng.standard_normal((M, F, T)) + 1j * rng.standard_normal((M, F, T))) * rng.random((M, 1, T)) ** 2
+    A = rng.standard_normal((F, M, M)) + 1j * rng.standard_normal((F, M, M))
+    return np.einsum("fmn,nft->mft", A, S)
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("loss", [True, False])
+@pytest.mark.parametrize("M,K,spatial,normalize", [
+    (4, 3, "IP", "power"), (2, 4, "IP", "projection-back"), (3, 2, "IP", False), (4, 6, "IP", "power"),
+    (4, 3, "ISS", "power"), (3, 3, "IP2", "power"), (4, 5, "IP2", False), (5, 3, "IP", "power"),
+    (6, 7, "ISS", "projection-back")])
+def test_gauss_ilrma_one_call_loop_equals_python_loop(M, K, spatial, normalize, loss, dtype):
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+
+    class PythonLoop(GaussILRMA):
+        def _fast_loop_plan(self):
+            return None
+
+    X = _mixture(M, 33, 130, seed=M * 10 + K)
+    out = []
+    for cls in (GaussILRMA, PythonLoop):
+        np.random.seed(5)
+        with pytest.warns(UserWarning) if spatial == "ISS" else _null():
+            m = cls(n_basis=K, algorithm_spatial=spatial, normalize=normalize, recordable_loss=loss, dtype=dtype)
+        Y = m(X, iteration=4)
+        Y2 = m(X, iteration=3)  # warm start: state and `loss` carry over (ilrma.py:67-72, 44-48)
+        out.append((Y, Y2, m.demix_filter, m.basis, m.activation, None if not loss else np.asarray(m.loss),
+                    getattr(m, "update_pair", None)))
+    a, b = out
+    for i in range(5):
+        assert _same(a[i], b[i]), i
+    if loss:
+        assert a[5].shape == (4 + 1 + 3 + 1,) and _same(a[5], b[5])
+        assert np.all(np.isfinite(a[5]))
+    assert a[6] == b[6]
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_gauss_ilrma_one_call_loop_is_taken_and_matches_the_reference():
+    """No callbacks -> the library loop; values against the reference's own output (fixture)."""
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    g = load_golden("ilrma_m4_k4_pow_d2")
+    np.random.seed(int(g["seed"]))
+    model = GaussILRMA(n_basis=int(g["K"]), domain=float(g["domain"]))
+    assert model._fast_loop_plan.__func__ is GaussILRMA._fast_loop_plan
+    Y = model(g["X"], iteration=int(max(g["iters"])))
+    assert model._fast_loop_plan() == dict(normalize=1, pb_exponent=2.0)
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(Y, g["Y_out"]) < 1e-6
+    k = int(max(g["iters"]))
+    assert rel_err(model.demix_filter, g["W_%d" % k]) < 1e-6
+
+
+def test_consistent_ilrma_and_batched_one_call_loop():
+    from audio_source_separation_amd.bss.ilrma import ConsistentGaussILRMA, GaussILRMA
+
+    class PythonLoop(ConsistentGaussILRMA):
+        def _fast_loop_plan(self):
+            return None
+
+    X = _mixture(2, 33, 96, seed=3)
+    res = []
+    for cls in (ConsistentGaussILRMA, PythonLoop):
+        np.random.seed(1)
+        m = cls(n_basis=2, fft_size=64)
+        res.append((m(X, iteration=3), m.demix_filter, m.basis, np.asarray(m.loss)))
+    for x, y in zip(*res):
+        assert _same(x, y)
+
+    class Loop(GaussILRMA):
+        def _fast_loop_plan(self):
+            return None
+
+    Xb = np.stack([_mixture(3, 33, 100, seed=s) for s in (1, 2, 3)])
+    res = []
+    for cls in (GaussILRMA, Loop):
+        np.random.seed(2)
+        m = cls(n_basis=3)
+        res.append((m(Xb, iteration=3), m.demix_filter, np.asarray(m.loss)))
+    for x, y in zip(*res):
+        assert _same(x, y)
+    assert res[0][2].shape == (4, 3)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("loss", [True, False])
+@pytest.mark.parametrize("cls_name,M,spatial", [("AuxLaplaceIVA", 2, "IP"), ("AuxGaussIVA", 3, "IP"),
+                                                ("AuxLaplaceIVA", 4, "ISS"), ("AuxLaplaceIVA", 3, "IP2"),
+                                                ("AuxGaussIVA", 4, "ISS"), ("AuxLaplaceIVA", 5, "IP")])
+def test_auxiva_one_call_loop_equals_python_loop(cls_name, M, spatial, loss, dtype):
+    from audio_source_separation_amd.bss import iva
+    base = getattr(iva, cls_name)
+
+    class PythonLoop(base):
+        def _fast_loop_ok(self):
+            return False
+
+    X = _mixture(M, 33, 130, seed=M)
+    out = []
+    for cls in (base, PythonLoop):
+        m = cls(algorithm_spatial=spatial, recordable_loss=loss, dtype=dtype)
+        Y = m(X, iteration=5)
+        Y2 = m(X, iteration=2)
+        nll = m.compute_negative_loglikelihood()
+        out.append((Y, Y2, m.demix_filter, nll, None if not loss else np.asarray(m.loss), getattr(m, "update_pair", None)))
+    a, b = out
+    for i in range(4):
+        assert _same(a[i], b[i]), i
+    if loss:
+        assert a[4].shape == (5 + 1 + 2 + 1,) and _same(a[4], b[4])
+        assert a[4][-1] == a[3]  # the cached weights / loss after the loop belong to the final filters
+    assert a[5] == b[5]
+
+
+@pytest.mark.parametrize("name", ["auxiva_laplace_m2", "auxiva_gauss_m3"])
+def test_auxiva_one_call_loop_matches_the_reference(name):
+    from audio_source_separation_amd.bss import iva
+    g = load_golden(name)
+    cls = iva.AuxLaplaceIVA if "laplace" in name else iva.AuxGaussIVA
+    model = cls()
+    assert model._fast_loop_ok()
+    k = int(max(g["iters"]))
+    Y = model(g["X"], iteration=k)
+    np.testing.assert_allclose(model.loss, g["loss"], rtol=1e-9)
+    assert rel_err(model.demix_filter, g["W_%d" % k]) < 1e-6
+    assert rel_err(Y, g["Y_out"]) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("loss", [True, False])
+@pytest.mark.parametrize("cls_name,K,kw", [("EUCNMF", 8, {}), ("KLNMF", 5, dict(domain=1.5)), ("ISNMF", 3, {}),
+                                           ("ISNMF", 20, dict(algorithm="me")), ("tNMF", 6, dict(nu=5.0)),
+                                           ("CauchyNMF", 4, dict(algorithm="me")), ("EUCNMF", 70, {})])
+def test_nmf_one_call_loop_equals_python_loop(cls_name, K, kw, loss, dtype):
+    from audio_source_separation_amd.algorithm import nmf
+    base = getattr(nmf, cls_name)
+
+    class PythonLoop(base):
+        def _fast_loop_ok(self):
+            return False
+
+    rng = np.random.default_rng(K)
+    X = rng.random((65, 150)) ** 2 + 1e-3
+    out = []
+    for cls in (base, PythonLoop):
+        np.random.seed(3)
+        m = cls(n_basis=K, dtype=dtype, recordable_loss=loss, **kw)
+        Tb, V = m(X, iteration=6)
+        out.append((Tb, V, np.asarray(m.loss)))
+    a, b = out
+    assert _same(a[0], b[0]) and _same(a[1], b[1]) and _same(a[2], b[2])
+    assert a[2].shape == ((6,) if loss else (0,))
+    if loss:
+        assert np.all(np.isfinite(a[2]))
+
+
+def test_nmf_one_call_loop_keeps_the_reference_errors():
+    from audio_source_separation_amd.algorithm.nmf import ISNMF
+    m = ISNMF(n_basis=2, algorithm="nope")
+    with pytest.raises(ValueError):
+        m(np.ones((8, 8)), iteration=3)
+    m = ISNMF(n_basis=2, algorithm="me", domain=1.5)
+    with pytest.raises(AssertionError):
+        m(np.ones((8, 8)), iteration=3)

@@ -28,4 +28,7 @@ for name, fn in (("nmf_update IS", lambda: eng.nmf_update(_lib.NMF_IS_MM, X, Tb,
     for _ in range(20): fn()
     e1.record(); e1.synchronize()
     ms = e0.elapsed_time(e1) / 20
-    print("%-22s %8.1f us  %6.1f TFLOP/s (12FTK)" % (name, ms * 1e3, 12 * F * T * K / ms / 1e9))
+    # flops: an update is six F x T x K products (two reconstructions, four contractions) = 12 F T K; a loss evaluation is
+    # ONE reconstruction = 2 F T K (+ the elementwise criterion)
+    mult = 2 if "loss" in name else 12
+    print("%-22s %8.1f us  %6.1f TFLOP/s (%dFTK)" % (name, ms * 1e3, mult * F * T * K / ms / 1e9, mult))

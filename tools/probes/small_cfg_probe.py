@@ -39,3 +39,17 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print("%s %s: %.1f update_once/s (%.1f us each; host loop alone %.1f us each)" % (cfg, dtype, steps / (t2 - t0), (t2 - t0) / steps * 1e6, (t1 - t0) / steps * 1e6))
+# the same iterations as ONE library call (round 4: assx_nmf_iterate / assx_auxiva_iterate, what __call__ uses when no
+# callback has to run between iterations); loss evaluation off, like the loop above
+eng = m._engine
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+if cfg == "cfg1":
+    eng.nmf_iterate(steps, m._kind_code(), m._X, m._dev("T", False), m._dev("V", False), domain=m.domain, eps=m.eps)
+else:
+    r = eng.empty((1, M, T))
+    eng.auxiva_iterate(steps, m._KIND, m._X, m._Wd, r, eps=m.eps, threshold=m.threshold, status=m._status)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("%s %s: %.1f iterations/s in one library call (%.1f us each; enqueueing alone %.1f us each)" % (cfg, dtype, steps / (t2 - t0), (t2 - t0) / steps * 1e6, (t1 - t0) / steps * 1e6))
