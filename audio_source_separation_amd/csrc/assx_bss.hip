@@ -424,11 +424,20 @@ __global__ void __launch_bounds__(256) normalize_pb_kernel(Cx<R>* __restrict__ W
 // ------------------------------------------------------------------------------------------
 // AuxIVA: s[b,n,t] = sum_f |y_n(f,t)|^2 partials over f-splits: part[b][fs][n][t]
 // ------------------------------------------------------------------------------------------
+// Round 4: the finalize step (r from the slab sums, loss data term) is folded in behind a "last workgroup done" ticket
+// (assx_common.hpp: take_ticket): the FS workgroups of one (utterance, frame block) publish their slabs, the holder of the
+// last ticket sums them in the strand order of auxiva_stat_finalize_kernel and writes r -- one launch less per AuxIVA
+// iteration (4 -> 3).  tickets == nullptr: slabs only (the separate finalize follows).
 template <typename R, int M>
 __global__ void __launch_bounds__(256) auxiva_stat_partial_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W,
-                                                                 R* __restrict__ part, Dims d, int FS, int fchunk) {
+                                                                 R* part, Dims d, int FS, int fchunk, int* tickets,
+                                                                 R* __restrict__ r, double* lpart, double* loss, int kind,
+                                                                 R eps, int lstride) {
   constexpr int N = M;
   __shared__ R lds[2 * N * WAVE];
+  __shared__ int s_last;
+  __shared__ double s_sum[REDUCE_THREADS];
+  static_assert(REDUCE_THREADS == 256, "the folded loss sum reproduces sum_reduce_kernel's order with this workgroup");
   const int tb_ = blockIdx.x, fs = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & (WAVE - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -453,9 +462,82 @@ __global__ void __launch_bounds__(256) auxiva_stat_partial_kernel(const Cx<R>* _
     for (int n = 0; n < N; ++n) acc[n] += cabs2(y[n]);
   }
   block4_reduce_to_wave0<R, N>(acc, lds);
-  if (wv == 0 && valid) {
+  const bool fold = tickets != nullptr;
+  if (wv == 0) {
+    if (valid) {
 #pragma unroll
-    for (int n = 0; n < N; ++n) part[(((size_t)b * FS + fs) * N + n) * T + t] = acc[n];
+      for (int n = 0; n < N; ++n) {
+        R* q = part + (((size_t)b * FS + fs) * N + n) * T + t;
+        if (fold) st_agent(q, acc[n]);
+        else *q = acc[n];
+      }
+    }
+    if (fold) {
+      const bool last = take_ticket(tickets + (size_t)b * gridDim.x + tb_, FS);
+      if (lane == 0) s_last = last;
+    }
+  }
+  if (!fold) return;
+  // With the loss (folded path only): the log-det terms of this workgroup's bins ride along (frame block 0's
+  // workgroups write them), and a second ticket per utterance -- taken by everyone who has written loss partials --
+  // lets the last writer add them up: the loss needs no launch of its own (logdet_kernel + sum_reduce_kernel before).
+  const int nblk = N * (int)gridDim.x;
+  int contributions = 0;
+  if (loss && tb_ == 0) {
+    for (int f = f0 + (int)threadIdx.x; f < f1; f += 256)
+      st_agent(lpart + (size_t)b * lstride + nblk + f, neg2T_logabsdet<M, R>(W, (size_t)b * F + f, T));
+    contributions = 1;
+  }
+  __syncthreads();
+  if (s_last) {
+  // ---- holder of the last ticket: r = sqrt(s) (Laplace, iva.py:490) | s / F (Gauss, iva.py:723) for the N x 64 outputs of
+  // this frame block; loss data term per (source, frame block) -> lpart[b][n * blocks + tb]
+  const size_t NT = (size_t)N * T;
+  for (int n = wv; n < N; n += 4) {
+    double term = 0.0;
+    if (valid) {
+      const R s = slab_sum4(part + (size_t)b * FS * NT + (size_t)n * T + t, NT, FS);
+      R rv;
+      if (kind == ASSX_IVA_LAPLACE) {
+        rv = sqrt(s);
+        term = 2.0 * (double)rv;                       // iva.py:615-617
+      } else {
+        rv = s / (R)F;
+        term = (double)F * log((double)floor_eps<R>(rv, eps));  // iva.py:797-800
+      }
+      r[(size_t)b * NT + (size_t)n * T + t] = rv;
+    }
+    if (lpart) {
+      term = wave_allreduce_sum<double>(term);
+      if (lane == 0) st_agent(lpart + (size_t)b * lstride + (size_t)n * gridDim.x + tb_, term);
+    }
+  }
+  contributions += 1;
+  }
+  if (!loss || contributions == 0) return;
+  // every wave's partial stores have been accepted before the workgroup's contribution is counted
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (wv == 0) {
+    int* t2 = tickets + (size_t)gridDim.z * gridDim.x + b;
+    bool last = false;
+    for (int c = 0; c < contributions; ++c) last = take_ticket(t2, (int)gridDim.x + FS) || last;
+    if (lane == 0) s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- last writer of the utterance: loss[b] = sum of its lstride partials, in sum_reduce_kernel's order
+  {
+    const double* p = lpart + (size_t)b * lstride;
+    double acc2 = 0.0;
+    for (int i = threadIdx.x; i < lstride; i += REDUCE_THREADS) acc2 += ld_agent(p + i);
+    s_sum[threadIdx.x] = acc2;
+    __syncthreads();
+    for (int off = REDUCE_THREADS / 2; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) s_sum[threadIdx.x] += s_sum[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[b] = s_sum[0];
   }
 }
 
@@ -463,17 +545,19 @@ __global__ void __launch_bounds__(256) auxiva_stat_partial_kernel(const Cx<R>* _
 template <typename R>
 __global__ void __launch_bounds__(256) auxiva_stat_finalize_kernel(const R* __restrict__ part, R* __restrict__ r,
                                                                   double* __restrict__ lpart, int N, int F, int T,
-                                                                  int FS, int kind, R eps, int lstride) {
-  // 64 outputs per workgroup, 4 threads per output: thread (o, q) sums the slabs fs = q, q+4, ... (independent loads,
-  // unrolled), the four strands are combined in a fixed order.  (One thread per output walking all FS slabs was a
-  // 32-deep chain of L2 latencies on 16 workgroups: 8.8 us for 4096 outputs.)
+                                                                  int FS, int kind, R eps, int lstride, int TBk) {
+  // Only launched where the fold above is off (FS == 1 or ASSX_AUX_FOLD=0).  One workgroup per (source, frame block):
+  // 64 outputs, 4 threads per output: thread (o, q) sums the slabs fs = q, q+4, ... (independent loads), the four
+  // strands are combined in a fixed order -- the order slab_sum4 reproduces.
   __shared__ R strand[4][64];
   const int b = blockIdx.y;
   const size_t NT = (size_t)N * T;
   const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const size_t idx = (size_t)blockIdx.x * 64 + o;
+  const int n = blockIdx.x / TBk, tb = blockIdx.x % TBk;
+  const int t = tb * 64 + o;
+  const size_t idx = (size_t)n * T + t;
   R s = 0;
-  if (idx < NT) {
+  if (t < T) {
 #pragma unroll 4
     for (int fs = q; fs < FS; fs += 4) s += part[((size_t)b * FS + fs) * NT + idx];
   }
@@ -481,7 +565,7 @@ __global__ void __launch_bounds__(256) auxiva_stat_finalize_kernel(const R* __re
   __syncthreads();
   if (q == 0) {
     double term = 0.0;
-    if (idx < NT) {
+    if (t < T) {
       s = (strand[0][o] + strand[1][o]) + (strand[2][o] + strand[3][o]);
       R rv;
       if (kind == ASSX_IVA_LAPLACE) {
@@ -859,7 +943,7 @@ inline WsLayout ws_layout(int B, int M, int F, int T, int K, int dtype) {
   L.u = off;
   off += align_up((size_t)B * M * F * M * M * 2 * r, 256);
   L.lpart = off;
-  size_t nl = (size_t)B * ((size_t)TS * F + (size_t)M * F + (size_t)(M * T + 63) / 64 + F + 16 +
+  size_t nl = (size_t)B * ((size_t)TS * F + (size_t)M * F + (size_t)M * ((T + 63) / 64) + F + 16 +
                            (size_t)flat_loss(F, T).G);
   off += align_up(nl * 8, 256);
   L.small = off;
@@ -2005,15 +2089,32 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
     constexpr int MM = decltype(mt)::value;
     int FS, fchunk;
     f_split(B, F, T, &FS, &fchunk);
-    hipLaunchKernelGGL((auxiva_stat_partial_kernel<R, MM>), dim3(blocks_for(T, WAVE), FS, B), dim3(256), 0, st,
-                       (const Cx<R>*)X, (const Cx<R>*)W, (R*)ws, Dims{B, F, T, 0}, FS, fchunk);
-    ASSX_LAUNCH_CHECK(ctx, "auxiva_stat_partial_kernel");
-    const int nblk = (int)blocks_for((size_t)MM * T, 64);
+    // one loss partial per (source, frame block) -- for T a multiple of 64 exactly the blocks of the flattened (n, t)
+    // index the separate finalize kernel used
+    const int TBk = (int)blocks_for(T, WAVE), nblk = MM * TBk;
     const int lstride = nblk + F;
-    hipLaunchKernelGGL((auxiva_stat_finalize_kernel<R>), dim3(nblk, B), dim3(256), 0, st, (const R*)ws, (R*)r,
-                       loss ? lpart : (double*)nullptr, MM, F, T, FS, kind, (R)eps, lstride);
-    ASSX_LAUNCH_CHECK(ctx, "auxiva_stat_finalize_kernel");
-    if (loss) {
+    // ASSX_AUX_FOLD=1: finalize, log-det terms and loss sum inside the pass (3 launches per iteration instead of 4, 5 -> 3
+    // with the loss).  OFF by default: measured SLOWER on MI355X -- config 3: 36.4 against 32.5 us per iteration, 40.6
+    // against 39.1 with the loss (profiles/r04_auxiva_fold.txt) -- write-through records + ticket + read-back are three
+    // memory round trips across the XCDs, more than a dependent launch (2.7 us) plus the 2 us finalize.  Read on every
+    // call (tests run both forms in one process).
+    const int fold = env_int("ASSX_AUX_FOLD", 0);
+    int* tickets = nullptr;
+    if (fold && FS > 1) {
+      tickets = ensure_tickets(ctx, (size_t)B * TBk + B, st);
+      if (!tickets) return ASSX_E_UNSUPPORTED;
+    }
+    const bool folded = tickets != nullptr;
+    hipLaunchKernelGGL((auxiva_stat_partial_kernel<R, MM>), dim3(TBk, FS, B), dim3(256), 0, st, (const Cx<R>*)X,
+                       (const Cx<R>*)W, (R*)ws, Dims{B, F, T, 0}, FS, fchunk, tickets, (R*)r,
+                       loss ? lpart : (double*)nullptr, folded ? loss : (double*)nullptr, kind, (R)eps, lstride);
+    ASSX_LAUNCH_CHECK(ctx, "auxiva_stat_partial_kernel");
+    if (!folded) {
+      hipLaunchKernelGGL((auxiva_stat_finalize_kernel<R>), dim3(nblk, B), dim3(256), 0, st, (const R*)ws, (R*)r,
+                         loss ? lpart : (double*)nullptr, MM, F, T, FS, kind, (R)eps, lstride, TBk);
+      ASSX_LAUNCH_CHECK(ctx, "auxiva_stat_finalize_kernel");
+    }
+    if (loss && !folded) {
       hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st, (const Cx<R>*)W,
                          lpart, B, F, T, lstride, nblk);
       ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");

@@ -441,6 +441,26 @@ __device__ __forceinline__ bool take_ticket(int* ticket, int members) {
   return __builtin_amdgcn_readfirstlane(last) != 0;
 }
 
+// sum of S slab entries `stride` apart, in the strand order of the finalize kernels of rounds 1-3 (nmf_finalize_kernel,
+// auxiva_stat_finalize_kernel): strand q adds s = q, q + 4, ...;
+// the strands are combined as (0 + 1) + (2 + 3).  Agent-scope loads: the slabs were written by other workgroups of
+// this launch (assx_common.hpp: take_ticket).
+template <typename R>
+__device__ __forceinline__ R slab_sum4(const R* p, size_t stride, int S) {
+  // 16 loads in flight per trip (a trip is one memory round trip: with 4 the holder of the last ticket walked 32 slabs
+  // in 8 dependent round trips); the additions keep the strand order whatever the chunking
+  R q[4] = {0, 0, 0, 0};
+  for (int s0 = 0; s0 < S; s0 += 16) {
+    R v[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) v[c] = ld_agent(p + (size_t)min(s0 + c, S - 1) * stride);
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (s0 + c < S) q[c & 3] += v[c];
+  }
+  return (q[0] + q[1]) + (q[2] + q[3]);
+}
+
 // ------------------------------------------------------------------------------------------
 // wave-level reductions (wave64)
 // ------------------------------------------------------------------------------------------

@@ -121,27 +121,6 @@ __device__ __forceinline__ R nmf_apply(R old, R num, R den, R eps, PowSpec p) {
   return old * powspec<R>(q, p);
 }
 
-// sum of S slab entries `stride` apart, in the strand order of nmf_finalize_kernel: strand q adds s = q, q + 4, ...;
-// the strands are combined as (0 + 1) + (2 + 3).  Agent-scope loads: the slabs were written by other workgroups of
-// this launch (assx_common.hpp: take_ticket).
-template <typename R>
-__device__ __forceinline__ R slab_sum4(const R* p, size_t stride, int S) {
-  R q0 = 0, q1 = 0, q2 = 0, q3 = 0;
-  int s = 0;
-  for (; s + 4 <= S; s += 4) {
-    const R a = ld_agent(p + (size_t)s * stride), b = ld_agent(p + (size_t)(s + 1) * stride),
-            c = ld_agent(p + (size_t)(s + 2) * stride), d = ld_agent(p + (size_t)(s + 3) * stride);
-    q0 += a;
-    q1 += b;
-    q2 += c;
-    q3 += d;
-  }
-  if (s < S) q0 += ld_agent(p + (size_t)s * stride);
-  if (s + 1 < S) q1 += ld_agent(p + (size_t)(s + 1) * stride);
-  if (s + 2 < S) q2 += ld_agent(p + (size_t)(s + 2) * stride);
-  return (q0 + q1) + (q2 + q3);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Work partition of the two half kernels (round 4).  One matrix = nblk output blocks (basis half: 16 bins; activation
 // half: 16 frames) x nstep wave-steps (16-frame / 16-bin sub-tiles the block's sums run over).  The nblk * nstep steps

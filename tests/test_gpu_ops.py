@@ -281,10 +281,14 @@ def test_projection_back_golden(eng):
         assert rel_err(s, g["scale_n%d" % N]) < tol(eng, 1e-11, 1e-3)
 
 
+@pytest.mark.parametrize("fold", ["0", "1"])
 @pytest.mark.parametrize("kind", ["laplace", "gauss"])
 @pytest.mark.parametrize("M,F,T", SHAPES)
-def test_auxiva_weights_and_loss(eng, kind, M, F, T):
+def test_auxiva_weights_and_loss(eng, kind, M, F, T, fold, monkeypatch):
+    """fold = 1: the statistic's finalize, the log-det terms and the loss sum inside the pass behind tickets
+    (ASSX_AUX_FOLD, off by default: measured slower than the separate launches, profiles/r04_auxiva_fold.txt)."""
     from audio_source_separation_amd import _lib
+    monkeypatch.setenv("ASSX_AUX_FOLD", fold)
     X, W = mixture(M, F, T, 60), rand_filters(M, F, 61)
     code = _lib.IVA_LAPLACE if kind == "laplace" else _lib.IVA_GAUSS
     r, loss = eng.auxiva_weights(dev_c(eng, X[None]), dev_c(eng, W[None]), code, with_loss=True)
