@@ -17,4 +17,11 @@ int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, doub
                       const void* Tb, const void* V, void* ws, int B, int F, int T, int K, int dtype, hipStream_t st,
                       const void** part, int* slabs);
 
+// The ILRMA source model for n_basis > 4 straight from the mixture (assx_nmf_xfed.hpp): the IS-type update `kind` with
+// target |w_n^H x|^2 formed on the fly, Tb (B,N,F,K) and V (B,N,K,T) updated in place; `ws` = the NMF scratch of
+// assx_nmf_workspace_bytes(B * M, F, T, K).  Returns ASSX_E_UNSUPPORTED (and launches nothing) outside its range
+// (2 <= M <= 4, n_basis <= 32): the caller then takes the power-map route.
+int nmf_update_xfed(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* W,
+                    void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st);
+
 }  // namespace assx

@@ -1,0 +1,390 @@
+// The ILRMA source model for n_basis > 4 (ilrma.py:356-366, 409-430) straight from the mixture: the two matrix-core
+// NMF halves of assx_nmf_mfma.hpp with their target P_n = |w_n^H x|^2 formed ON THE FLY.
+//
+// Until round 3 the source model went  X --demix_power_map_kernel--> P (B,N,F,T)  --two NMF halves--> Tb, V :  268.7 MB
+// read + 134.3 MB written by the map (62.6 us at config 4), then 134.3 MB read by each half.  An X-fed half was priced in
+// round 3 and dropped ("needs all four sources in one wave to read X once -- ~300 VGPRs -- or re-reads X once per
+// source").  There is a third way: the sources of an utterance become the WAVES of a workgroup.  Wave n owns source n;
+// all waves walk the same 16 x 16 sub-tiles of the spectrogram, the sub-tile's samples of the M channels are staged
+// ONCE per workgroup in LDS (each wave fetches one channel: 16 rows x 256 B, coalesced), every wave forms its own
+// |w_n^H x|^2 from that tile in the accumulator layout and feeds it to the very chain of products of the map-fed
+// kernels.  X is read once per half (268.7 MB), the map and its launch are gone, and no cross-wave combine is left:
+// a wave's accumulators are already one source's sums.
+//
+// Work partition, records, tickets and the multiplicative step are those of assx_nmf_mfma.hpp (NmfPart over one
+// utterance's (block, step) space; a step is done by all M waves at once; record matrices are indexed b * N + n like the
+// batch of the map-fed kernels, so the slab layout -- and nmf_ws -- are shared).  Double-buffered tile + one workgroup
+// barrier per step.
+#pragma once
+#include "assx_nmf_mfma.hpp"
+
+namespace assx {
+
+// ---------------------------------------------------------------------------------------------------------
+// basis half.  grid (G, 1, B), M waves; block = 16 bins, step = 16 frames.  part[slab][(b*M + n)*2 + s][f*K + k]
+// ---------------------------------------------------------------------------------------------------------
+template <typename R, int M, int KT, int D2K>
+__global__ void __launch_bounds__(64 * M)
+    nmf_basis_xfed_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, R* Tb, const R* __restrict__ V,
+                          R* part, int* tickets, NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe) {
+  using MM = Mfma16<R>;
+  using acc_t = typename MM::acc_t;
+  constexpr int N = M;
+  constexpr int KS = KT * 4, KP = KT * 16, LD = 17, NLD = KP * 16 / 64;
+  constexpr int XLD = 17;  // padded row (16-byte units) of the staged X tile: conflict-free b128 reads down a column
+  __shared__ R vts[M * KP * LD];
+  __shared__ __attribute__((aligned(16))) Vec2<R> xt[2][M][16][XLD];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, n = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave = source = channel fetched
+  const int li = lane & 15, lk = lane >> 4;
+  const int b = blockIdx.z, g = blockIdx.x;
+  const size_t bn = (size_t)b * N + n, BN = (size_t)B * N;
+  R(*vt)[LD] = reinterpret_cast<R(*)[LD]>(vts + n * KP * LD);
+  const R* vb = V + bn * K * T;
+  const size_t FT = (size_t)F * T, FK = (size_t)F * K;
+  const Cx<R>* xm = X + ((size_t)b * M + n) * FT;  // the channel this wave stages
+  unsigned voff[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) voff[i] = (unsigned)((min(4 * i + lk, K - 1) * (size_t)T + li) * sizeof(R));
+  // X tile piece i of this lane: row lk + 4 i of the block's 16 bins, frames li of the step's 16 (one 16 / 8-byte sample)
+  const unsigned xvoff = (unsigned)(((size_t)lk * T + li) * sizeof(Cx<R>));
+  const unsigned xrow4 = 4u * (unsigned)T * (unsigned)sizeof(Cx<R>);
+  const BufRsrc vrs = make_rsrc(vb), xrs = make_rsrc(xm);
+
+  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
+    const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
+    const int s0 = lo > base ? (int)(lo - base) : 0;
+    const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
+    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int slot = g - gf;
+    const int f0 = blk * 16;
+    const int f = min(f0 + li, F - 1);  // rows past F feed only output rows that are never written
+    const bool rows_in = f0 + 16 <= F;
+
+    R tb[KS];  // B operand of product (1): Tb^T[k = 4j + lk][f]
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int k = 4 * j + lk;
+      tb[j] = (k < K) ? Tb[(bn * F + f) * K + k] : (R)0;
+    }
+    Vec2<R> w[M];  // this source's demixing row of the lane's bin
+#pragma unroll
+    for (int m = 0; m < M; ++m) w[m] = ldv<R>(W + (((size_t)b * F + f) * N + n) * M + m);
+    acc_t num[KT], den[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        num[c][r] = 0;
+        den[c][r] = 0;
+      }
+    const int te = min(T, s1 * 16);
+    R stage[NLD];
+    Vec2<R> xs[4];  // this wave's channel of the NEXT step's tile
+    auto fetch = [&](int t0) {
+      if (t0 + 16 <= T && rows_in) {  // whole tile inside the matrix (workgroup-uniform)
+        const unsigned soff = (unsigned)t0 * (unsigned)sizeof(R);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) stage[i] = buf_ld<R>(vrs, voff[i], soff);
+        const unsigned xso = ((unsigned)f0 * (unsigned)T + (unsigned)t0) * (unsigned)sizeof(Cx<R>);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[i] = buf_ldv<R>(xrs, xvoff, xso + i * xrow4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int e = i * 64 + lane;
+          const int k = min(e >> 4, K - 1), tt = min(t0 + (e & 15), T - 1);
+          stage[i] = vb[(size_t)k * T + tt];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          xs[i] = ldv<R>(xm + (size_t)min(f0 + lk + 4 * i, F - 1) * T + min(t0 + li, T - 1));
+      }
+    };
+    auto compute = [&](auto masked, int t0, int buf) {
+      acc_t tv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[r] = 0;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) tv = MM::mma(vt[4 * j + lk][li], tb[j], tv);
+      R a[4], bm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Vec2<R> x[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) x[m] = xt[buf][m][li][MM::crow(r, lane)];
+        Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) cfma(y, tocx<R>(w[m]), tocx<R>(x[m]));
+        nmf_terms<R, D2K>(s, cabs2(y), tv[r], eps, a[r], bm[r]);
+        if (decltype(masked)::value && t0 + MM::crow(r, lane) >= T) {
+          a[r] = 0;
+          bm[r] = 0;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const R vv = vt[16 * c + li][MM::crow(r, lane)];
+          num[c] = MM::mma(a[r], vv, num[c]);
+          den[c] = MM::mma(bm[r], vv, den[c]);
+        }
+      }
+    };
+    auto step = [&](auto masked, int t0, int buf) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) vt[(i * 64 + lane) >> 4][lane & 15] = stage[i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xt[buf][n][lk + 4 * i][li] = xs[i];
+      if (t0 + 16 < te) fetch(t0 + 16);  // the next tile travels while this one is consumed
+      __syncthreads();  // the M channels of the tile are in place; buffer `buf ^ 1` is free again once everybody is here
+      compute(masked, t0, buf);
+    };
+    int t0 = s0 * 16, it = 0;
+    if (t0 < te) fetch(t0);
+    for (; t0 + 16 <= te; t0 += 16, ++it) step(IntC<0>(), t0, it & 1);
+    if (t0 < te) step(IntC<1>(), t0, it & 1);
+
+    // ---- end of this workgroup's share of the block: every wave holds its own source's sums
+    R* pn = part + ((size_t)slot * BN * 2 + bn * 2) * FK;
+    const bool direct = members == 1;
+#pragma unroll
+    for (int c = 0; c < KT; ++c) {
+      const int kb = 16 * c + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int fo = f0 + MM::crow(r, lane);
+        if (fo < F && kb < K) {
+          const size_t o = (size_t)fo * K + kb;
+          if (direct) {
+            R* tp = Tb + bn * FK + o;
+            *tp = nmf_apply<R, D2K>(*tp, num[c][r], den[c][r], eps, pe);
+          } else {
+            st_agent(pn + o, num[c][r]);
+            st_agent(pn + FK + o, den[c][r]);
+          }
+        }
+      }
+    }
+    if (!direct) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's records are out ...
+      __syncthreads();                                   // ... and so are the other sources'
+      if (n == 0) {
+        const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
+        if (lane == 0) s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {
+        // holder of the last ticket: wave n sums the slabs of source n's 16 x K block and updates Tb in place (every
+        // member read its rows of Tb at the top of the block, before it took its ticket)
+        const R* p0 = part + bn * 2 * FK;
+        const size_t slab = BN * 2 * FK;
+        for (int o = lane; o < 16 * K; o += 64) {
+          const int fo = f0 + o / K;
+          if (fo >= F) break;
+          const size_t idx = (size_t)fo * K + o % K;
+          R* tp = Tb + bn * FK + idx;
+          const R old = *tp;
+          const R nn = slab_sum4(p0 + idx, slab, members), dd = slab_sum4(p0 + FK + idx, slab, members);
+          *tp = nmf_apply<R, D2K>(old, nn, dd, eps, pe);
+        }
+      }
+    }
+    __syncthreads();  // the tile buffers and s_last are reused by the next block of this range
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// activation half.  grid (G, 1, B), M waves; block = 16 frames, step = 16 bins.  part[slab][(b*M + n)*2 + s][k*T + t]
+// The demixing rows of the step's 16 bins (all sources: 16 x M x M samples, contiguous in W) are staged with the tile.
+// ---------------------------------------------------------------------------------------------------------
+template <typename R, int M, int KT, int D2K>
+__global__ void __launch_bounds__(64 * M)
+    nmf_act_xfed_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, const R* __restrict__ Tb, R* V,
+                        R* part, int* tickets, NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe) {
+  using MM = Mfma16<R>;
+  using acc_t = typename MM::acc_t;
+  constexpr int N = M;
+  constexpr int KS = KT * 4, KP = KT * 16, LD = KP + 4, NLD = KP * 16 / 64;
+  constexpr int XLD = 17;
+  constexpr int WPB = M * M;                    // samples of W per bin
+  constexpr int WPT = (16 * WPB + 64 * M - 1) / (64 * M);  // pieces of the W tile per thread (1 for M = 2..4)
+  __shared__ R tts[M * 16 * LD];
+  __shared__ __attribute__((aligned(16))) Vec2<R> xt[2][M][16][XLD];
+  __shared__ __attribute__((aligned(16))) Vec2<R> wt[2][16 * WPB];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, n = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lk = lane >> 4;
+  const int b = blockIdx.z, g = blockIdx.x;
+  const size_t bn = (size_t)b * N + n, BN = (size_t)B * N;
+  R(*tt_)[LD] = reinterpret_cast<R(*)[LD]>(tts + n * 16 * LD);
+  const R* tbb = Tb + bn * F * K;
+  const size_t FT = (size_t)F * T, KTt = (size_t)K * T;
+  const Cx<R>* xm = X + ((size_t)b * M + n) * FT;
+  const Cx<R>* wb = W + (size_t)b * F * WPB;
+  constexpr bool TUNI = (64 % KP) == 0;
+  unsigned toff[TUNI ? 1 : NLD];
+#pragma unroll
+  for (int i = 0; i < (TUNI ? 1 : NLD); ++i) {
+    const int e = i * 64 + lane;
+    toff[i] = (unsigned)(((size_t)(e / KP) * K + min(e % KP, K - 1)) * sizeof(R));
+  }
+  const unsigned tstep = (unsigned)(64 / KP) * (unsigned)K * (unsigned)sizeof(R);
+  const unsigned xvoff = (unsigned)(((size_t)lk * T + li) * sizeof(Cx<R>));
+  const unsigned xrow4 = 4u * (unsigned)T * (unsigned)sizeof(Cx<R>);
+  const BufRsrc trs = make_rsrc(tbb), xrs = make_rsrc(xm);
+
+  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
+    const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
+    const int s0 = lo > base ? (int)(lo - base) : 0;
+    const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
+    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int slot = g - gf;
+    const int t0 = blk * 16;
+    const int t = min(t0 + li, T - 1);
+    const bool tvalid = t0 + li < T;
+    const bool cols_in = t0 + 16 <= T;
+
+    R vbr[KS];  // B operand of product (1): V[k = 4j + lk][t]
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int k = 4 * j + lk;
+      vbr[j] = (k < K) ? V[(bn * K + k) * T + t] : (R)0;
+    }
+    acc_t num[KT], den[KT];
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        num[c][r] = 0;
+        den[c][r] = 0;
+      }
+    const int fe = min(F, s1 * 16);
+    R stage[NLD];
+    Vec2<R> xs[4];
+    Vec2<R> ws_[WPT];
+    auto fetch = [&](int f0) {
+      if (f0 + 16 <= fe && cols_in) {
+        const unsigned tso = (unsigned)f0 * (unsigned)K * (unsigned)sizeof(R);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) stage[i] = TUNI ? buf_ld<R>(trs, toff[0], tso + i * tstep) : buf_ld<R>(trs, toff[TUNI ? 0 : i], tso);
+        const unsigned xso = ((unsigned)f0 * (unsigned)T + (unsigned)t0) * (unsigned)sizeof(Cx<R>);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xs[i] = buf_ldv<R>(xrs, xvoff, xso + i * xrow4);
+      } else {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+          const int e = i * 64 + lane;
+          const int fr = f0 + e / KP, k = min(e % KP, K - 1);
+          stage[i] = (fr < fe) ? tbb[(size_t)fr * K + k] : (R)0;  // bins beyond the range contribute 0
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          xs[i] = ldv<R>(xm + (size_t)min(f0 + lk + 4 * i, F - 1) * T + min(t0 + li, T - 1));
+      }
+#pragma unroll
+      for (int q = 0; q < WPT; ++q) {  // the 16 bins' demixing rows: piece (thread) of a contiguous run of W
+        const int e = q * 64 * M + (int)threadIdx.x;
+        const int fr = min(f0 + e / WPB, F - 1);
+        ws_[q] = (e < 16 * WPB) ? ldv<R>(wb + (size_t)fr * WPB + e % WPB) : Vec2<R>{0, 0};
+      }
+    };
+    auto compute = [&](auto masked, int f0, int buf) {
+      acc_t tv;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tv[r] = 0;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) tv = MM::mma(tt_[li][4 * j + lk], vbr[j], tv);
+      R a[4], bm[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = MM::crow(r, lane);  // bin of the sub-tile this accumulator register belongs to
+        Cx<R> y = cmake<R>(0, 0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) cfma(y, tocx<R>(wt[buf][row * WPB + n * M + m]), tocx<R>(xt[buf][m][row][li]));
+        nmf_terms<R, D2K>(s, cabs2(y), tv[r], eps, a[r], bm[r]);
+        if (decltype(masked)::value && f0 + row >= fe) {
+          a[r] = 0;
+          bm[r] = 0;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < KT; ++c) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const R tv3 = tt_[MM::crow(r, lane)][16 * c + li];
+          num[c] = MM::mma(tv3, a[r], num[c]);
+          den[c] = MM::mma(tv3, bm[r], den[c]);
+        }
+      }
+    };
+    auto step = [&](auto masked, int f0, int buf) {
+#pragma unroll
+      for (int i = 0; i < NLD; ++i) {
+        const int e = i * 64 + lane;
+        tt_[e / KP][e % KP] = stage[i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) xt[buf][n][lk + 4 * i][li] = xs[i];
+#pragma unroll
+      for (int q = 0; q < WPT; ++q) {
+        const int e = q * 64 * M + (int)threadIdx.x;
+        if (e < 16 * WPB) wt[buf][e] = ws_[q];
+      }
+      if (f0 + 16 < fe) fetch(f0 + 16);
+      __syncthreads();
+      compute(masked, f0, buf);
+    };
+    int f0 = s0 * 16, it = 0;
+    if (f0 < fe) fetch(f0);
+    for (; f0 + 16 <= fe; f0 += 16, ++it) step(IntC<0>(), f0, it & 1);
+    if (f0 < fe) step(IntC<1>(), f0, it & 1);
+
+    R* pn = part + ((size_t)slot * BN * 2 + bn * 2) * KTt;
+    const bool direct = members == 1;
+#pragma unroll
+    for (int c = 0; c < KT; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
+        if (kb < K && tvalid) {
+          const size_t o = (size_t)kb * T + t;
+          if (direct) {
+            R* vp = V + bn * KTt + o;
+            *vp = nmf_apply<R, D2K>(*vp, num[c][r], den[c][r], eps, pe);
+          } else {
+            st_agent(pn + o, num[c][r]);
+            st_agent(pn + KTt + o, den[c][r]);
+          }
+        }
+      }
+    if (!direct) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (n == 0) {
+        const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
+        if (lane == 0) s_last = last;
+      }
+      __syncthreads();
+      if (s_last) {
+        const R* p0 = part + bn * 2 * KTt;
+        const size_t slab = BN * 2 * KTt;
+        for (int o = lane; o < 16 * K; o += 64) {
+          const int tc = t0 + (o & 15);
+          if (tc >= T) continue;
+          const size_t idx = (size_t)(o >> 4) * T + tc;
+          R* vp = V + bn * KTt + idx;
+          const R old = *vp;
+          const R nn = slab_sum4(p0 + idx, slab, members), dd = slab_sum4(p0 + KTt + idx, slab, members);
+          *vp = nmf_apply<R, D2K>(old, nn, dd, eps, pe);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace assx
