@@ -1456,6 +1456,28 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     static const int wide_k = env_int("ASSX_WIDE_K", 1);
     const bool full_mask = (source_mask & ((1u << MM) - 1u)) == ((1u << MM) - 1u);
     bool have_map = false;
+    if (loss_prev && K > KU && wide_k && full_mask && domain == 2.0 && env_int("ASSX_FUSE_LOSS", 1)) {
+      // n_basis > 4 (round 4): the loss of the model at entry rides on the X-fed basis half (assx_nmf_xfed.hpp), which
+      // forms the same |w^H x|^2 and Tb V -- no pass of its own, no power map
+      const int ncov = nmf_xfed_loss_partials(MM, F, T, K);
+      const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
+      const int ls = ncov + F;  // [per-(workgroup, source) data terms | F log-det terms]
+      if (ncov > 0 && (size_t)B * ls * sizeof(double) <= L.small - L.lpart) {
+        double* lp = (double*)((char*)ws + L.lpart);
+        hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st,
+                           (const Cx<R>*)W, lp, B, F, T, ls, ncov);
+        ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
+        rc = nmf_update_xfed(ctx, ASSX_NMF_IS_MM, domain, 0.0, eps, X, W, Tb, V, (char*)ws + L.nmf, B, MM, F, T, K, dtype,
+                             st, lp, ls);
+        if (rc != ASSX_E_UNSUPPORTED) {
+          if (rc) return rc;
+          hipLaunchKernelGGL(ilrma_loss_finish_kernel, dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lp, loss_prev,
+                             F, ncov, ls);
+          ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_finish_kernel");
+          return 0;
+        }
+      }
+    }
     if (loss_prev) {
       const bool fusable = domain == 2.0 && K <= KU && env_int("ASSX_BASIS_VDMA", 1) && env_int("ASSX_FUSE_LOSS", 1);
       if (!fusable) {

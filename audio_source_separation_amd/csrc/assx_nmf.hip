@@ -590,28 +590,43 @@ static int nmf_half_launch(assx_ctx* ctx, const TermSpec& ts, int half, const vo
   return 0;
 }
 
+static NmfPart xfed_basis_part(int F, int T, int KT) {
+  // one utterance = one partition; every step is done by the M waves (sources) of a workgroup at once.
+  // three workgroups per CU where their LDS (tile double buffer + staging, < 54 KB at n_basis <= 16) allows it, two
+  // otherwise (profiles/r04_xfed_wgs_sweep.txt: 256 / 384 / 512 / 640 / 768 / 1024 -> 0.253 / 0.263 / 0.227 / 0.248 /
+  // 0.224 / 0.247 ms per n_basis = 10 iteration)
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
+}
+static NmfPart xfed_act_part(int F, int T, int KT) {
+  return make_nmf_part((T + 15) / 16, (F + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
+}
+static bool xfed_applies(int kind, int M, int K) {
+  static const int on = nmf_env_int("ASSX_NMF_XFED", 1);  // 0: the power-map route of rounds 1-3 (A/B runs)
+  return on && M >= 2 && M <= 4 && K <= 32 && (kind == ASSX_NMF_IS_MM || kind == ASSX_NMF_T_RAW);
+}
+
 template <typename R, int M, int KT>
 static int nmf_update_xfed_t(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X,
                              const void* W, void* Tb, void* V, void* ws, int B, int F, int T, int K, int dtype,
-                             hipStream_t st) {
+                             hipStream_t st, double* lpart, int lstride) {
   const NmfWs L = nmf_ws(B * M, F, T, K, dtype);
   R* part = (R*)((char*)ws + L.part);
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
-  // one utterance = one partition; every step is done by the M waves (sources) of a workgroup at once
-  // three workgroups per CU where their LDS (tile double buffer + staging, < 54 KB at n_basis <= 16) allows it, two
-  // otherwise (profiles/r04_xfed_wgs_sweep.txt: 256 / 384 / 512 / 640 / 768 / 1024 -> 0.253 / 0.263 / 0.227 / 0.248 /
-  // 0.224 / 0.247 ms per n_basis = 10 iteration)
-  const int wgs = nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET);
-  const NmfPart pb = make_nmf_part((F + 15) / 16, (T + 15) / 16, 1, wgs);
-  const NmfPart pa = make_nmf_part((T + 15) / 16, (F + 15) / 16, 1, wgs);
+  const NmfPart pb = xfed_basis_part(F, T, KT), pa = xfed_act_part(F, T, KT);
   int* tickets = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st);
   if (!tickets) return ASSX_E_ARG;
   const bool d2 = domain == 2.0 && kind == ASSX_NMF_IS_MM;
 #define XFED(D2K)                                                                                                        \
   do {                                                                                                                   \
-    hipLaunchKernelGGL((nmf_basis_xfed_kernel<R, M, KT, D2K>), dim3(pb.G, 1, B), dim3(64 * M), 0, st, (const Cx<R>*)X,   \
-                       (const Cx<R>*)W, (R*)Tb, (const R*)V, part, tickets, pb, B, F, T, K, (R)eps, ts, pe);             \
+    if (lpart)                                                                                                           \
+      hipLaunchKernelGGL((nmf_basis_xfed_kernel<R, M, KT, ASSX_NMF_IS_MM, true>), dim3(pb.G, 1, B), dim3(64 * M), 0, st, \
+                         (const Cx<R>*)X, (const Cx<R>*)W, (R*)Tb, (const R*)V, part, tickets, pb, B, F, T, K, (R)eps,   \
+                         ts, pe, lpart, lstride);                                                                        \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((nmf_basis_xfed_kernel<R, M, KT, D2K>), dim3(pb.G, 1, B), dim3(64 * M), 0, st, (const Cx<R>*)X, \
+                         (const Cx<R>*)W, (R*)Tb, (const R*)V, part, tickets, pb, B, F, T, K, (R)eps, ts, pe,            \
+                         (double*)nullptr, 0);                                                                           \
     ASSX_LAUNCH_CHECK(ctx, "nmf_basis_xfed_kernel");                                                                     \
     hipLaunchKernelGGL((nmf_act_xfed_kernel<R, M, KT, D2K>), dim3(pa.G, 1, B), dim3(64 * M), 0, st, (const Cx<R>*)X,     \
                        (const Cx<R>*)W, (const R*)Tb, (R*)V, part, tickets, pa, B, F, T, K, (R)eps, ts, pe);             \
@@ -623,20 +638,26 @@ static int nmf_update_xfed_t(assx_ctx* ctx, int kind, double domain, double para
   return 0;
 }
 
+int nmf_xfed_loss_partials(int M, int F, int T, int K) {
+  if (!xfed_applies(ASSX_NMF_IS_MM, M, K)) return 0;
+  return xfed_basis_part(F, T, (K + 15) / 16).G * M;
+}
+
 int nmf_update_xfed(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* W,
-                    void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st) {
-  static const int on = nmf_env_int("ASSX_NMF_XFED", 1);  // 0: the power-map route of rounds 1-3 (A/B runs)
-  if (!on || M < 2 || M > 4 || K > 32 || (kind != ASSX_NMF_IS_MM && kind != ASSX_NMF_T_RAW)) return ASSX_E_UNSUPPORTED;
+                    void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st,
+                    double* lpart, int lstride) {
+  if (!xfed_applies(kind, M, K)) return ASSX_E_UNSUPPORTED;
+  if (lpart && !(kind == ASSX_NMF_IS_MM && domain == 2.0)) return ASSX_E_UNSUPPORTED;
   if ((unsigned long long)M * F * T * 16 >= (1ull << 32) || (unsigned long long)K * T * 8 >= (1ull << 32)) return ASSX_E_UNSUPPORTED;
   // the partition arithmetic of the kernels is 32-bit and a workgroup holds < 64 KB of LDS
 #define XFED_BY(RT)                                                                                                     \
   switch (M * 10 + (K + 15) / 16) {                                                                                     \
-    case 21: return nmf_update_xfed_t<RT, 2, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st); \
-    case 22: return nmf_update_xfed_t<RT, 2, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st); \
-    case 31: return nmf_update_xfed_t<RT, 3, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st); \
-    case 32: return nmf_update_xfed_t<RT, 3, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st); \
-    case 41: return nmf_update_xfed_t<RT, 4, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st); \
-    case 42: return nmf_update_xfed_t<RT, 4, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st); \
+    case 21: return nmf_update_xfed_t<RT, 2, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 22: return nmf_update_xfed_t<RT, 2, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 31: return nmf_update_xfed_t<RT, 3, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 32: return nmf_update_xfed_t<RT, 3, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 41: return nmf_update_xfed_t<RT, 4, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 42: return nmf_update_xfed_t<RT, 4, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
   }
   if (dtype == ASSX_F64) {
     XFED_BY(double)

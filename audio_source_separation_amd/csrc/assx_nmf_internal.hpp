@@ -21,7 +21,12 @@ int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, doub
 // target |w_n^H x|^2 formed on the fly, Tb (B,N,F,K) and V (B,N,K,T) updated in place; `ws` = the NMF scratch of
 // assx_nmf_workspace_bytes(B * M, F, T, K).  Returns ASSX_E_UNSUPPORTED (and launches nothing) outside its range
 // (2 <= M <= 4, n_basis <= 32): the caller then takes the power-map route.
+// lpart != nullptr (IS_MM, domain 2 only -- otherwise ASSX_E_UNSUPPORTED): the basis half also leaves the data term of
+// the model's negative log-likelihood AT ENTRY behind, one partial per (workgroup, source) at lpart[b * lstride + i],
+// i < nmf_xfed_loss_partials(...); the caller adds the log-det terms and sums.
 int nmf_update_xfed(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* W,
-                    void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st);
+                    void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st,
+                    double* lpart = nullptr, int lstride = 0);
+int nmf_xfed_loss_partials(int M, int F, int T, int K);  // partials per utterance the fused loss writes; 0: not applicable
 
 }  // namespace assx

@@ -23,10 +23,18 @@ namespace assx {
 // ---------------------------------------------------------------------------------------------------------
 // basis half.  grid (G, 1, B), M waves; block = 16 bins, step = 16 frames.  part[slab][(b*M + n)*2 + s][f*K + k]
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int M, int KT, int D2K>
+// LOSS (domain 2, Gaussian model: D2K = IS_MM): the pass also accumulates the data term of the negative log-likelihood
+// of the model it reads -- sum_{n,f,t} P / R + log R with the very P = |w_n^H x|^2 and R = max(Tb V, eps) it forms anyway
+// (ilrma.py:672-675), every (n, f, t) exactly once -- so recording the loss of iteration i costs a dozen instructions per
+// element of iteration i+1's basis half instead of a pass over X of its own (the n_basis <= 4 kernels do the same,
+// assx_stream.hpp).  sum log R travels as a mantissa product + exponent.  One partial per (workgroup, source):
+// lpart[b * lstride + g * M + n]; the caller adds the log-det terms and sums (ilrma_loss_finish_kernel).
+template <typename R, int M, int KT, int D2K, bool LOSS = false>
 __global__ void __launch_bounds__(64 * M)
     nmf_basis_xfed_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, R* Tb, const R* __restrict__ V,
-                          R* part, int* tickets, NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe) {
+                          R* part, int* tickets, NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe,
+                          double* __restrict__ lpart, int lstride) {
+  static_assert(!LOSS || D2K == ASSX_NMF_IS_MM, "the fused loss is the domain-2 Gaussian one");
   using MM = Mfma16<R>;
   using acc_t = typename MM::acc_t;
   constexpr int N = M;
@@ -51,6 +59,8 @@ __global__ void __launch_bounds__(64 * M)
   const unsigned xrow4 = 4u * (unsigned)T * (unsigned)sizeof(Cx<R>);
   const BufRsrc vrs = make_rsrc(vb), xrs = make_rsrc(xm);
 
+  double ltot = 0.0;  // LOSS: this wave's share, summed over the blocks of its range
+
   const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
     const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
@@ -61,6 +71,8 @@ __global__ void __launch_bounds__(64 * M)
     const int f0 = blk * 16;
     const int f = min(f0 + li, F - 1);  // rows past F feed only output rows that are never written
     const bool rows_in = f0 + 16 <= F;
+    double lacc = 0.0, lm = 1.0;  // LOSS: sum P/R of this lane's bin; sum log R as mantissa product + exponent
+    int le = 0;
 
     R tb[KS];  // B operand of product (1): Tb^T[k = 4j + lk][f]
 #pragma unroll
@@ -109,6 +121,7 @@ __global__ void __launch_bounds__(64 * M)
 #pragma unroll
       for (int j = 0; j < KS; ++j) tv = MM::mma(vt[4 * j + lk][li], tb[j], tv);
       R a[4], bm[4];
+      double lprod = 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         Vec2<R> x[M];
@@ -117,11 +130,22 @@ __global__ void __launch_bounds__(64 * M)
         Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
         for (int m = 0; m < M; ++m) cfma(y, tocx<R>(w[m]), tocx<R>(x[m]));
-        nmf_terms<R, D2K>(s, cabs2(y), tv[r], eps, a[r], bm[r]);
-        if (decltype(masked)::value && t0 + MM::crow(r, lane) >= T) {
+        const R P = cabs2(y);
+        nmf_terms<R, D2K>(s, P, tv[r], eps, a[r], bm[r]);
+        const bool dead = decltype(masked)::value && t0 + MM::crow(r, lane) >= T;
+        if (LOSS && !dead) {  // D2K = IS_MM: bm = 1 / max(tv, eps)
+          lacc += (double)(P * bm[r]);
+          lprod *= (double)floor_eps<R>(tv[r], eps);
+        }
+        if (dead) {
           a[r] = 0;
           bm[r] = 0;
         }
+      }
+      if (LOSS) {
+        int e;
+        lm = frexp(lm * lprod, &e);
+        le += e;
       }
 #pragma unroll
       for (int c = 0; c < KT; ++c) {
@@ -147,6 +171,8 @@ __global__ void __launch_bounds__(64 * M)
     for (; t0 + 16 <= te; t0 += 16, ++it) step(IntC<0>(), t0, it & 1);
     if (t0 < te) step(IntC<1>(), t0, it & 1);
 
+    if (LOSS && f0 + li < F)  // a lane's elements all belong to one bin: rows past F (copies of row F-1) drop out here
+      ltot += lacc + (double)le * 0.6931471805599453 + log(lm);
     // ---- end of this workgroup's share of the block: every wave holds its own source's sums
     R* pn = part + ((size_t)slot * BN * 2 + bn * 2) * FK;
     const bool direct = members == 1;
@@ -193,6 +219,10 @@ __global__ void __launch_bounds__(64 * M)
       }
     }
     __syncthreads();  // the tile buffers and s_last are reused by the next block of this range
+  }
+  if (LOSS) {
+    ltot = wave_allreduce_sum<double>(ltot);
+    if (lane == 0) lpart[(size_t)b * lstride + (size_t)g * M + n] = ltot;
   }
 }
 
