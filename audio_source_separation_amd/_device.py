@@ -57,6 +57,19 @@ class _ThreadContexts:
 
 
 _TLS = threading.local()
+_ALL_HELD = []  # every thread's _ThreadContexts, for the interpreter-exit hook below
+
+
+def _destroy_all_contexts():
+    """Destroy the contexts while the HIP runtime is still alive: a context owns pinned staging buffers, events and a
+    pool of host threads (csrc/assx_xfer.hip), and `__del__` during interpreter finalisation is too late to call HIP."""
+    for held in list(_ALL_HELD):
+        held.__del__()
+
+
+import atexit  # noqa: E402
+
+atexit.register(_destroy_all_contexts)
 
 
 def context(dev):
@@ -67,6 +80,7 @@ def context(dev):
     held = getattr(_TLS, "held", None)
     if held is None:
         held = _TLS.held = _ThreadContexts()
+        _ALL_HELD.append(held)
     h = held.by_device.get(dev.index)
     if h is None:
         h = ctypes.c_void_p()
@@ -110,7 +124,11 @@ def to_device(a, dtype, dev):
     A NumPy array goes through `assx_upload` (csrc/assx_xfer.hip): chunks ride a ring of pinned staging buffers, host
     threads copy -- and convert to the device precision, so float32 mode moves half the bytes -- while the previous
     chunk is on the bus.  The call returns once the host array has been consumed; the tail of the DMA is ordered before
-    later work on torch's current stream."""
+    later work on torch's current stream.
+
+    Stream-ordering contract: the returned tensor is valid for work enqueued on torch's CURRENT stream of `dev` (the
+    stream every Engine call uses); a consumer on another stream must first wait on the current one
+    (`other.wait_stream(torch.cuda.current_stream(dev))`)."""
     if isinstance(a, torch.Tensor):
         return a.to(device=dev, dtype=dtype).contiguous()
     arr = np.ascontiguousarray(a)
@@ -142,7 +160,8 @@ def to_numpy(t, np_dtype=None):
     if (not t.is_cuda) or code is None or out_dt not in _NP_CODE or _NP_CODE[out_dt][1] != code[1]:
         a = t.cpu().numpy()
         return a.astype(np_dtype, copy=False) if np_dtype is not None else a
-    t = t.contiguous()
+    # a lazily conjugated / negated view shares its storage with the original: materialise it before the raw copy
+    t = t.resolve_conj().resolve_neg().contiguous()
     out = np.empty(tuple(t.shape), dtype=out_dt)
     if out.size:
         dev = t.device

@@ -37,6 +37,10 @@
 #define COVM_SKIP 0  // timing experiments only (tools/probes/covm_parts.sh): 1 products, 2 fan-out, 4 X requests, 8 publish, 16 barrier, 32 operand requests
 #endif
 
+#if (COVM_SKIP || COVM_TRACE) && !defined(ASSX_PROBE_BUILD)
+#error "COVM_SKIP / COVM_TRACE are timing experiments (wrong results by construction): build them with -DASSX_PROBE_BUILD into a probe library, never into libassx.so"
+#endif
+
 namespace assx {
 
 // which bin of the group a matrix-core row stands for (rows the accumulator layout cannot hand to a lane in its first

@@ -89,15 +89,19 @@ __device__ __forceinline__ double group_spectral_norm(Cd a, int i, int j, bool a
   const Cd g0 = g;
   // G <- G^2 / tr(G^2): tr(G) = 1 throughout, and tr(G^2) -> 1 as G approaches the projector on the dominant eigenvector
   // (1 - tr(G^2) falls quadratically: (l2/l1)^(2^k)).  Every group of the wave has converged once none of them is more than
-  // 1e-14 away from 1 (the Rayleigh quotient below is then exact to ~1e-28 in the eigenvector error) -- typically after 5-8 squarings; the bound of 24 is what round 2 always ran (float32 models
-  // put many bins into the ambiguous band of the condition guard, and 2 x 24 squarings per such wave doubled the sweep).
+  // 1e-14 away from 1 (the Rayleigh quotient below is then within ~5e-15 relative of lambda_max: for the mixed state G_k its
+  // error is linear in 1 - tr(G^2), ample for a guard that compares against a threshold) -- typically after 5-8 squarings;
+  // the bound of 24 is what round 2 always ran (float32 models put many bins into the ambiguous band of the condition guard,
+  // and 2 x 24 squarings per such wave doubled the sweep).  A group whose trace came out 0 (a wholly inactive group of a
+  // tail wave) counts as converged and is not divided by: before, such a wave ran all 24 squarings on NaNs.
   for (int it = 0; it < 24; ++it) {
     Cd h = cmake<double>(0.0, 0.0);
 #pragma unroll
     for (int k = 0; k < M; ++k) cfma(h, group_shfl<GW>(g, i * M + k), group_shfl<GW>(g, k * M + j));
     const double t2 = group_sum<GW>((active && i == j) ? h.x : 0.0);
-    g = cscale(h, 1.0 / t2);
-    if (!__any(!(1.0 - t2 < 1e-14))) break;  // wave-uniform (NaN keeps iterating to the bound, as before)
+    const bool dead = t2 == 0.0;
+    g = cscale(h, dead ? 0.0 : 1.0 / t2);
+    if (!__any(!(dead || 1.0 - t2 < 1e-14))) break;  // wave-uniform (NaN keeps iterating to the bound, as before)
   }
   // Rayleigh quotient tr(G0 Gk) / tr(Gk), tr(Gk) = 1
   const Cd gt = group_shfl<GW>(g, j * M + i);

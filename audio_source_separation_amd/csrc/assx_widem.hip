@@ -47,7 +47,9 @@ static Ws layout(int B, int M, int F, int T, int K, int dtype) {
   off += align_up((size_t)B * ((size_t)M * RB + (size_t)M * ((T + 255) / 256) + F + 64) * 8, 256);
   w.rec = off;  // src_cov_kernel records [g][slot][n][M*M]; ahead of the regions whose size depends on n_basis
   const FlatPart fc = flat_src_cov(B, F, T);
-  off += align_up((size_t)fc.G * fc.S * M * M * M * r, 256);
+  // only the compile-time-M covariance kernels (M <= 8) write these records: the run-time-M path (9 <= M <= 32) never
+  // does, and at M = 32 the region would be ~250 MB of scratch per utterance nobody touches
+  if (M <= 8) off += align_up((size_t)fc.G * fc.S * M * M * M * r, 256);
   w.nmf = off;
   off += align_up(assx_nmf_workspace_bytes(B * M, F, T, Kc, dtype), 256);
   w.tmp = off;

@@ -440,6 +440,9 @@ __device__ __forceinline__ void fence_rows(V (&xr)[M]) {  // value fence on the 
   }
 }
 
+#if defined(PAIRCOV_TRACE) && PAIRCOV_TRACE && !defined(ASSX_PROBE_BUILD)
+#error "PAIRCOV_TRACE adds a debug entry point and stamps: build it with -DASSX_PROBE_BUILD into a probe library, never into libassx.so"
+#endif
 #ifndef PAIRCOV_TRACE
 #define PAIRCOV_TRACE 0
 #endif

@@ -24,6 +24,7 @@ Rank 0 prints ONE JSON line with
                 `value` without the edges, `value_incl_edges` with scatter X / gather Y over RCCL.
 """
 import argparse
+import gc
 import json
 import os
 import platform
@@ -60,6 +61,11 @@ def parse():
     p.add_argument("--cpu-reference-form", default="quarter", choices=["quarter", "full", "off"],
                    help="reference-form (materialising XX/R) CPU leg: on T/4 frames (default), the full shape, or not")
     p.add_argument("--with-loss", action="store_true", help="also report it/s with recordable_loss=True")
+    p.add_argument("--with-f32", type=int, default=1,
+                   help="1 (default): also time the float32 storage mode on the same workload (extra line value_f32; < 1 s)")
+    p.add_argument("--with-default-basis", type=int, default=1,
+                   help="1 (default): also time the reference's default n_basis = 10 (ilrma.py:183), loss off and on "
+                        "(value_k10, value_k10_with_loss; < 1 s)")
     p.add_argument("--prewarm-ms", type=float, default=150.0,
                    help="untimed load before the W warm-up steps: the clocks take ~100 ms of work to settle "
                         "(20 timed steps after 5 / 50 / 500 warm-up steps: 0.2025 / 0.1986 / 0.1945 ms per step)")
@@ -300,11 +306,12 @@ def main():
     cplx = torch.complex128 if args.dtype == "float64" else torch.complex64
     Xrun = X.to(cplx).contiguous()
 
-    def make_model(record_loss):
+    def make_model(record_loss, dtype=None, n_basis=None):
         np.random.seed(111 + rank)
-        m = GaussILRMA(n_basis=K, recordable_loss=record_loss, dtype=args.dtype, device=dev,
+        dtype = dtype or args.dtype
+        m = GaussILRMA(n_basis=n_basis or K, recordable_loss=record_loss, dtype=dtype, device=dev,
                        power_statistic=args.power_statistic)
-        m.input = Xrun
+        m.input = Xrun if dtype == args.dtype else X.to(torch.complex64 if dtype == "float32" else torch.complex128).contiguous()
         m._reset()
         return m
 
@@ -327,14 +334,24 @@ def main():
             model.update_once()
             if with_loss:
                 model._record_loss()  # exactly what GaussILRMA.__call__ does per iteration (value stays in HBM)
+        # like timeit: no cyclic garbage collection inside the timed region (a model of an earlier leg is a reference
+        # cycle -- model <-> loss list -- and a full collection in the middle of a leg costs tens of ms of host time:
+        # round 4 saw a side leg turn host-bound, 374 us per step, for exactly that reason)
+        gc.collect()
+        gc.disable()
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
             model.update_once()
             if with_loss:
                 model._record_loss()
+        host_loop[0] = (time.perf_counter() - t0) / steps  # enqueueing alone (diagnostic: is a leg host-bound?)
         barrier()
-        return D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        dt = D.max_over_ranks(time.perf_counter() - t0, device=dev)
+        gc.enable()
+        return dt
+
+    host_loop = [0.0]
 
     model = make_model(False)
 
@@ -389,6 +406,20 @@ def main():
         dt = timed_steps(ml, args.steps, args.warmup, with_loss=True)
         extra["value_with_loss"] = n_gpus * B * args.steps / dt
         del ml
+
+    # side lines of the same workload (never `value`): the float32 storage mode, and the reference's default n_basis
+    side_steps, side_warm = min(args.steps, 100), min(args.warmup, 10)
+    if args.with_f32 and args.dtype == "float64":
+        m32 = make_model(False, dtype="float32")
+        extra["value_f32"] = round(n_gpus * B * side_steps / timed_steps(m32, side_steps, side_warm), 2)
+        del m32
+    if args.with_default_basis and K != 10:
+        for key, rl in (("value_k10", False), ("value_k10_with_loss", True)):
+            mk = make_model(rl, n_basis=10)
+            extra[key] = round(n_gpus * B * side_steps / timed_steps(mk, side_steps, side_warm, with_loss=rl), 2)
+            extra[key + "_host_us_per_step"] = round(host_loop[0] * 1e6, 1)
+            del mk
+    torch.cuda.empty_cache()
 
     # ---------------- CPU baseline: the NumPy oracle on the same workload (rank 0, N=1 only)
     cpu_baseline = None

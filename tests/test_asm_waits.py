@@ -32,3 +32,33 @@ def test_kernels_do_not_touch_pending_inline_asm_loads(tmp_path, probe):
                        text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("total 0"), r.stdout[-2000:]
     assert open(asm).read().count("#ASMSTART") > 100  # the kernels were really emitted
+
+
+def _hipcc():
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    return hipcc
+
+
+def test_checker_reports_a_register_consumed_before_its_wait(tmp_path):
+    """tests/asm_wait_bad.hip has the round-3 bug on purpose: the checker must name it."""
+    asm = tmp_path / "bad.s"
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S",
+                    os.path.join(ROOT, "tests", "asm_wait_bad.hip"), "-o", str(asm)], check=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_wait_check.py"), str(asm)], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 1 and "asm_wait_bad_kernel" in r.stdout and "ds_read_b128" in r.stdout, r.stdout
+
+
+def test_build_fails_on_a_kernel_that_touches_a_pending_asm_load(tmp_path):
+    """csrc/build.sh walks the device assembly of every translation unit it compiles (ASSX_CHECK, on by default) and a
+    report fails the build: fed the bad kernel (ASSX_SRCS) it must exit non-zero and say why; fed a clean unit, zero."""
+    _hipcc()
+    build = os.path.join(ROOT, "audio_source_separation_amd", "csrc", "build.sh")
+    env = dict(os.environ, ASSX_OBJ=str(tmp_path), ASSX_OUT=str(tmp_path / "lib.so"), ASSX_SRCS="../../tests/asm_wait_bad")
+    r = subprocess.run(["bash", build], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "asm_wait_check FAILED" in r.stderr, (r.returncode, r.stderr[-1500:])
+    env["ASSX_SRCS"] = "assx_api"
+    r = subprocess.run(["bash", build], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "asm_wait_check assx_api: total 0" in r.stdout, (r.returncode, r.stderr[-1500:])

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Everything profiles/<tag>_* is made of, in one run on the GPU box:  bash tools/collect_profiles.sh r03
+# Everything profiles/<tag>_* is made of, in one run on the GPU box:  bash tools/collect_profiles.sh r04
 # (bench lines, rocprofv3 kernel tables, SQ / traffic PMC passes -- PMC only ever with --kernel-trace, as gpurun wants)
-TAG="${1:-r03}"
+TAG="${1:-r04}"
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -21,6 +21,9 @@ py $ROOT/tools/nmf_bench.py float32 > $OUT/nmf_bench_f32.txt 2>/dev/null
 py $ROOT/tools/widem_bench.py 5:4 6:4 7:4 8:4 8:10 > $OUT/widem_bench.txt 2>/dev/null
 py $ROOT/tools/widem_bench.py 5:4 8:4 --dtype float32 > $OUT/widem_bench_f32.txt 2>/dev/null
 py $ROOT/tools/fshard_bench.py > $OUT/fshard_bench_k4.json 2>/dev/null
+for c in cfg1 cfg3; do for d in float64 float32; do py $ROOT/tools/probes/small_cfg_probe.py $c $d 2000 2>/dev/null >> $OUT/small_cfgs.txt; done; done
+for d in float64 float32; do py $ROOT/tools/probes/call_cfgs.py $d 2>/dev/null >> $OUT/call_cfgs.txt; done
+py $B --cpu-iters 0 --basis 10 --with-loss --steps 200 --warmup 20 --roofline-b8 0 > $OUT/bench_f64_k10_with_loss.json 2>/dev/null
 # rocprofv3 kernel tables: the driver's own command line, the K=10 line, NMF config 2, the wide-channel path
 rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg4 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_f32 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --dtype float32 --roofline-b8 0 > /dev/null 2>&1
@@ -38,6 +41,6 @@ py $ROOT/tools/pmc_traffic.py collect > /dev/null 2>&1
 py $ROOT/tools/pmc_traffic.py report > $OUT/cov_traffic.json 2>&1
 cp $ROOT/profiles/cov_traffic.json $OUT/cov_traffic.json 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -mllvm -amdgpu-mfma-vgpr-form $ROOT/tools/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > $OUT/clock_probe.txt; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/mfma_valu_share_probe.hip -o /tmp/share_probe && /tmp/share_probe > $OUT/mfma_valu_share_probe.txt
-cd $ROOT && timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $OUT/gpu_tests.log
+cd $ROOT && timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/gpu_tests.log
 rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] $ROOT/gpurun_out/pmc_fetch_* $ROOT/gpurun_out/pmc_write_* 2>/dev/null
 ls -la $OUT

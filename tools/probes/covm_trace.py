@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of cov_mfma_kernel's trips from a -DCOVM_TRACE=1 build (see assx_cov_mfma.hpp): shader-clock stamps of waves 0
+"""Timeline of cov_mfma_kernel's trips from a -DASSX_PROBE_BUILD -DCOVM_TRACE=1 build (see assx_cov_mfma.hpp): shader-clock stamps of waves 0
 and 5 of workgroup 100 at 8 points of every trip, printed as the mean cycles between consecutive points."""
 import os
 import sys

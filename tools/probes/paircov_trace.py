@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of pair_cov_kernel's trips from a -DPAIRCOV_TRACE=1 build (csrc/assx_widem_cov.hpp): shader-clock stamps of
+"""Timeline of pair_cov_kernel's trips from a -DASSX_PROBE_BUILD -DPAIRCOV_TRACE=1 build (csrc/assx_widem_cov.hpp): shader-clock stamps of
 waves 0 and 5 of workgroup 100 at 6 points of every trip, printed as the mean cycles between consecutive points."""
 import ctypes
 import os
