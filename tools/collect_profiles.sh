@@ -25,9 +25,9 @@ for c in cfg1 cfg3; do for d in float64 float32; do py $ROOT/tools/probes/small_
 for d in float64 float32; do py $ROOT/tools/probes/call_cfgs.py $d 2>/dev/null >> $OUT/call_cfgs.txt; done
 py $B --cpu-iters 0 --basis 10 --with-loss --steps 200 --warmup 20 --roofline-b8 0 > $OUT/bench_f64_k10_with_loss.json 2>/dev/null
 # rocprofv3 kernel tables: the driver's own command line, the K=10 line, NMF config 2, the wide-channel path
-rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg4 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/prof_f32 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --dtype float32 --roofline-b8 0 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats -d $OUT/prof_k10 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --basis 10 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_cfg4 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --with-f32 0 --with-default-basis 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_f32 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --dtype float32 --roofline-b8 0 --with-default-basis 0 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/prof_k10 -o p -- python $B --steps 20 --warmup 5 --cpu-iters 0 --basis 10 --with-f32 0 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_nmf -o p -- python $ROOT/tools/nmf_bench.py float64 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_m8 -o p -- python $ROOT/tools/widem_bench.py 8:4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_m5 -o p -- python $ROOT/tools/widem_bench.py 5:4 > /dev/null 2>&1
