@@ -1082,6 +1082,21 @@ template <typename R, int M>
 int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
            double thr, int32_t* status, int B, int F, hipStream_t st, double den_floor = 0.0, int wb = 1) {
   constexpr int GPW = WAVE / next_pow2_c(M * M);
+  // round 4, ASSX_IP_PAR=1: the sources of a bin side by side in one wave (assx_group_linalg.hpp: ip_par_kernel).  Parity-
+  // green on every test (tests/test_gpu_ops.py runs both forms) and SLOWER: 19.2 us against 14.9 us at config 4
+  // (profiles/r04_ip_par.txt), so the sequential sweep stays the default.  Read on every call.
+  const int par = env_int("ASSX_IP_PAR", 0);
+  if (par) {
+    const dim3 gp(blocks_for((size_t)B * F, GPW / M)), bp(64);
+    if (part)
+      hipLaunchKernelGGL((ip_par_kernel<R, M, true>), gp, bp, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
+                         1.0 / (double)T, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor, wb);
+    else
+      hipLaunchKernelGGL((ip_par_kernel<R, M, false>), gp, bp, 0, st, (const Cx<R>*)U, (const R*)nullptr, fp, 1.0,
+                         (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status, B, F, den_floor, 1);
+    ASSX_LAUNCH_CHECK(ctx, "ip_par_kernel");
+    return 0;
+  }
   const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
   if (part)
     hipLaunchKernelGGL((ip_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,

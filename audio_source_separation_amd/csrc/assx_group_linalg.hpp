@@ -270,6 +270,180 @@ __global__ void __launch_bounds__(64)
 }
 
 // ------------------------------------------------------------------------------------------
+// (a5) IP sweep, sources side by side (round 4; M <= 4).  ip_group_kernel walks the sources one after the other and
+//      every step is a full Gauss-Jordan inversion of W U_n by in-group shuffles: 4 x ~6500 cycles of dependent
+//      latency on a chip that is otherwise idle (16.7 us for the 1025 bins of config 4).  But
+//          (W U_n)^{-1} e_n = U_n^{-1} (W^{-1} e_n),
+//      and U_n^{-1} does not depend on the sweep: here the M sources of a bin are M lane groups of ONE wave; group n
+//      inverts U_n, every group inverts W (the two eliminations interleave), and the Gauss-Seidel part is left with,
+//      per source:  P = U_n^{-1} A  (A = W^{-1} as updated so far: P IS (W U_n)^{-1}, its column n the solution, its
+//      norm the condition guard's), den^2 = a_n^H P e_n (= w^H U_n w: U_n is Hermitian), the new row conj(w) / den, and
+//      a rank-one update of A (Sherman-Morrison; the new pivot r^T a_n equals den up to rounding) -- products and
+//      gathers by shuffles, two rounds deep, instead of an elimination.  The step of source n is computed by every
+//      group (SIMD) and taken from group n, which broadcasts the new W and A.  Same guard (Frobenius bounds, exact
+//      spectral norms in the ambiguous band, group n only), same flags, same floor on the normaliser (t-ILRMA).
+//      Rounding differs from the elimination form by O(cond eps), like any two solvers.
+//      MEASURED (profiles/r04_ip_par.txt): 19.2 us against 14.9 us for ip_group_kernel at config 4 -- the estimate
+//      above counted shuffle rounds; what a lone wave on a SIMD pays is ~32 cycles per DEPENDENT f64 instruction, and
+//      the step still strings ~100 of them together (two 4-deep complex product chains, a complex square root, three
+//      complex reciprocals) behind two eliminations that the compiler does not interleave.  Off by default
+//      (ASSX_IP_PAR=1 selects it; both forms are tested).
+// ------------------------------------------------------------------------------------------
+template <int M, int GW>
+__device__ __forceinline__ bool group_cond_below_if(bool want, Cd a0, Cd ainv, bool active, bool singular, double thr) {
+  const double nA2 = group_sum<GW>(active ? cabs2(a0) : 0.0);
+  const double nI2 = group_sum<GW>(active ? cabs2(ainv) : 0.0);
+  double c2 = nA2 * nI2, thr2 = thr * thr, m2 = (double)(M * M);
+  if (!(c2 > 1e-290 && c2 < 1e290 && thr2 < 1e290)) {
+    c2 = sqrt(nA2) * sqrt(nI2);
+    thr2 = thr;
+    m2 = (double)M;
+  }
+  const bool amb = want && !singular && (c2 == c2) && c2 >= thr2 && c2 < thr2 * m2;
+  bool ok = !singular && (c2 == c2) && c2 < thr2;
+  if (__any(amb)) {
+    const int lane = threadIdx.x & (GW - 1);
+    const int i = active ? lane / M : 0, j = active ? lane % M : 0;
+    const double s = group_spectral_norm<M, GW>(a0, i, j, active) * group_spectral_norm<M, GW>(ainv, i, j, active);
+    if (amb) ok = s < thr;
+  }
+  return ok;
+}
+
+template <typename R, int M, bool FROM_PART>
+__global__ void __launch_bounds__(64)
+    ip_par_kernel(const Cx<R>* __restrict__ U, const R* __restrict__ part, FlatPart fp, double inv_T,
+                  Cx<R>* __restrict__ W, const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
+                  int32_t* __restrict__ status, int B, int F, double den_floor, int wb = 1) {
+  constexpr int N = M;
+  constexpr int MM = M * M;
+  constexpr int GW = next_pow2_c(MM);
+  constexpr int GPW = WAVE / GW;   // lane groups per wave
+  constexpr int BPW = GPW / N;     // bins per wave (M = 4, 3: 1; M = 2: 8)
+  static_assert(BPW >= 1, "a wave holds the sources of at least one bin");
+  const int lane = threadIdx.x & (WAVE - 1);
+  const int e = lane & (GW - 1);
+  const int grp = lane / GW;
+  const bool spare = grp >= BPW * N;                    // M = 3: the fourth group shadows source 2, stores nothing
+  const int slot = spare ? BPW - 1 : grp / N;           // bin of the wave this group works on
+  const int src = spare ? N - 1 : grp - slot * N;       // ... and its source
+  const int lane0 = slot * N * GW;                      // first lane of the bin's groups
+  const long long bin = (long long)blockIdx.x * BPW + slot;
+  const bool in_range = bin < (long long)B * F;
+  const long long bf = in_range ? bin : (long long)B * F - 1;
+  const bool active = e < MM;
+  const int i = active ? e / M : 0, j = active ? e % M : 0;
+  const int b = (int)(bf / F), f = (int)(bf - (long long)b * F);
+
+  Cd w;
+  {
+    const Cx<R> v = W[(size_t)bf * MM + i * M + j];
+    w = cmake<double>((double)v.x, (double)v.y);
+  }
+  Cx<R> cv = cmake<R>((R)0, (R)0);
+  if (pw) cv = C[(size_t)bf * MM + i * M + j];
+  int flags = 0;
+  // ---- this lane's element of U_src
+  Cd u = cmake<double>(0.0, 0.0);
+  if (FROM_PART) {
+    long long jrec = bf;
+    int sub = 0;
+    if (wb > 1) {
+      jrec = (long long)b * ((F + wb - 1) / wb) + f / wb;
+      sub = f % wb;
+    }
+    int g_lo, g_hi;
+    flat_cover(fp, jrec, g_lo, g_hi);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int base = (i == j) ? i : M + 2 * (lo * M - lo * (lo + 1) / 2 + (hi - lo - 1));
+    constexpr int RC = 4;  // records in chunks whose loads are all in flight together; ascending order
+    for (int g0 = g_lo; g0 <= g_hi; g0 += RC) {
+      R vx[RC], vy[RC];
+#pragma unroll
+      for (int c = 0; c < RC; ++c) {
+        const int g = min(g0 + c, g_hi);
+        const R* p = part + (((size_t)g * fp.S + flat_slot(fp, jrec, g)) * wb + sub) * N * MM + src * MM + base;
+        vx[c] = p[0];
+        vy[c] = (i != j) ? p[1] : (R)0;
+      }
+#pragma unroll
+      for (int c = 0; c < RC; ++c)
+        if (g0 + c <= g_hi) {
+          u.x += (double)vx[c];
+          if (i != j) u.y += (double)vy[c];
+        }
+    }
+    if (i > j) u.y = -u.y;
+    u = cmake<double>(u.x * inv_T, u.y * inv_T);
+  } else {
+    const Cx<R> v = U[(((size_t)b * N + src) * F + f) * MM + i * M + j];
+    u = cmake<double>((double)v.x, (double)v.y);
+  }
+
+  // ---- the two inversions that do not wait for the sweep
+  bool sU = false, sW = false;
+  const Cd Bm = group_gj_inverse<M, GW>(u, i, j, sU);  // U_src^{-1}
+  Cd A = group_gj_inverse<M, GW>(w, i, j, sW);         // W^{-1}: identical in every group of the bin
+
+#pragma unroll 1
+  for (int n = 0; n < N; ++n) {
+    const bool mine = src == n;
+    // P = Bm A (= (W U_src)^{-1}); a0 = W U_src for the guard
+    Cd P = cmake<double>(0.0, 0.0), a0 = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      cfma(P, group_shfl<GW>(Bm, i * M + k), group_shfl<GW>(A, k * M + j));
+      cfma(a0, group_shfl<GW>(w, i * M + k), group_shfl<GW>(u, k * M + j));
+    }
+    const bool singular = sU || sW;
+    // gathers along column n: s = a_n^H P e_n, zt_j = sum_k conj(P_kn) A_kj
+    Cd sq = cmake<double>(0.0, 0.0), zt = cmake<double>(0.0, 0.0);
+#pragma unroll
+    for (int k = 0; k < M; ++k) {
+      const Cd pk = group_shfl<GW>(P, k * M + n), akn = group_shfl<GW>(A, k * M + n), akj = group_shfl<GW>(A, k * M + j);
+      cfma(sq, cconj(akn), pk);
+      cfma(zt, cconj(pk), akj);
+    }
+    const Cd wj = group_shfl<GW>(P, j * M + n);   // solution component j
+    const Cd ain = group_shfl<GW>(A, i * M + n);  // column n of A, row i
+    Cd den = csqrt_fast(sq);
+    if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
+    const Cd rj = cdiv_fast(cconj(wj), den);                      // new row n, element j
+    // A' = A - a_n (r^T A - e_n^T) / (r^T a_n),  r^T A = zt / den,  r^T a_n = conj(s) / den
+    const Cd zj = cdiv_fast(zt, den), piv = cdiv_fast(cconj(sq), den);
+    const Cd zd = cmake<double>(zj.x - (j == n ? 1.0 : 0.0), zj.y);
+    const Cd corr = cmul(ain, cdiv_fast(zd, piv));
+    // the guard LAST in program order: its norms (two group sums) are independent of everything above and an in-order wave
+    // only overlaps what the compiler can interleave inside one basic block -- ahead of the wave vote of its slow path
+    const bool ok = group_cond_below_if<M, GW>(mine, a0, P, active, singular, thr);
+    const bool upd = ok && !singular;
+    const Cd An = upd ? cmake<double>(A.x - corr.x, A.y - corr.y) : A;
+    const Cd Wn = (upd && i == n) ? rj : w;
+    if (mine && !spare) {
+      if (singular) flags |= ASSX_STATUS_SINGULAR;
+      else if (!ok) flags |= ASSX_STATUS_COND_REJECT;
+    }
+    // everybody takes the step from group n of its bin
+    const int from = lane0 + n * GW + e;
+    A = cmake<double>(__shfl(An.x, from, WAVE), __shfl(An.y, from, WAVE));
+    w = cmake<double>(__shfl(Wn.x, from, WAVE), __shfl(Wn.y, from, WAVE));
+  }
+
+  if (in_range && active && src == 0 && !spare) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
+  if (pw) {  // per-bin share of mean|y_n|^2 = mean_f w_n^H C_f w_n: group src does source src
+    const Cd c = cmake<double>((double)cv.x, (double)cv.y);
+    const Cd wni = group_shfl<GW>(w, src * M + i);
+    const Cd wnj = group_shfl<GW>(w, src * M + j);
+    const Cd t1 = cmul(wni, c);
+    double term = t1.x * wnj.x + t1.y * wnj.y;  // Re(W[n,i] C[i,j] conj(W[n,j]))
+    if (!active) term = 0.0;
+    const double sum = group_sum<GW>(term);
+    if (in_range && e == 0 && !spare) pw[((size_t)b * N + src) * F + f] = sum;
+  }
+  if (flags && status && in_range && e == 0) atomicOr(&status[b], flags);
+}
+
+// ------------------------------------------------------------------------------------------
 // (f1) ISS sweep (ilrma.py:537-564, iva.py:525-542, 758-775).  The reference applies the rank-1 updates to
 //      Y (N passes that read and rewrite Y).  Y = W X stays linear in W, so the statistics are quadratic forms of
 //      the SAME weighted covariances the IP path uses:

@@ -95,8 +95,10 @@ def test_cov_batched_matches_single(eng):
         assert np.array_equal(Ub[b], U1)
 
 
+@pytest.mark.parametrize("ip_par", ["0", "1"])
 @pytest.mark.parametrize("M,F,T", SHAPES[:3])
-def test_ip_update(eng, M, F, T):
+def test_ip_update(eng, M, F, T, ip_par, monkeypatch):
+    monkeypatch.setenv("ASSX_IP_PAR", ip_par)
     X, W = mixture(M, F, T, 7), rand_filters(M, F, 8)
     r = np.random.default_rng(9).random((M, T)) + 0.05
     U = orc.weighted_covariance(X, r)
@@ -108,8 +110,11 @@ def test_ip_update(eng, M, F, T):
     assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-10, 1e-3)
 
 
-def test_ip_cond_guard_and_singular():
-    """cond(WU) >= threshold keeps the row (ilrma.py:520-528); an exactly singular WU flags LinAlgError."""
+@pytest.mark.parametrize("ip_par", ["0", "1"])
+def test_ip_cond_guard_and_singular(ip_par, monkeypatch):
+    """cond(WU) >= threshold keeps the row (ilrma.py:520-528); an exactly singular WU flags LinAlgError.
+    ip_par = 1: the sources-side-by-side form of the sweep (ASSX_IP_PAR, csrc/assx_group_linalg.hpp: ip_par_kernel)."""
+    monkeypatch.setenv("ASSX_IP_PAR", ip_par)
     from audio_source_separation_amd import _lib
     from audio_source_separation_amd.ops import Engine
     eng = Engine("float64")
