@@ -6,6 +6,7 @@
 // iteration costs a handful of launches instead of 4-7 interpreter round trips (the small BASELINE configurations were
 // bounded by the Python loop, profiles/r03_small_cfgs.txt).
 #include "assx_common.hpp"
+#include "assx_nmf_internal.hpp"
 
 using namespace assx;
 
@@ -15,14 +16,21 @@ int assx_nmf_iterate(assx_ctx* ctx, int n_iter, int kind, double domain, double 
                      void* Tb, void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream) {
   ASSX_REQUIRE_CTX(ctx);
   ASSX_REQUIRE(ctx, n_iter >= 0, ASSX_E_ARG, "n_iter must be >= 0, got %d", n_iter);
+  // loss[i] = criterion of the model after update i (nmf.py:48-53).  It is a function of the model update i + 1 reads, so
+  // it rides on that update's basis half (nmf_update_with_loss); only the last one costs a pass of its own.
   for (int i = 0; i < n_iter; ++i) {
-    int rc = assx_nmf_update_ex(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, stream);
-    if (rc) return rc;
-    if (loss) {
-      rc = assx_nmf_loss_ex(ctx, kind, domain, param, eps, X, Tb, V, loss + (size_t)i * B, ws, B, F, T, K, dtype, stream);
-      if (rc) return rc;
+    int rc;
+    if (i == 0 || !loss) {
+      rc = assx_nmf_update_ex(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, stream);  // validates
+    } else {
+      rc = nmf_update_with_loss(ctx, kind, domain, param, eps, X, Tb, V, loss + (size_t)(i - 1) * B, ws, B, F, T, K, dtype,
+                                (hipStream_t)stream);
     }
+    if (rc) return rc;
   }
+  if (loss && n_iter > 0)
+    return assx_nmf_loss_ex(ctx, kind, domain, param, eps, X, Tb, V, loss + (size_t)(n_iter - 1) * B, ws, B, F, T, K, dtype,
+                            stream);
   return 0;
 }
 

@@ -397,6 +397,8 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
     mfma_loss_split(1, F, T, &FS, &fchunk);
     size_t nl = (size_t)B * F * ((T + 255) / 256);
     if ((size_t)B * FS * ((T + 15) / 16) > nl) nl = (size_t)B * FS * ((T + 15) / 16);
+    const size_t fused = (size_t)B * 4 * (size_t)nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET);  // loss on the basis half
+    if (fused > nl) nl = fused;
     off += align_up(nl * 8, 256);
   }
   w.total = off;
@@ -407,9 +409,10 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
 // (assx_nmf_mfma.hpp) -- one update is 2 launches (4 until round 3)
 template <typename R, int KT>
 int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
-                    int B, int F, int T, int K, int dtype, hipStream_t st) {
+                    int B, int F, int T, int K, int dtype, hipStream_t st, double* loss_prev = nullptr) {
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
   R* part = (R*)((char*)ws + L.part);
+  double* lpart = (double*)((char*)ws + L.lpart);
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   const NmfPart pb = mfma_basis_part<R>(nmf_group(ctx), F, T, KT), pa = mfma_act_part<R>(nmf_group(ctx), F, T, KT);
@@ -418,11 +421,23 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
   hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X,      \
-                     (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe)
+                     (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe, (double*)nullptr, 0, 0.0)
+#define NMF_BASIS_LOSS(D2K)                                                                                    \
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K, true>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X, \
+                     (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe, lpart, 4 * pb.G, eps)
 #define NMF_ACT(D2K)                                                                                           \
   hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pa.G, 1, B), dim3(256), 0, st, (const R*)X,         \
                      (const R*)Tb, (R*)V, part, tickets, 1, pa, B, F, T, K, (R)eps, ts, pe)
-  if (d2 && kind == ASSX_NMF_EUC) NMF_BASIS(ASSX_NMF_EUC);
+  if (loss_prev && !d2) return fail(ctx, ASSX_E_UNSUPPORTED, "nmf_update_mfma: the fused loss needs domain 2 and EUC / KL / IS");
+  if (loss_prev) {
+    // the criterion of the model AT ENTRY rides on the basis half; its per-wave partials are summed right behind it
+    if (kind == ASSX_NMF_EUC) NMF_BASIS_LOSS(ASSX_NMF_EUC);
+    else if (kind == ASSX_NMF_KL) NMF_BASIS_LOSS(ASSX_NMF_KL);
+    else NMF_BASIS_LOSS(ASSX_NMF_IS_MM);
+    ASSX_LAUNCH_CHECK(ctx, "nmf_basis_mfma_kernel(loss)");
+    hipLaunchKernelGGL(sum_reduce_f64_kernel, dim3(B), dim3(256), 0, st, (const double*)lpart, loss_prev, (size_t)4 * pb.G);
+    ASSX_LAUNCH_CHECK(ctx, "sum_reduce_f64_kernel");
+  } else if (d2 && kind == ASSX_NMF_EUC) NMF_BASIS(ASSX_NMF_EUC);
   else if (d2 && kind == ASSX_NMF_KL) NMF_BASIS(ASSX_NMF_KL);
   else if (d2) NMF_BASIS(ASSX_NMF_IS_MM);
   else NMF_BASIS(-1);
@@ -432,6 +447,7 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   else if (d2) NMF_ACT(ASSX_NMF_IS_MM);
   else NMF_ACT(-1);
 #undef NMF_BASIS
+#undef NMF_BASIS_LOSS
 #undef NMF_ACT
   ASSX_LAUNCH_CHECK(ctx, "nmf_act_mfma_kernel");
   return 0;
@@ -477,18 +493,31 @@ inline int small_rank_max() {  // largest n_basis routed to the vector-ALU kerne
 
 template <typename R>
 int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
-                    int B, int F, int T, int K, int dtype, hipStream_t st) {
+                    int B, int F, int T, int K, int dtype, hipStream_t st, double* loss_prev = nullptr) {
   static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
+  if (loss_prev) {
+    // loss of the model at entry: on the basis half where that kernel can (matrix-core path, domain 2, EUC / KL / IS), else
+    // by the stand-alone pass first
+    static const int fuse = nmf_env_int("ASSX_NMF_FUSE_LOSS", 1);
+    const bool fits = (unsigned long long)F * T * sizeof(R) < (1ull << 32) && (unsigned long long)K * T * sizeof(R) < (1ull << 32);
+    const bool small = K <= small_rank_max() && kind == ASSX_NMF_IS_MM && domain == 2.0;
+    const bool fusable = fuse && !no_mfma && fits && !small && K <= NMF_MFMA_MAX_K && domain == 2.0 && kind <= ASSX_NMF_IS_ME;
+    if (!fusable) {
+      int rc = assx_nmf_loss_ex(ctx, kind, domain, param, eps, X, Tb, V, loss_prev, ws, B, F, T, K, dtype, (void*)st);
+      if (rc) return rc;
+      loss_prev = nullptr;
+    }
+  }
   if (K <= small_rank_max() && kind == ASSX_NMF_IS_MM && domain == 2.0 && !no_mfma)
     return nmf_update_small<R>(ctx, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
   // the matrix-core kernels address a matrix with 32-bit byte offsets
   const bool fits32 = (unsigned long long)F * T * sizeof(R) < (1ull << 32) && (unsigned long long)K * T * sizeof(R) < (1ull << 32);
   if (K <= NMF_MFMA_MAX_K && !no_mfma && fits32) {
     switch ((K + 15) / 16) {
-      case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-      case 2: return nmf_update_mfma<R, 2>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-      case 3: return nmf_update_mfma<R, 3>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
-      default: return nmf_update_mfma<R, 4>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
+      case 1: return nmf_update_mfma<R, 1>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st, loss_prev);
+      case 2: return nmf_update_mfma<R, 2>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st, loss_prev);
+      case 3: return nmf_update_mfma<R, 3>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st, loss_prev);
+      default: return nmf_update_mfma<R, 4>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st, loss_prev);
     }
   }
   const NmfWs L = nmf_ws(B, F, T, K, dtype);
@@ -644,6 +673,13 @@ static int nmf_update_xfed_t(assx_ctx* ctx, int kind, double domain, double para
   else XFED(-1);
 #undef XFED
   return 0;
+}
+
+int nmf_update_with_loss(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb,
+                         void* V, double* loss_prev, void* ws, int B, int F, int T, int K, int dtype, hipStream_t st) {
+  if (dtype == ASSX_F64) return nmf_update_impl<double>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st, loss_prev);
+  if (dtype == ASSX_F32) return nmf_update_impl<float>(ctx, kind, domain, param, eps, X, Tb, V, ws, B, F, T, K, dtype, st, loss_prev);
+  return fail(ctx, ASSX_E_ARG, "bad dtype %d", dtype);
 }
 
 int nmf_xfed_loss_partials(int M, int F, int T, int K) {

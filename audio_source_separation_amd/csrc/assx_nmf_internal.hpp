@@ -31,4 +31,11 @@ int nmf_update_xfed(assx_ctx* ctx, int kind, double domain, double param, double
 // half runs map-fed on it (faster than forming it a second time); nullptr: both halves X-fed, no map.
 int nmf_xfed_loss_partials(int M, int F, int T, int K);  // partials per utterance the fused loss writes; 0: not applicable
 
+// One multiplicative update (the checks of assx_nmf_update_ex are the caller's) that also returns, in loss_prev (B,)
+// float64 or nullptr, the criterion of the model AT ENTRY -- i.e. the loss the reference records after the previous
+// update (nmf.py:48-53): accumulated inside the basis half where that is a matrix-core kernel with domain 2 and an EUC /
+// KL / IS rule, by the stand-alone pass otherwise.  assx_nmf_iterate strings these together.
+int nmf_update_with_loss(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb,
+                         void* V, double* loss_prev, void* ws, int B, int F, int T, int K, int dtype, hipStream_t st);
+
 }  // namespace assx

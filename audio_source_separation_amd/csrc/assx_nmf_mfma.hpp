@@ -171,10 +171,16 @@ inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
 // basis half: num|den (F,K) = [A|Bm] (F,T) . V^T.   grid (G, 1, B), 4 waves; block = 16 bins, step = 16 frames.
 //   part[slab][b*2 + s][f*K + k]
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT, int D2K = -1>
+// LOSS (domain 2, EUC / KL / IS: D2K >= 0): the half also accumulates criterion(Tb V, X) of the model it READS (nmf.py:
+// 170-174, 229-233, 288-292; divergence.py:21-45) -- the loss the reference records after the PREVIOUS update -- from the
+// very Tb V and X it holds, every (f, t) exactly once: one partial per (workgroup, wave) at lpart[b * lstride + 4 g + wave],
+// summed by the caller.  IS: sum (ratio - 1) and sum log ratio as a mantissa product; KL needs a log per element.
+template <typename R, int KT, int D2K = -1, bool LOSS = false>
 __global__ void __launch_bounds__(256)
     nmf_basis_mfma_kernel(const R* __restrict__ X, R* Tb, const R* __restrict__ V, R* part, int* tickets, int apply,
-                          NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe) {
+                          NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe,
+                          double* __restrict__ lpart = nullptr, int lstride = 0, double leps = 0.0) {
+  static_assert(!LOSS || D2K >= 0, "the fused loss is evaluated for domain 2 (EUC / KL / IS)");
   using MM = Mfma16<R>;
   using acc_t = typename MM::acc_t;
   constexpr int KS = KT * 4;      // k-slices of 4 in product (1)
@@ -207,6 +213,7 @@ __global__ void __launch_bounds__(256)
   for (int i = 0; i < NLD; ++i) voff[i] = (unsigned)((min(4 * i + lk, K - 1) * (size_t)T + li) * sizeof(R));
   constexpr int XSTEP = MM::crow(1, 0) - MM::crow(0, 0);  // frames between consecutive accumulator registers
   const BufRsrc vrs = make_rsrc(vb), xrs = make_rsrc(xb);
+  double ltot = 0.0;  // LOSS: this wave's share
 
   const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
@@ -218,6 +225,8 @@ __global__ void __launch_bounds__(256)
     const int f0 = blk * 16;
     const int f = min(f0 + li, F - 1);  // rows past F feed only output rows that are never written
     const unsigned xoff = (unsigned)(((size_t)f * T + MM::crow(0, lane)) * sizeof(R));
+    double lacc = 0.0, lm = 1.0;  // LOSS: this lane's bin; sum log ratio (IS) as mantissa product + exponent
+    int le = 0;
 
     R tb[KS];  // B operand of product (1): Tb^T[k = 4j + lk][f]
 #pragma unroll
@@ -263,13 +272,35 @@ __global__ void __launch_bounds__(256)
       for (int j = 0; j < KS; ++j) tv = MM::mma(vt[4 * j + lk][li], tb[j], tv);  // A operand: V^T[t = li][k]
       // (2) elementwise in the accumulator layout
       R a[4], bm[4];
+      double lprod = 1.0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         nmf_terms<R, D2K>(s, xc[r], tv[r], eps, a[r], bm[r]);
-        if (decltype(masked)::value && t0 + MM::crow(r, lane) >= T) {  // ragged last sub-tile of the matrix only
+        const bool dead = decltype(masked)::value && t0 + MM::crow(r, lane) >= T;  // ragged last sub-tile of the matrix only
+        if (LOSS && !dead) {  // criterion((Tb V)^(2/2), x): Tb V as the product gave it, NOT floored
+          const double in = (double)tv[r], xx = (double)xc[r];
+          if (D2K == ASSX_NMF_EUC) {
+            lacc = fma(xx - in, xx - in, lacc);
+          } else {
+            const double in_ = in + leps, tg_ = xx + leps;  // divergence.py:26-27, 39-40
+            const double ratio = tg_ * fast_rcp(in_);
+            if (D2K == ASSX_NMF_KL) {
+              lacc += tg_ * log(ratio) + in_ - tg_;
+            } else {
+              lacc += ratio - 1.0;
+              lprod *= ratio;
+            }
+          }
+        }
+        if (dead) {
           a[r] = 0;
           bm[r] = 0;
         }
+      }
+      if (LOSS && D2K == ASSX_NMF_IS_MM) {
+        int e;
+        lm = frexp(lm * lprod, &e);
+        le += e;
       }
       // (3) num[f, kb] += sum_t a[f,t] V[kb,t]: accumulator register r is k-slice r of the A operand
 #pragma unroll
@@ -300,6 +331,8 @@ __global__ void __launch_bounds__(256)
     for (; t0 + 16 <= te; t0 += 64) step(IntC<0>(), t0);
     if (t0 < te) step(IntC<1>(), t0);
 
+    if (LOSS && f0 + li < F)  // a lane's elements belong to one bin: rows past F (copies of row F-1) drop out here
+      ltot += lacc - ((double)le * 0.6931471805599453 + log(lm));
     // ---- end of the block's share of this workgroup: the 4 waves in ascending order (wave 0 holds the total)
     __syncthreads();  // every wave is done with its staging slice: the memory now carries the combine
     if (wv > 0) {
@@ -378,6 +411,10 @@ __global__ void __launch_bounds__(256)
       }
     }
     __syncthreads();  // the combine memory becomes staging memory again (next block of this range)
+  }
+  if (LOSS) {
+    ltot = wave_allreduce_sum<double>(ltot);
+    if (lane == 0) lpart[(size_t)b * lstride + (size_t)g * 4 + wv] = ltot;
   }
 }
 

@@ -304,9 +304,11 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
  * the entry points above in the order the classes call them, so model(X, iteration=k) equals k x update_once() bit
  * for bit.  The host classes use them when no callback has to run between iterations.
  *
- * assx_nmf_iterate: n_iter x { assx_nmf_update_ex ; loss[i] = assx_nmf_loss_ex } (NMFbase.update, nmf.py:45-53).
- *   loss: device float64 (n_iter, B), or NULL = the criterion is not evaluated (an extension: the reference always
- *   records it). */
+ * assx_nmf_iterate: n_iter x { assx_nmf_update_ex ; loss[i] = criterion of the updated model } (NMFbase.update,
+ *   nmf.py:45-53).  loss: device float64 (n_iter, B), or NULL = the criterion is not evaluated (an extension: the
+ *   reference always records it).  The model is exactly that of n_iter x assx_nmf_update_ex; loss[i] equals
+ *   assx_nmf_loss_ex up to the order of summation: for domain 2 and the EUC / KL / IS rules on the matrix-core path it is
+ *   accumulated inside update i + 1 (which reads the very model it is the criterion of) instead of in a pass of its own. */
 int assx_nmf_iterate(assx_ctx* ctx, int n_iter, int kind, double domain, double param, double eps, const void* X,
                      void* Tb, void* V, double* loss, void* ws, int B, int F, int T, int K, int dtype, void* stream);
 /* assx_auxiva_iterate: the loop of AuxIVAbase.__call__ (iva.py:420-441) for one contrast `kind`:

@@ -178,7 +178,11 @@ def test_nmf_one_call_loop_equals_python_loop(cls_name, K, kw, loss, dtype):
         Tb, V = m(X, iteration=6)
         out.append((Tb, V, np.asarray(m.loss)))
     a, b = out
-    assert _same(a[0], b[0]) and _same(a[1], b[1]) and _same(a[2], b[2])
+    assert _same(a[0], b[0]) and _same(a[1], b[1])
+    # the criterion values agree up to the order of summation: the library loop accumulates loss[i] inside update i + 1
+    # (matrix-core path, domain 2, EUC / KL / IS), the Python loop runs the stand-alone pass
+    tol = 1e-12 if dtype == "float64" else 1e-6
+    np.testing.assert_allclose(a[2], b[2], rtol=tol)
     assert a[2].shape == ((6,) if loss else (0,))
     if loss:
         assert np.all(np.isfinite(a[2]))
