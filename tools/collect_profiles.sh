@@ -42,5 +42,7 @@ py $ROOT/tools/pmc_traffic.py report > $OUT/cov_traffic.json 2>&1
 cp $ROOT/profiles/cov_traffic.json $OUT/cov_traffic.json 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w -mllvm -amdgpu-mfma-vgpr-form $ROOT/tools/probes/clock_probe.hip -o /tmp/clock_probe && /tmp/clock_probe > $OUT/clock_probe.txt; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -w $ROOT/tools/probes/mfma_valu_share_probe.hip -o /tmp/share_probe && /tmp/share_probe > $OUT/mfma_valu_share_probe.txt
 cd $ROOT && timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/gpu_tests.log
+# soak: the suite twice more (timing-dependent errors show as a run that differs)
+for i in 2 3; do timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -1 >> $OUT/soak.txt; done
 rm -rf $OUT/prof_*/*.db $OUT/sq_*_[abc] $ROOT/gpurun_out/pmc_fetch_* $ROOT/gpurun_out/pmc_write_* 2>/dev/null
 ls -la $OUT
