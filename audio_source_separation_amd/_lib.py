@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401,E402
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libassx.so")
+# ASSX_LIB_PATH: another build of the same library (A/B measurements of kernel variants; never a fallback)
+LIB_PATH = os.environ.get("ASSX_LIB_PATH") or os.path.join(_HERE, "csrc", "libassx.so")
 
 F32, F64 = 0, 1
 W_NONE, W_NT, W_NFT = 0, 1, 2

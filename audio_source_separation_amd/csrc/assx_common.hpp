@@ -196,11 +196,25 @@ __device__ __forceinline__ buf_u4 make_rsrc_words(const void* base, size_t bytes
   r.w = 0x00020000u;
   return r;
 }
+// ASSX_X_POLICY_ID: cache-policy bits of the streamed X loads (1 " nt", 2 " sc1", 3 " sc0 sc1"; A/B builds).
+// Default none: measured in round 4 (profiles/r04_x_policy_ab.txt).
+#ifndef ASSX_X_POLICY_ID
+#define ASSX_X_POLICY_ID 0
+#endif
+#if ASSX_X_POLICY_ID == 1
+#define ASSX_X_POLICY " nt"
+#elif ASSX_X_POLICY_ID == 2
+#define ASSX_X_POLICY " sc1"
+#elif ASSX_X_POLICY_ID == 3
+#define ASSX_X_POLICY " sc0 sc1"
+#else
+#define ASSX_X_POLICY ""
+#endif
 __device__ __forceinline__ void buf_ldv_tied(Vec2<double>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" ASSX_X_POLICY : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 __device__ __forceinline__ void buf_ldv_tied(Vec2<float>& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, %3 offen" ASSX_X_POLICY : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 // one real per lane, same contract as buf_ldv_tied
 __device__ __forceinline__ void buf_ld_tied(double& dst, buf_u4 rsrc, unsigned voff, unsigned soff) {
