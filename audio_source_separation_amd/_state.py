@@ -4,8 +4,11 @@ The reference keeps `demix_filter`, `basis`, `activation`, `estimation` as NumPy
 callbacks read after every iteration (egs/bss-example/ilrma/test_gauss-ilrma.ipynb cells 69-78)
 and that `_reset` warm-starts from via `hasattr` (src/bss/ilrma.py:67-72, 88-104).  Here the
 authoritative copy is a device tensor; the NumPy view is downloaded lazily and cached until a
-kernel touches the tensor again, so a loop without callbacks never leaves the GPU.  Downloaded views are READ-ONLY
-(in-place edits would not reach the device): assign a new array to modify state.
+kernel touches the tensor again, so a loop without callbacks never leaves the GPU.  The downloaded view is a tracked
+ndarray (round 4): an in-place edit -- `model.basis[...] *= s`, `model.demix_filter[f] = w`, also through slices of it --
+marks the device copy stale, and the next kernel uploads the edited host array first, as in the reference, whose
+attributes are plain NumPy arrays (src/bss/ilrma.py:97-104).  Edits of an OLD snapshot (the model has been updated
+since it was handed out) do nothing, like edits of any copy.
 """
 import numpy as np
 
@@ -13,11 +16,50 @@ from ._device import to_device, to_numpy, torch
 
 
 class _Entry:
-    __slots__ = ("host", "dev")
+    __slots__ = ("host", "dev", "owner")
 
-    def __init__(self, host=None, dev=None):
+    def __init__(self, host=None, dev=None, owner=None):
         self.host = host
         self.dev = dev
+        self.owner = owner  # the model: an edit of state invalidates a loss value parked for the next pass
+
+
+class TrackedArray(np.ndarray):
+    """The NumPy face of a device-resident model array.  Behaves like the ndarray it is; writing into it (or into a view
+    of it) while it is still the model's current snapshot drops the device copy, so that the next kernel sees the edit."""
+
+    _entry = None
+    _root = None
+
+    def __array_finalize__(self, obj):
+        if obj is not None:
+            self._entry = getattr(obj, "_entry", None)
+            self._root = getattr(obj, "_root", None)
+
+    def _edited(self):
+        ent = self._entry
+        if ent is not None and ent.host is not None and ent.host is self._root and ent.dev is not None \
+                and np.may_share_memory(self, ent.host):  # a .copy() of the snapshot is the caller's own array
+            resolve = getattr(ent.owner, "_resolve_deferred_loss", None)
+            if resolve is not None:
+                resolve()  # a loss still to be folded into the next pass refers to the state as it was
+            ent.dev = None
+
+    def __setitem__(self, key, value):
+        self._edited()  # before the write: a deferred loss must still see the old values on the device (it does: dev is intact until dropped)
+        super().__setitem__(key, value)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        plain = tuple(np.asarray(x) if isinstance(x, TrackedArray) else x for x in inputs)
+        if out is not None:
+            for o in out:
+                if isinstance(o, TrackedArray):
+                    o._edited()
+            kwargs["out"] = tuple(o.view(np.ndarray) if isinstance(o, TrackedArray) else o for o in out)
+        res = getattr(ufunc, method)(*plain, **kwargs)
+        if out is not None:
+            return out[0] if len(out) == 1 else out
+        return res  # results of arithmetic are plain arrays
 
 
 class DeviceArray:
@@ -43,10 +85,11 @@ class DeviceArray:
         if ent.host is None:
             a = to_numpy(ent.dev, np.complex128 if self.complex_ else np.float64)
             a = a if obj._batched else a[0]
-            # the device tensor stays authoritative: an in-place edit of this snapshot (`model.demix_filter[...] *= s`)
-            # would be silently dropped at the next kernel, whereas it takes effect in the reference.  Make it fail
-            # loudly instead; ASSIGNING an array (`model.demix_filter = new`) is the supported way to modify state.
-            a.setflags(write=False)
+            # in the reference these are plain attributes: `model.demix_filter[...] *= s` takes effect at the next
+            # update.  The snapshot is tracked: a write drops the device copy, the next kernel uploads the host array.
+            a = a.view(TrackedArray)
+            a._entry, a._root = ent, a
+            ent.owner = obj
             ent.host = a
         return ent.host
 

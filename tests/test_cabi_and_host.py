@@ -218,6 +218,31 @@ def test_lazy_loss_list_blocks_of_a_one_call_loop():
     assert len(ll) == 2 and np.array_equal(ll[1], [3.0, 4.0]) and np.asarray(ll).shape == (2, 2)
 
 
+def test_tracked_snapshot_marks_the_device_copy_stale_on_write():
+    """`model.basis[...] *= s` must reach the device (the reference's attributes are plain arrays): the NumPy snapshot of a
+    device array is tracked; writes -- __setitem__, ufuncs with out=, through views -- drop the device copy; copies and
+    arithmetic results are plain, untracked arrays."""
+    from audio_source_separation_amd._state import TrackedArray, _Entry
+    ent = _Entry(dev="device tensor")
+    a = np.arange(12.0).reshape(3, 4).view(TrackedArray)
+    a._entry, a._root = ent, a
+    ent.host = a
+    assert type(a * 2) is np.ndarray and ent.dev is not None       # reading / arithmetic: nothing happens
+    assert float(a.sum()) == 66.0 and ent.dev is not None
+    a[1][:] = 0                                                    # through a view
+    assert ent.dev is None and np.array_equal(a[1], np.zeros(4))
+    ent.dev = "again"
+    a *= 3                                                         # in-place ufunc
+    assert ent.dev is None and a[0, 1] == 3.0
+    ent.dev = "again"
+    c = a.copy()
+    c[0, 0] = 5                                                    # the caller's own copy
+    assert ent.dev == "again"
+    ent.host = None                                                # the model moved on: `a` is an old snapshot
+    a[0, 0] = 7
+    assert ent.dev == "again"
+
+
 def test_stft_geometry_matches_scipy_semantics():
     """assx_stft_num_frames / assx_istft_num_samples (host arithmetic, no GPU) against the oracle's restatement of
     scipy.signal.stft / istft (boundary + padding rules) over many lengths, frame sizes and hops."""

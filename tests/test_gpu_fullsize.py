@@ -251,16 +251,49 @@ def test_iss_callback_can_rebuild_the_filter():
     assert len(seen) == 4 and max(seen[:-1]) < 1e-9
 
 
-def test_state_snapshots_are_read_only_and_assignment_works():
+def test_state_edits_in_place_and_by_assignment_reach_the_device():
+    """The reference's model arrays are plain NumPy attributes: `model.basis[...] *= s` or `model.demix_filter[f] = w`
+    between updates take effect at the next one (ilrma.py:97-104).  Here the arrays live in HBM; the snapshot handed out
+    is tracked, an in-place edit (also through a slice) makes the next kernel upload it.  Round 3 refused such edits."""
     from audio_source_separation_amd.bss.ilrma import GaussILRMA
     X = mixture(2, 9, 128, 80)
+
+    def run(edit):
+        np.random.seed(1)
+        m = GaussILRMA(n_basis=2)
+        m(X, iteration=1)
+        edit(m)
+        m.update_once()
+        return m.demix_filter.copy(), m.basis.copy(), m.activation.copy()
+
+    def in_place(m):
+        m.basis[...] *= 1.5            # ufunc with out=
+        m.demix_filter[3] = 2.0 * m.demix_filter[3]   # __setitem__
+        row = m.activation[1]          # a view of the snapshot
+        row[0, :7] = 0.25
+
+    def by_assignment(m):
+        T, W, V = m.basis.copy(), m.demix_filter.copy(), m.activation.copy()
+        T *= 1.5
+        W[3] = 2.0 * W[3]
+        V[1, 0, :7] = 0.25
+        m.basis, m.demix_filter, m.activation = T, W, V
+
+    a, b, c = run(in_place), run(by_assignment), run(lambda m: None)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert not np.array_equal(a[0], c[0]) and not np.array_equal(a[1], c[1])   # the edits did something
     np.random.seed(1)
     m = GaussILRMA(n_basis=2)
     m(X, iteration=1)
     W = m.demix_filter
-    with pytest.raises(ValueError):
-        W[0, 0, 0] = 0  # an in-place edit of a downloaded snapshot would be lost: refused loudly
-    m.demix_filter = W * 2.0  # assignment is the supported way
+    Wc = W.copy()
+    Wc[0] = 0                       # a copy is the caller's own array
+    old = m.demix_filter
+    m.update_once()
+    old[0] = 0                      # an OLD snapshot: the model has moved on, nothing happens to it
+    assert np.abs(m.demix_filter[0]).max() > 0
+    m.demix_filter = W * 2.0        # assignment still works
     assert np.array_equal(m.demix_filter, W * 2.0)
     assert rel_err(m.separate(X, m.demix_filter), 2.0 * orc.separate(X, W)) < 1e-12
 
