@@ -237,10 +237,6 @@ __global__ void __launch_bounds__(64)
     const Cd a0 = a;
     bool singular = false;
     a = group_gj_inverse<M, GW>(a, i, j, singular);
-    // ---- cond_2(WU) < threshold ?
-    const bool ok = group_cond_below<M, GW>(a0, a, active, singular, thr);
-    if (singular) flags |= ASSX_STATUS_SINGULAR;       // numpy.linalg.solve raises here
-    else if (!ok) flags |= ASSX_STATUS_COND_REJECT;    // keep the old row (np.where(condition, ..., w_n_Hermite))
     // ---- w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
     const Cd wi = group_shfl<GW>(a, i * M + n);
     const Cd wj = group_shfl<GW>(a, j * M + n);
@@ -249,7 +245,14 @@ __global__ void __launch_bounds__(64)
     const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
     Cd den = csqrt_fast(q);
     if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
-    if (ok && !singular && i == n) w = cdiv_fast(cconj(wj), den);
+    const Cd wnew = cdiv_fast(cconj(wj), den);
+    // ---- cond_2(WU) < threshold ?  LAST in program order (round 4): its two norm sums depend only on a0 and the inverse, and
+    // an in-order wave overlaps them with the chain above only if they sit in the same basic block -- i.e. ahead of the
+    // wave vote of the guard's slow path; evaluated first, they stood in front of the row's whole chain.
+    const bool ok = group_cond_below<M, GW>(a0, a, active, singular, thr);
+    if (singular) flags |= ASSX_STATUS_SINGULAR;       // numpy.linalg.solve raises here
+    else if (!ok) flags |= ASSX_STATUS_COND_REJECT;    // keep the old row (np.where(condition, ..., w_n_Hermite))
+    if (ok && !singular && i == n) w = wnew;
   }
 
   if (in_range && active) W[(size_t)bf * MM + i * M + j] = cmake<R>((R)w.x, (R)w.y);
