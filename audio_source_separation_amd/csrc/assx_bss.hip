@@ -1483,7 +1483,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
                            (const Cx<R>*)W, lp, B, F, T, ls, ncov);
         ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
         rc = nmf_update_xfed(ctx, ASSX_NMF_IS_MM, domain, 0.0, eps, X, W, Tb, V, (char*)ws + L.nmf, B, MM, F, T, K, dtype,
-                             st, lp, ls, (char*)ws + L.map);
+                             st, lp, ls);
         if (rc != ASSX_E_UNSUPPORTED) {
           if (rc) return rc;
           hipLaunchKernelGGL(ilrma_loss_finish_kernel, dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lp, loss_prev,
@@ -1523,8 +1523,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
         // round 4: no map at all where the X-fed halves apply (n_basis <= 32): |w_n^H x|^2 is formed inside the two
         // matrix-core kernels from an X tile shared by the workgroup's waves (assx_nmf_xfed.hpp) -- 2 launches and
         // 2 x 268.7 MB read instead of 3 launches, 268.7 MB read + 134 MB written + 2 x 134 MB read
-        rc = nmf_update_xfed(ctx, ASSX_NMF_IS_MM, domain, 0.0, eps, X, W, Tb, V, (char*)ws + L.nmf, B, MM, F, T, K, dtype, st,
-                             nullptr, 0, pw);
+        rc = nmf_update_xfed(ctx, ASSX_NMF_IS_MM, domain, 0.0, eps, X, W, Tb, V, (char*)ws + L.nmf, B, MM, F, T, K, dtype, st);
         if (rc != ASSX_E_UNSUPPORTED) return rc;
         hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
                            (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});
@@ -1987,8 +1986,7 @@ int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void*
     if (K > KU && wide) {  // n_basis > 4: P = |W x|^2 once, then the batched tNMF-type update on the matrix cores
       const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
       R* pw = (R*)((char*)ws + L.map);
-      int rx = nmf_update_xfed(ctx, ASSX_NMF_T_RAW, 2.0, nu, eps, X, W, Tb, V, (char*)ws + L.nmf, B, MM, F, T, K, dtype, st,
-                               nullptr, 0, pw);
+      int rx = nmf_update_xfed(ctx, ASSX_NMF_T_RAW, 2.0, nu, eps, X, W, Tb, V, (char*)ws + L.nmf, B, MM, F, T, K, dtype, st);
       if (rx != ASSX_E_UNSUPPORTED) return rx;
       hipLaunchKernelGGL((demix_power_map_kernel<R, MM>), dim3(blocks_for(T, 256), F, B), dim3(256), 0, st,
                          (const Cx<R>*)X, (const Cx<R>*)W, pw, Dims{B, F, T, 0});

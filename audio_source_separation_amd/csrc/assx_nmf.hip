@@ -637,13 +637,13 @@ static bool xfed_applies(int kind, int M, int K) {
 template <typename R, int M, int KT>
 static int nmf_update_xfed_t(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X,
                              const void* W, void* Tb, void* V, void* ws, int B, int F, int T, int K, int dtype,
-                             hipStream_t st, double* lpart, int lstride, void* pmap) {
+                             hipStream_t st, double* lpart, int lstride) {
   const NmfWs L = nmf_ws(B * M, F, T, K, dtype);
   R* part = (R*)((char*)ws + L.part);
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   const NmfPart pb = xfed_basis_part(F, T, KT), pa = xfed_act_part(F, T, KT);
-  int* tickets = ensure_tickets(ctx, (size_t)B * M * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st);
+  int* tickets = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st);
   if (!tickets) return ASSX_E_ARG;
   const bool d2 = domain == 2.0 && kind == ASSX_NMF_IS_MM;
 #define XFED(D2K)                                                                                                        \
@@ -651,23 +651,15 @@ static int nmf_update_xfed_t(assx_ctx* ctx, int kind, double domain, double para
     if (lpart)                                                                                                           \
       hipLaunchKernelGGL((nmf_basis_xfed_kernel<R, M, KT, ASSX_NMF_IS_MM, true>), dim3(pb.G, 1, B), dim3(64 * M), 0, st, \
                          (const Cx<R>*)X, (const Cx<R>*)W, (R*)Tb, (const R*)V, part, tickets, pb, B, F, T, K, (R)eps,   \
-                         ts, pe, lpart, lstride, (R*)pmap);                                                              \
+                         ts, pe, lpart, lstride);                                                                        \
     else                                                                                                                 \
       hipLaunchKernelGGL((nmf_basis_xfed_kernel<R, M, KT, D2K>), dim3(pb.G, 1, B), dim3(64 * M), 0, st, (const Cx<R>*)X, \
                          (const Cx<R>*)W, (R*)Tb, (const R*)V, part, tickets, pb, B, F, T, K, (R)eps, ts, pe,            \
-                         (double*)nullptr, 0, (R*)pmap);                                                                 \
+                         (double*)nullptr, 0);                                                                           \
     ASSX_LAUNCH_CHECK(ctx, "nmf_basis_xfed_kernel");                                                                     \
-    if (pmap) {                                                                                                          \
-      /* activation half on the map the basis half left behind: the map-fed kernel, batch = B x sources */              \
-      const NmfPart pm = mfma_act_part<R>(M, F, T, KT);                                                                  \
-      hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pm.G, 1, B * M), dim3(256), 0, st, (const R*)pmap,     \
-                         (const R*)Tb, (R*)V, part, tickets, 1, pm, B * M, F, T, K, (R)eps, ts, pe);                     \
-      ASSX_LAUNCH_CHECK(ctx, "nmf_act_mfma_kernel");                                                                     \
-    } else {                                                                                                             \
-      hipLaunchKernelGGL((nmf_act_xfed_kernel<R, M, KT, D2K>), dim3(pa.G, 1, B), dim3(64 * M), 0, st, (const Cx<R>*)X,   \
-                         (const Cx<R>*)W, (const R*)Tb, (R*)V, part, tickets, pa, B, F, T, K, (R)eps, ts, pe);           \
-      ASSX_LAUNCH_CHECK(ctx, "nmf_act_xfed_kernel");                                                                     \
-    }                                                                                                                    \
+    hipLaunchKernelGGL((nmf_act_xfed_kernel<R, M, KT, D2K>), dim3(pa.G, 1, B), dim3(64 * M), 0, st, (const Cx<R>*)X,     \
+                       (const Cx<R>*)W, (const R*)Tb, (R*)V, part, tickets, pa, B, F, T, K, (R)eps, ts, pe);             \
+    ASSX_LAUNCH_CHECK(ctx, "nmf_act_xfed_kernel");                                                                       \
   } while (0)
   if (d2) XFED(ASSX_NMF_IS_MM);
   else XFED(-1);
@@ -689,24 +681,19 @@ int nmf_xfed_loss_partials(int M, int F, int T, int K) {
 
 int nmf_update_xfed(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* W,
                     void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st,
-                    double* lpart, int lstride, void* pmap) {
-  // Default: both halves from X, no map at all.  ASSX_XFED_ACT=map: the basis half also leaves the demixed power behind
-  // and the activation half is the map-fed kernel -- measured SLOWER (profiles/r04_xfed_act_route.txt: the 134 MB of
-  // 32-byte stores take the basis half from 67 to 106 us; the map-fed activation half saves only 33 of them back)
-  static const char* act_env = getenv("ASSX_XFED_ACT");
-  if (!(act_env && act_env[0] == 'm')) pmap = nullptr;
+                    double* lpart, int lstride) {
   if (!xfed_applies(kind, M, K)) return ASSX_E_UNSUPPORTED;
   if (lpart && !(kind == ASSX_NMF_IS_MM && domain == 2.0)) return ASSX_E_UNSUPPORTED;
   if ((unsigned long long)M * F * T * 16 >= (1ull << 32) || (unsigned long long)K * T * 8 >= (1ull << 32)) return ASSX_E_UNSUPPORTED;
   // the partition arithmetic of the kernels is 32-bit and a workgroup holds < 64 KB of LDS
 #define XFED_BY(RT)                                                                                                     \
   switch (M * 10 + (K + 15) / 16) {                                                                                     \
-    case 21: return nmf_update_xfed_t<RT, 2, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride, pmap); \
-    case 22: return nmf_update_xfed_t<RT, 2, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride, pmap); \
-    case 31: return nmf_update_xfed_t<RT, 3, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride, pmap); \
-    case 32: return nmf_update_xfed_t<RT, 3, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride, pmap); \
-    case 41: return nmf_update_xfed_t<RT, 4, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride, pmap); \
-    case 42: return nmf_update_xfed_t<RT, 4, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride, pmap); \
+    case 21: return nmf_update_xfed_t<RT, 2, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 22: return nmf_update_xfed_t<RT, 2, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 31: return nmf_update_xfed_t<RT, 3, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 32: return nmf_update_xfed_t<RT, 3, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 41: return nmf_update_xfed_t<RT, 4, 1>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
+    case 42: return nmf_update_xfed_t<RT, 4, 2>(ctx, kind, domain, param, eps, X, W, Tb, V, ws, B, F, T, K, dtype, st, lpart, lstride); \
   }
   if (dtype == ASSX_F64) {
     XFED_BY(double)

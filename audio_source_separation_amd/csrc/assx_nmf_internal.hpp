@@ -26,9 +26,7 @@ int nmf_half_partials(assx_ctx* ctx, int kind, double domain, double param, doub
 // i < nmf_xfed_loss_partials(...); the caller adds the log-det terms and sums.
 int nmf_update_xfed(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, const void* W,
                     void* Tb, void* V, void* ws, int B, int M, int F, int T, int K, int dtype, hipStream_t st,
-                    double* lpart = nullptr, int lstride = 0, void* pmap = nullptr);
-// pmap: optional (B,M,F,T) reals of scratch; given, the basis half also writes the demixed power there and the activation
-// half runs map-fed on it (faster than forming it a second time); nullptr: both halves X-fed, no map.
+                    double* lpart = nullptr, int lstride = 0);
 int nmf_xfed_loss_partials(int M, int F, int T, int K);  // partials per utterance the fused loss writes; 0: not applicable
 
 // One multiplicative update (the checks of assx_nmf_update_ex are the caller's) that also returns, in loss_prev (B,)

@@ -33,9 +33,10 @@ template <typename R, int M, int KT, int D2K, bool LOSS = false>
 __global__ void __launch_bounds__(64 * M)
     nmf_basis_xfed_kernel(const Cx<R>* __restrict__ X, const Cx<R>* __restrict__ W, R* Tb, const R* __restrict__ V,
                           R* part, int* tickets, NmfPart pt, int B, int F, int T, int K, R eps, TermSpec s, PowSpec pe,
-                          double* __restrict__ lpart, int lstride, R* __restrict__ pmap) {
-  // pmap != nullptr: the demixed power this half forms is also left behind, (B,N,F,T) reals -- the activation half then
-  // runs map-fed (nmf_act_mfma_kernel: half the LDS traffic and vector work of the X-fed one) without a map LAUNCH.
+                          double* __restrict__ lpart, int lstride) {
+  // (Round 4 also tried leaving the demixed power behind for a map-fed activation half: the 134 MB of 32-byte stores took
+  // this half from 67 to 106 us, the map-fed activation half gave back 33 -- profiles/r04_xfed_act_route.txt -- and the
+  // per-element store branches cut the block the compiler schedules.  Removed.)
   static_assert(!LOSS || D2K == ASSX_NMF_IS_MM, "the fused loss is the domain-2 Gaussian one");
   using MM = Mfma16<R>;
   using acc_t = typename MM::acc_t;
@@ -135,7 +136,6 @@ __global__ void __launch_bounds__(64 * M)
         const R P = cabs2(y);
         nmf_terms<R, D2K>(s, P, tv[r], eps, a[r], bm[r]);
         const bool dead = decltype(masked)::value && t0 + MM::crow(r, lane) >= T;
-        if (pmap && !dead && f0 + li < F) pmap[(bn * F + f) * T + t0 + MM::crow(r, lane)] = P;
         if (LOSS && !dead) {  // D2K = IS_MM: bm = 1 / max(tv, eps)
           lacc += (double)(P * bm[r]);
           lprod *= (double)floor_eps<R>(tv[r], eps);
