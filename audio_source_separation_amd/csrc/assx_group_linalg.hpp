@@ -17,15 +17,98 @@ namespace assx {
 //      reduced here (saves the separate finalize launch); otherwise as dense U (B,N,F,M,M).
 //      Optionally emits pw[b][n][f] = w_n^H C_f w_n (the per-bin share of the power normalisation statistic).
 // ------------------------------------------------------------------------------------------
+// ---- data movement inside a lane group without the LDS pipe (round 4).  __shfl is ds_bpermute_b32: every use is a round
+//      trip through the LDS unit behind an s_waitcnt, and the per-bin sweeps are single dependent chains on an otherwise
+//      idle SIMD -- their time is the SUM of such latencies.  The patterns that are fixed at compile time and stay inside a
+//      DPP row (16 lanes) move with DPP instead: row_newbcast (one lane of every row to the whole row), quad_perm (a lane
+//      of every quad to the whole quad, the xor-1 / xor-2 exchanges) and row_ror.  Pure data movement: no result changes.
+//      ASSX_GROUP_DPP=0 (A/B builds, tools/probes/ip_dpp_probe.hip) keeps the ds_bpermute forms.
+#ifndef ASSX_GROUP_DPP
+#define ASSX_GROUP_DPP 1
+#endif
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E, DPP_ROW_ROR = 0x120, DPP_ROW_NEWBCAST = 0x150;
+constexpr int dpp_quad_bcast(int k) { return k * 0x55; }
+template <int CTRL, int BANKS = 0xF>
+__device__ __forceinline__ double dpp_mov(double v, double old = 0.0) {  // lanes of the banks (quads) not in BANKS keep `old`
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xF, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xF, BANKS, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {  // l wave-uniform
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// butterfly sum over the group, every lane ends with the total.  The pairing is that of v += shfl_xor(v, off), off = GW/2
+// .. 1, in both forms: after the steps with off >= 16 the values repeat with period 16, so lane e ^ 8 holds what the lane
+// 8 further round its row holds, and after off = 8 (period 8) lane e ^ 4 what the lane 4 further round holds.
 template <int GW>
 __device__ __forceinline__ double group_sum(double v) {
+  static_assert(GW == 1 || GW == 4 || GW >= 16, "a group is a quad or whole DPP rows");
+#if ASSX_GROUP_DPP
+#pragma unroll
+  for (int off = GW / 2; off >= 16; off >>= 1) v += __shfl_xor(v, off, GW);
+  if (GW >= 16) v += dpp_mov<DPP_ROW_ROR + 8>(v);
+  if (GW >= 8) v += dpp_mov<DPP_ROW_ROR + 4>(v);
+  if (GW >= 4) v += dpp_mov<DPP_QUAD_XOR2>(v);
+  if (GW >= 2) v += dpp_mov<DPP_QUAD_XOR1>(v);
+#else
 #pragma unroll
   for (int off = GW / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, GW);
+#endif
   return v;
 }
 template <int GW>
 __device__ __forceinline__ Cd group_shfl(Cd v, int src) {
   return cmake<double>(__shfl(v.x, src, GW), __shfl(v.y, src, GW));
+}
+// lane L (compile time) of every group, to the whole group
+template <int GW, int L>
+__device__ __forceinline__ double group_bcast(double v) {
+#if ASSX_GROUP_DPP
+  if constexpr (GW == 64) return readlane_f64(v, L);
+  else if constexpr (GW == 16) return dpp_mov<DPP_ROW_NEWBCAST + L>(v);
+  else if constexpr (GW == 4) return dpp_mov<dpp_quad_bcast(L)>(v);
+  else
+#endif
+    return __shfl(v, L, GW);
+}
+template <int GW, int L>
+__device__ __forceinline__ Cd group_bcast(Cd v) {
+  return cmake<double>(group_bcast<GW, L>(v.x), group_bcast<GW, L>(v.y));
+}
+// element (i, C) of an M x M matrix spread one element per lane (lane i * M + j of the group), to lane (i, j): column C
+// (compile time) along the rows
+template <int M, int GW, int C>
+__device__ __forceinline__ double group_row_bcast(double v, int i) {
+#if ASSX_GROUP_DPP
+  if constexpr (M == 4) return dpp_mov<dpp_quad_bcast(C)>(v);  // a matrix row is a quad
+  else if constexpr (M == 2) return dpp_mov<(C) | (C << 2) | ((2 + C) << 4) | ((2 + C) << 6)>(v);  // half a quad
+  else if constexpr (M == 8) {  // a matrix row is half a DPP row: banks 0-1 and 2-3
+    const double lo = dpp_mov<DPP_ROW_NEWBCAST + C, 0x3>(v, v);
+    return dpp_mov<DPP_ROW_NEWBCAST + 8 + C, 0xC>(v, lo);
+  } else
+#endif
+    return __shfl(v, i * M + C, GW);
+}
+template <int M, int GW, int C>
+__device__ __forceinline__ Cd group_row_bcast(Cd v, int i) {
+  return cmake<double>(group_row_bcast<M, GW, C>(v.x, i), group_row_bcast<M, GW, C>(v.y, i));
+}
+
+// the same with a wave-uniform column known at run time only (the source index of a sweep): M uniform branches
+template <int M, int GW>
+__device__ __forceinline__ Cd group_row_bcast_rt(Cd v, int i, int col) {
+#if ASSX_GROUP_DPP
+  if constexpr (M == 2 || M == 4 || M == 8) {
+    Cd r = v;
+    static_for<M>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      if (col == k) r = group_row_bcast<M, GW, k>(v, i);
+    });
+    return r;
+  } else
+#endif
+    return group_shfl<GW>(v, i * M + col);
 }
 
 // In-group Gauss-Jordan inverse with partial pivoting (LAPACK's pivot rule: first max of |re|+|im|) of the M x M
@@ -33,34 +116,37 @@ __device__ __forceinline__ Cd group_shfl(Cd v, int src) {
 template <int M, int GW>
 __device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singular) {
   int piv[M];
-#pragma unroll
-  for (int c = 0; c < M; ++c) {
+  static_for<M>([&](auto cc) {
+    constexpr int c = decltype(cc)::value;
     int p = c;
     double best = -1.0;
-#pragma unroll
-    for (int r = c; r < M; ++r) {
-      const double m1 = cabs1(group_shfl<GW>(a, r * M + c));
+    const double m1own = cabs1(a);  // the metric travels (one real), not the element
+    static_for<M - c>([&](auto rc) {
+      constexpr int r = c + decltype(rc)::value;
+      const double m1 = group_bcast<GW, r * M + c>(m1own);
       if (m1 > best) {
         best = m1;
         p = r;
       }
-    }
+    });
     if (!(best > 0.0)) singular = true;
     piv[c] = p;
     const int src_i = (i == c) ? p : ((i == p) ? c : i);
     a = group_shfl<GW>(a, src_i * M + j);  // row interchange c <-> p
-    const Cd pv = group_shfl<GW>(a, c * M + c);
+    const Cd pv = group_bcast<GW, c * M + c>(a);
     const Cd ipv = crcp_fast(pv);
+    // (fetching the pivot row in the round trip of the interchange -- row p before it -- was measured: no faster, and the
+    // moved loads made the compiler contract the products below differently: last-bit changes in float64.  Not kept.)
     const Cd acj = group_shfl<GW>(a, c * M + j);
     const Cd rcj = cmul((j == c) ? cmake<double>(1.0, 0.0) : acj, ipv);
-    const Cd fic = group_shfl<GW>(a, i * M + c);
+    const Cd fic = group_row_bcast<M, GW, c>(a, i);
     if (i == c) {
       a = rcj;
     } else {
       const Cd base = (j == c) ? cmake<double>(0.0, 0.0) : a;
       a = cmake<double>(base.x - (fic.x * rcj.x - fic.y * rcj.y), base.y - (fic.x * rcj.y + fic.y * rcj.x));
     }
-  }
+  });
   // undo the row interchanges as column interchanges (c = M-1 .. 0): composed on the column index first (integer
   // selects), then ONE shuffle instead of M dependent ones
   int jj = j;
@@ -96,8 +182,10 @@ __device__ __forceinline__ double group_spectral_norm(Cd a, int i, int j, bool a
   // tail wave) counts as converged and is not divided by: before, such a wave ran all 24 squarings on NaNs.
   for (int it = 0; it < 24; ++it) {
     Cd h = cmake<double>(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < M; ++k) cfma(h, group_shfl<GW>(g, i * M + k), group_shfl<GW>(g, k * M + j));
+    static_for<M>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      cfma(h, group_row_bcast<M, GW, k>(g, i), group_shfl<GW>(g, k * M + j));
+    });
     const double t2 = group_sum<GW>((active && i == j) ? h.x : 0.0);
     const bool dead = t2 == 0.0;
     g = cscale(h, dead ? 0.0 : 1.0 / t2);
@@ -107,6 +195,64 @@ __device__ __forceinline__ double group_spectral_norm(Cd a, int i, int j, bool a
   const Cd gt = group_shfl<GW>(g, j * M + i);
   const double lam = group_sum<GW>(active ? (g0.x * gt.x - g0.y * gt.y) : 0.0);
   return sqrt(lam * tr);
+}
+
+// cond_2(A) < thr decided for the groups inside the ambiguous band, from A (a0) and its inverse (ainv), element (i, j)
+// per lane (round 4; replaces  ||A||_2 ||A^-1||_2 < thr  from two calls of group_spectral_norm, which is kept for
+// degenerate traces and as the arithmetic the many-channel path restates).  Both Gram matrices are squared in ONE loop
+// (two independent chains for a lone wave to interleave: the squarings are dependent-latency bound), and the loop ends
+// when the answer is known instead of when the norms have converged:
+//   G_0 = A^H A / tr,  G_{k+1} = G_k^2 s_k  (s_k ~ 1 / t_k, t_k = tr G_k^2; any s_k would do, see below),
+//   mu_k = lambda_max(G_k):  mu_{k+1} = mu_k^2 s_k  and, since tr G_k = 1 and G_k >= 0,   t_k <= mu_k <= sqrt(t_k).
+// With P_k = mu_k(A) mu_k(A^-1) and tau_k = t_k(A) t_k(A^-1):  cond_2^2 = tr tr' P_0 < thr^2  <=>  P_0 < theta_0 = thr^2 /
+// (tr tr'), and P_{k+1} < theta_{k+1} = theta_k^2 s_k s'_k  <=>  P_k < theta_k  (the SAME factors scale both sides: the
+// accuracy of the reciprocals does not enter).  theta_k / P_k is squared by every step, so it leaves the interval
+// [tau_k, sqrt(tau_k)] / P_k, which shrinks to a point, after 2-4 steps unless cond_2 sits within rounding of thr:
+//   tau_k < theta_k^2  =>  P_k <= sqrt(tau_k) < theta_k : below;      tau_k >= theta_k  =>  P_k >= theta_k : not below.
+// theta_k stays in [1 / M^2, 1] until then (it starts there: tr tr' is the squared Frobenius product, and the band is
+// thr^2 <= tr tr' < M^2 thr^2).  Undecided after 24 steps, or a trace that is not a positive normal number: the old form.
+template <int M, int GW>
+__device__ __forceinline__ bool group_cond_band(Cd a0, Cd ainv, int i, int j, bool active, bool amb, double thr) {
+  Cd g1 = cmake<double>(0.0, 0.0), g2 = g1;
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    cfma(g1, cconj(group_shfl<GW>(a0, k * M + i)), group_shfl<GW>(a0, k * M + j));
+    cfma(g2, cconj(group_shfl<GW>(ainv, k * M + i)), group_shfl<GW>(ainv, k * M + j));
+  }
+  const bool diag = active && i == j;
+  const double tr1 = group_sum<GW>(diag ? g1.x : 0.0), tr2 = group_sum<GW>(diag ? g2.x : 0.0);
+  const double thr2 = thr * thr, den = tr1 * tr2;
+  const bool plain = tr1 > 1e-290 && tr1 < 1e290 && tr2 > 1e-290 && tr2 < 1e290 && den > 1e-290 && den < 1e290 && thr2 < 1e290;
+  bool undecided = amb && plain, odd = amb && !plain, ok = false;
+  double theta = thr2 * fast_rcp(plain ? den : 1.0);
+  g1 = cscale(g1, fast_rcp(plain ? tr1 : 1.0));
+  g2 = cscale(g2, fast_rcp(plain ? tr2 : 1.0));
+  for (int it = 0; it < 24 && __any(undecided); ++it) {
+    Cd h1 = cmake<double>(0.0, 0.0), h2 = h1;
+    static_for<M>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      cfma(h1, group_row_bcast<M, GW, k>(g1, i), group_shfl<GW>(g1, k * M + j));
+      cfma(h2, group_row_bcast<M, GW, k>(g2, i), group_shfl<GW>(g2, k * M + j));
+    });
+    const double t1 = group_sum<GW>(diag ? h1.x : 0.0), t2 = group_sum<GW>(diag ? h2.x : 0.0);
+    const double tau = t1 * t2, th2 = theta * theta;
+    if (undecided && tau < th2) {
+      ok = true;
+      undecided = false;
+    } else if (undecided && tau >= theta) {
+      undecided = false;
+    }
+    const bool live = t1 > 0.0 && t2 > 0.0;  // not a wholly inactive group of a tail wave (nor a NaN)
+    const double s1 = live ? fast_rcp(t1) : 0.0, s2 = live ? fast_rcp(t2) : 0.0;
+    g1 = cscale(h1, s1);
+    g2 = cscale(h2, s2);
+    theta = th2 * s1 * s2;
+  }
+  if (__any(undecided || odd)) {  // rounding-close to the threshold, or extreme magnitudes: the converged norms
+    const double s = group_spectral_norm<M, GW>(a0, i, j, active) * group_spectral_norm<M, GW>(ainv, i, j, active);
+    if (undecided || odd) ok = s < thr;
+  }
+  return ok;
 }
 
 // cond_2(A) < thr from A (a0) and its inverse (ainv), element (i, j) per lane: Frobenius bounds, exact spectral
@@ -128,8 +274,8 @@ __device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bo
   if (__any(amb)) {
     const int lane = threadIdx.x & (GW - 1);
     const int i = active ? lane / M : 0, j = active ? lane % M : 0;
-    const double s = group_spectral_norm<M, GW>(a0, i, j, active) * group_spectral_norm<M, GW>(ainv, i, j, active);
-    if (amb) ok = s < thr;
+    const bool below = group_cond_band<M, GW>(a0, ainv, i, j, active, amb, thr);
+    if (amb) ok = below;
   }
   return ok;
 }
@@ -232,13 +378,15 @@ __global__ void __launch_bounds__(64)
       if (q == n) u = uall[q];
     // ---- A = W @ U_n
     Cd a = cmake<double>(0.0, 0.0);
-#pragma unroll
-    for (int k = 0; k < M; ++k) cfma(a, group_shfl<GW>(w, i * M + k), group_shfl<GW>(u, k * M + j));
+    static_for<M>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      cfma(a, group_row_bcast<M, GW, k>(w, i), group_shfl<GW>(u, k * M + j));
+    });
     const Cd a0 = a;
     bool singular = false;
     a = group_gj_inverse<M, GW>(a, i, j, singular);
     // ---- w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
-    const Cd wi = group_shfl<GW>(a, i * M + n);
+    const Cd wi = group_row_bcast_rt<M, GW>(a, i, n);
     const Cd wj = group_shfl<GW>(a, j * M + n);
     Cd term = cmul(cmul(cconj(wi), u), wj);
     if (!active) term = cmake<double>(0.0, 0.0);
@@ -307,8 +455,8 @@ __device__ __forceinline__ bool group_cond_below_if(bool want, Cd a0, Cd ainv, b
   if (__any(amb)) {
     const int lane = threadIdx.x & (GW - 1);
     const int i = active ? lane / M : 0, j = active ? lane % M : 0;
-    const double s = group_spectral_norm<M, GW>(a0, i, j, active) * group_spectral_norm<M, GW>(ainv, i, j, active);
-    if (amb) ok = s < thr;
+    const bool below = group_cond_band<M, GW>(a0, ainv, i, j, active, amb, thr);
+    if (amb) ok = below;
   }
   return ok;
 }

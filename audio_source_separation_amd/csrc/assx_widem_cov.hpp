@@ -446,6 +446,16 @@ __device__ __forceinline__ void fence_rows(V (&xr)[M]) {  // value fence on the 
 #ifndef PAIRCOV_TRACE
 #define PAIRCOV_TRACE 0
 #endif
+// PAIRCOV_SKIP (probe builds only; results are WRONG, the time is what is read -- tools/probes/paircov_knockout.sh,
+// profiles/r04_paircov_knockout.txt): 1 no fan-out, 2 no requests inside the loop, 4 no LDS reads of X rows / published
+// weights, 8 no barrier, 16 no weight chain at all (its LDS reads, its arithmetic, the publication); parts of it alone: 32 the
+// arithmetic, 64 the LDS reads of the weight inputs, 128 the publication, 256 the wait in front of the chain
+#if defined(PAIRCOV_SKIP) && PAIRCOV_SKIP && !defined(ASSX_PROBE_BUILD)
+#error "PAIRCOV_SKIP removes parts of pair_cov_kernel: build it with -DASSX_PROBE_BUILD into a probe library, never into libassx.so"
+#endif
+#ifndef PAIRCOV_SKIP
+#define PAIRCOV_SKIP 0
+#endif
 #if PAIRCOV_TRACE
 __device__ unsigned long long g_paircov_trace[1400];  // timing-experiment builds only
 #endif
@@ -678,6 +688,7 @@ __global__ void __launch_bounds__(WAVE * M)
       R& wlastn = wlasts[1 - H];
       const bool more = it + 1 < nblk;
       stamp();
+      if (!(PAIRCOV_SKIP & 8))
       asm volatile("s_barrier" ::: "memory");  // items it+1 (rows of X) and it+2 (weight inputs) have landed for every wave;
                                                 // the weights of item it+1 are published
       stamp();
@@ -704,18 +715,19 @@ __global__ void __launch_bounds__(WAVE * M)
       const unsigned xa1 = lds0 + (unsigned)sl1 * SLOT + (unsigned)lane * (unsigned)sizeof(Cx<R>);
       static_for<N>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
-        if constexpr (s == CHAIN_AT) {
-          lds_wait<x_reads_before(CHAIN_AT)>();  // LDS returns in order: the weight inputs (issued before any row of X) are here
+        if constexpr (s == CHAIN_AT && !(PAIRCOV_SKIP & 16)) {
+          if (!(PAIRCOV_SKIP & 256)) lds_wait<x_reads_before(CHAIN_AT)>();  // LDS returns in order: the weight inputs (issued before any row of X) are here
           fence_w(wn);
-          wgt_n = weight(tb2, wn);
+          if (!(PAIRCOV_SKIP & 32)) wgt_n = weight(tb2, wn);
         }
-        if constexpr (s == WRITE_AT) {
+        if constexpr (s == WRITE_AT && !(PAIRCOV_SKIP & (16 | 128))) {
           asm volatile("" : "+v"(wgt_n));
           lds_write_real(wbuf + (unsigned)(it & 1) * (unsigned)N * WROW + (unsigned)n * WROW +
                              (unsigned)lane * (unsigned)sizeof(R),
                          wgt_n);
         }
         const R ws = (N % 2 && s == N - 1) ? wlast : ((s & 1) ? wl[s >> 1].y : wl[s >> 1].x);
+        if (!(PAIRCOV_SKIP & 1))
 #pragma unroll
         for (int r = 0; r < M; ++r) acc[s * M + r] = fma(ws, p[r], acc[s * M + r]);
 #pragma unroll
@@ -724,18 +736,20 @@ __global__ void __launch_bounds__(WAVE * M)
           constexpr int e = decltype(ec)::value;
           if constexpr (event_slice(e) == s) {
             if constexpr (e == E_WALL) {
-              read_wall((it + 1) & 1, wln);
-              if (N % 2)
-                lds_read_real(wbuf + (unsigned)(((it + 1) & 1) * N + N - 1) * WROW + (unsigned)lane * (unsigned)sizeof(R), wlastn);
+              if (!(PAIRCOV_SKIP & 4)) {
+                read_wall((it + 1) & 1, wln);
+                if (N % 2)
+                  lds_read_real(wbuf + (unsigned)(((it + 1) & 1) * N + N - 1) * WROW + (unsigned)lane * (unsigned)sizeof(R), wlastn);
+              }
             } else if constexpr (e == E_WIN) {
-              read_w(sl2, wn);
+              if (!(PAIRCOV_SKIP & (16 | 64))) read_w(sl2, wn);
             } else if constexpr (e == E_REQ) {
-              request(it + DXS < nblk ? cr : first, sl);
+              if (!(PAIRCOV_SKIP & 2)) request(it + DXS < nblk ? cr : first, sl);
               // the cursors of the next trip, here where the scalar unit is idle
               advance(crn, TBk, F);
               tb1n = tb1 + 1 == TBk ? 0 : tb1 + 1;
               tb2n = tb2 + 1 == TBk ? 0 : tb2 + 1;
-            } else {
+            } else if (!(PAIRCOV_SKIP & 4)) {
               lds_read_cx<WP::nth_row(e - E_X) * (int)WBLK>(xa1, xn[WP::nth_row(e - E_X)]);
             }
           }
