@@ -727,7 +727,16 @@ class tILRMA(ILRMAbase):
         self._touch("W")
         self._estimation = None
 
+    def _require_plain_basis(self):
+        # The reference's t-ILRMA cannot update a partitioned model either (its update_source_model raises, ilrma.py:880-
+        # 883); here the refusal comes BEFORE the criterion at entry: tilrma_loss reads basis as (n_sources, n_bins,
+        # n_basis), and a partitioned basis (n_bins, n_basis) handed to it is read past its end (found as a memory fault
+        # that only some allocation layouts produce).  Observable difference: iteration=0 raises too.
+        if self.partitioning:
+            raise NotImplementedError("Only support when `partitioning=False` ")
+
     def _record_loss(self):
+        self._require_plain_basis()
         loss = self._engine.tilrma_loss(self._X, self._Wd, self._Td, self._Vd, self.nu, eps=self.eps)
         if isinstance(self.loss, LazyLossList):
             self.loss.append_device(loss, self._batched)
@@ -736,6 +745,7 @@ class tILRMA(ILRMAbase):
 
     def compute_negative_loglikelihood(self):
         """sum (1 + nu/2) log(1 + (2/nu) P/R) + log R - 2 T sum_f log|det W_f|   (ilrma.py:991-1018)."""
+        self._require_plain_basis()
         loss = self._engine.tilrma_loss(self._X, self._Wd, self._Td, self._Vd, self.nu, eps=self.eps)
         self._check_status()
         if self._batched:

@@ -76,6 +76,21 @@ class Engine:
         return int(B), int(M), int(F), int(T)
 
     # ------------------------------------------------------------------ (a3)
+    @staticmethod
+    def _model_shapes(X, W=None, Tb=None, V=None):
+        """The C-ABI takes pointers and sizes: a model array of another shape would be read past its end (a partitioned
+        basis (F, K) handed to an entry point that reads (N, F, K) was found as an intermittent memory fault).  Refuse it
+        here, where the shapes are still known."""
+        B, M, F, T = (int(d) for d in X.shape)
+        if W is not None and tuple(W.shape) != (B, F, M, M):
+            raise ValueError("demix_filter: expected shape %s, got %s" % ((B, F, M, M), tuple(W.shape)))
+        if Tb is not None:
+            K = int(Tb.shape[-1])
+            if tuple(Tb.shape) != (B, M, F, K):
+                raise ValueError("basis: expected shape %s, got %s" % ((B, M, F, K), tuple(Tb.shape)))
+            if V is not None and tuple(V.shape) != (B, M, K, T):
+                raise ValueError("activation: expected shape %s, got %s" % ((B, M, K, T), tuple(V.shape)))
+
     def demix(self, X, W, scale=None, out=None):
         B, M, F, T = self._dims(X)
         Y = out if out is not None else self.empty((B, M, F, T), complex_=True)
@@ -111,6 +126,7 @@ class Engine:
         """sources: None = all, or an iterable of source indices (pairwise update).
         loss_prev: optional (B,) float64 tensor receiving the loss of the model at entry (fused into the basis pass)."""
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         mask = (1 << M) - 1 if sources is None else sum(1 << int(n) for n in set(sources))
@@ -162,6 +178,7 @@ class Engine:
                              C=None, power_bins=None, spatial=_lib.SPATIAL_IP, pair=(0, 1)):
         """C (B,F,M,M) + power_bins (B,N,F) float64: also emit the per-bin power statistic of the updated filters."""
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         self._check(self._L.assx_ilrma_spatial_update(self.ctx, int(spatial), int(pair[0]), int(pair[1]), ptr(X), ptr(W), ptr(Tb), ptr(V), float(domain), float(eps),
@@ -172,6 +189,7 @@ class Engine:
     def ilrma_cov_partials(self, X, Tb, V, domain=2, eps=1e-12):
         """ONE launch of the covariance-accumulate kernel (stage 1 of ilrma_spatial_update); for kernel timing."""
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, None, Tb, V)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         self._check(self._L.assx_ilrma_cov_partials(self.ctx, ptr(X), ptr(Tb), ptr(V), float(domain), float(eps), ptr(ws),
@@ -214,6 +232,7 @@ class Engine:
 
     def ilrma_loss(self, X, W, Tb, V, domain=2, eps=1e-12, out=None):
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         loss = out if out is not None else self.empty((B,), dtype=torch.float64)
         ws = self._scratch(B, M, F, T, K)
@@ -247,6 +266,7 @@ class Engine:
         """n_iter x (source model, spatial model, normalisation); loss: (n_iter + 1, B) float64 or None.
         normalize: 0 none, 1 'power' (C + power_bins), 2 'projection-back' (scale scratch, ref, pb_exponent)."""
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         self._check(self._L.assx_ilrma_iterate(self.ctx, int(n_iter), int(spatial), int(pair[0]), int(pair[1]),
@@ -281,6 +301,7 @@ class Engine:
     # ------------------------------------------------------------------ t-ILRMA
     def tilrma_source_update(self, X, W, Tb, V, nu, eps=1e-12):
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         self._check(self._L.assx_tilrma_source_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
@@ -290,6 +311,7 @@ class Engine:
     def tilrma_spatial_update(self, X, W, Tb, V, nu, Xi, eps=1e-12, status=None, C=None, power_bins=None):
         """Xi: scratch (B,N,F,T) reals receiving the auxiliary weights."""
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         ws = self._scratch(B, M, F, T, K)
         self._check(self._L.assx_tilrma_spatial_update(self.ctx, ptr(X), ptr(W), ptr(Tb), ptr(V), float(nu), float(eps),
@@ -299,6 +321,7 @@ class Engine:
 
     def tilrma_loss(self, X, W, Tb, V, nu, eps=1e-12, out=None):
         B, M, F, T = self._dims(X)
+        self._model_shapes(X, W, Tb, V)
         K = int(Tb.shape[-1])
         loss = out if out is not None else self.empty((B,), dtype=torch.float64)
         ws = self._scratch(B, M, F, T, K)

@@ -305,3 +305,21 @@ def test_wav_io_round_trip(tmp_path):
     assert np.array_equal(y1, y[:, 0])
     with pytest.raises(ValueError):
         write_wav(path, np.zeros((2, 2, 2)), sr)
+
+
+def test_engine_refuses_model_arrays_of_another_shape():
+    """The C-ABI takes pointers and sizes; the host side is where a wrongly shaped model array can still be refused
+    (a partitioned basis read as (N, F, K) was an out-of-bounds read that only some allocation layouts turned into a fault)."""
+    from audio_source_separation_amd.ops import Engine
+    B, M, F, T, K = 1, 3, 5, 7, 2
+    X = np.zeros((B, M, F, T), np.complex128)
+    W = np.zeros((B, F, M, M), np.complex128)
+    Tb, V = np.zeros((B, M, F, K)), np.zeros((B, M, K, T))
+    Engine._model_shapes(X, W, Tb, V)
+    Engine._model_shapes(X, None, Tb, V)
+    with pytest.raises(ValueError, match="basis"):
+        Engine._model_shapes(X, W, np.zeros((B, F, K)), V)           # partitioned basis
+    with pytest.raises(ValueError, match="activation"):
+        Engine._model_shapes(X, W, Tb, np.zeros((B, K, T)))
+    with pytest.raises(ValueError, match="demix_filter"):
+        Engine._model_shapes(X, np.zeros((B, F, M, M - 1), np.complex128), Tb, V)

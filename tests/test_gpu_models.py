@@ -489,6 +489,8 @@ def test_tilrma_surface_and_f32():
         tILRMA(algorithm_spatial="ISS")
     with pytest.raises(NotImplementedError):
         tILRMA(partitioning=True)(X, iteration=1)
+    with pytest.raises(NotImplementedError):  # refused before the criterion at entry reads a (F, K) basis as (N, F, K)
+        tILRMA(partitioning=True)(X, iteration=0)
     with pytest.raises(AssertionError):
         tILRMA(domain=1)(X, iteration=1)
     with pytest.raises(ValueError):

@@ -32,6 +32,23 @@ rocprofv3 --kernel-trace --stats -d $OUT/prof_nmf -o p -- python $ROOT/tools/nmf
 rocprofv3 --kernel-trace --stats -d $OUT/prof_m8 -o p -- python $ROOT/tools/widem_bench.py 8:4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/prof_m5 -o p -- python $ROOT/tools/widem_bench.py 5:4 > /dev/null 2>&1
 for t in cfg4 f32 k10 nmf m8 m5; do py $ROOT/tools/rocprof_summary.py $OUT/prof_$t > $OUT/${t}_kernel_stats.md 2>&1; done
+# in-group data movement of the per-bin sweeps, DPP against ds_bpermute (needs csrc/ab/libassx_nodpp.so: build.sh with
+# ASSX_CHECK=0 ASSX_EXTRA_FLAGS=-DASSX_GROUP_DPP=0 ASSX_OBJ=ab ASSX_OUT=ab/libassx_nodpp.so)
+if [ -f $ROOT/audio_source_separation_amd/csrc/ab/libassx_nodpp.so ]; then
+  ( cd $ROOT && bash tools/probes/ip_dpp_ab.sh notests > /dev/null 2>&1 )
+  { echo "== per-bin sweeps: DPP / v_readlane data movement (a, the library) against -DASSX_GROUP_DPP=0 (b); tools/probes/ip_dpp_ab.sh"
+    echo "-- digests of (W, status) after two sweeps per shape: a against b"; cat $ROOT/gpurun_out/ipdpp/diff.txt
+    echo "-- spatial update, benchmark size (a)"; grep "#" $ROOT/gpurun_out/ipdpp/a.txt
+    echo "-- spatial update, benchmark size (b)"; grep "#" $ROOT/gpurun_out/ipdpp/b.txt
+    echo "-- sweep kernels under rocprofv3 (a)"; cat $ROOT/gpurun_out/ipdpp/a_kernels.md
+    echo "-- sweep kernels under rocprofv3 (b)"; cat $ROOT/gpurun_out/ipdpp/b_kernels.md
+    echo "-- headline bench, alternating libraries (it/s f64, ms per iteration, it/s f32)"
+    for rep in 1 2; do for v in a b; do
+      lib=$ROOT/audio_source_separation_amd/csrc/libassx.so; [ $v = b ] && lib=$ROOT/audio_source_separation_amd/csrc/ab/libassx_nodpp.so
+      ASSX_LIB_PATH=$lib python $B --cpu-iters 0 --roofline-b8 0 --with-default-basis 0 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['value'], d['ms_per_step'], d.get('value_f32'))"
+    done; done
+  } > $OUT/ip_dpp_ab.txt 2>&1
+fi
 # SQ counters
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_stream $TAG/sq_cov_k4 > $OUT/sq_cov_k4.txt 2>&1
 bash $ROOT/tools/pmc_kernel.sh "cov TV partial" cov_mfma $TAG/sq_cov_k10 --K 10 > $OUT/sq_cov_k10.txt 2>&1
