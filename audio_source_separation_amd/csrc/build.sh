@@ -16,7 +16,9 @@ OUT=${ASSX_OUT:-libassx.so}
 # ASSX_CHECK (default 1): every translation unit is compiled with -save-temps and tools/asm_wait_check.py walks its DEVICE
 # assembly -- no instruction may touch the destination of an inline-asm load that no s_waitcnt has covered yet (the
 # round-3 bug: registers of an asm LDS read copied before their wait, wrong only with two workgroups per CU at full
-# size).  A report fails the build.  ASSX_CHECK=0 skips it (kernel-tuning loops); an object built that way is rebuilt
+# size) -- and at every inline-asm LDS read the LDS-direct loads (buffer_load ... lds) in flight are counted against the
+# largest counted wait of the kernel + one trip's loads, three times round each loop: a ring that has lost a wait.  A
+# report fails the build.  ASSX_CHECK=0 skips it (kernel-tuning loops); an object built that way is rebuilt
 # and checked by the next checking build ($OBJ/<src>.checked is the stamp).
 CHECK=${ASSX_CHECK:-1}
 CHECKER="$(cd ../.. && pwd)/tools/asm_wait_check.py"

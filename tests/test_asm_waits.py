@@ -7,8 +7,8 @@ instructions ahead of the wait, harmless until two workgroups shared a CU and th
 a third of the bins, differently on every run).  No GPU needed: hipcc cross-compiles.  Compiled here: the streaming
 covariance kernels of csrc/assx_widem_cov.hpp in the instantiations of tests/asm_wait_probe.hip (under a minute) and the
 M <= 4 streaming kernels in the instantiations of the BASELINE configs (tests/asm_wait_probe_bss.hip, seconds); the whole of
-csrc/assx_widem.hip and csrc/assx_bss.hip take 4-5 minutes each and are checked by hand with the same tool (0 reports at
-the end of round 3)."""
+csrc/assx_widem.hip and csrc/assx_bss.hip take 4-5 minutes each and are checked by csrc/build.sh itself (ASSX_CHECK, round 4).
+Round 4 also: LDS-direct loads counted at inline-asm LDS reads (tests/asm_wait_ring.hip)."""
 import os
 import shutil
 import subprocess
@@ -62,3 +62,18 @@ def test_build_fails_on_a_kernel_that_touches_a_pending_asm_load(tmp_path):
     env["ASSX_SRCS"] = "assx_api"
     r = subprocess.run(["bash", build], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "asm_wait_check assx_api: total 0" in r.stdout, (r.returncode, r.stderr[-1500:])
+
+
+def test_checker_counts_lds_direct_loads_in_flight_at_asm_lds_reads(tmp_path):
+    """LDS-direct loads (buffer_load ... lds) land in LDS, not in a register the walk could follow, at run-time addresses.
+    What can be counted: at an inline-asm LDS read a ring has at most (largest counted wait + one trip's loads) of them in
+    flight.  tests/asm_wait_ring.hip holds a small ring twice: with its per-trip wait (clean) and without it (reported,
+    on the third time round the loop: the walk carries what a trip leaves pending)."""
+    asm = tmp_path / "ring.s"
+    subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-w", "--cuda-device-only", "-S",
+                    os.path.join(ROOT, "tests", "asm_wait_ring.hip"), "-o", str(asm)], check=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_wait_check.py"), str(asm)], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 1 and "ring_bad_kernel" in r.stdout and "LDS-direct loads in flight" in r.stdout, r.stdout
+    assert "ring_good_kernel" not in r.stdout and r.stdout.strip().endswith("total 1"), r.stdout
+    assert open(asm).read().count(" lds") >= 10  # both kernels really use LDS-direct loads

@@ -12,6 +12,15 @@ the counting is right).  The walk is linear; by default the pending lists are dr
 on paths that never follow each other).  Stores and scalar loads are ignored (stores make the vmcnt
 reading conservative; the kernels have no scalar loads inside their pipelined loops).
 
+LDS-DIRECT loads (buffer_load ... lds: the destination is LDS memory, not a register) are followed by COUNT (round 4): their
+landing addresses are run-time values (M0 from a rotating ring slot), which a static walk cannot compare with the address
+of a later ds_read, but every ring of these kernels keeps one invariant that can be counted: when an inline-asm LDS read
+executes, the wave has at most  Nmax + B  LDS-direct loads in flight, Nmax = the largest vmcnt immediate the kernel waits
+with, B = the LDS-direct loads one trip of the enclosing loop issues (0 outside loops).  A missing counted wait -- in the
+prologue, or at the end of a trip: the walk goes round every loop three times, so what a trip leaves behind adds up -- breaks
+it and is reported ("N LDS-direct loads in flight at an asm LDS read").  What this does NOT see: a wait whose immediate is
+too large by less than a trip's loads, or a read of the wrong slot; the full-size co-residency tests are the guard there.
+
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S csrc/assx_widem.hip -o /tmp/widem.s
     python tools/asm_wait_check.py /tmp/widem.s [kernel-name substring]"""
 import re
@@ -28,12 +37,48 @@ def regs(tok):
     return out
 
 
+LOOP_WALKS = 3  # times the walk goes round a loop (what a trip leaves in flight has to show up as an excess)
+
+
 def check(lines, name, linear=False):
     pend = {"lgkm": [], "vm": []}
     bad = []
+    seen = set()
     in_asm = False
     last_op = ""
-    for ln, raw in lines:
+    # ---- pre-pass: labels, the largest vmcnt immediate, the loops (backward branches) and their LDS-direct loads per trip
+    code = [raw.split(";")[0].strip() for _, raw in lines]
+    label_at = {c[:-1]: k for k, c in enumerate(code) if c.endswith(":")}
+    nmax = 0
+    for c in code:
+        if c.startswith("s_waitcnt"):
+            m = re.search(r"vmcnt\((\d+)\)", c)
+            if m:
+                nmax = max(nmax, int(m.group(1)))
+    is_ldsdirect = [(c.startswith("buffer_load") or c.startswith("global_load")) and " lds" in c for c in code]
+    loops = []  # (head index, branch index, LDS-direct loads in between)
+    for k, c in enumerate(code):
+        if c.startswith("s_cbranch") or c.startswith("s_branch"):
+            tgt = c.split()[-1]
+            t = label_at.get(tgt)
+            if t is not None and t < k:
+                loops.append((t, k, sum(is_ldsdirect[t:k])))
+    # the walk goes back at the BOTTOM-most branch to a head only: an earlier one (a conditional skip to the latch of a rotated
+    # loop) falls through, so that the blocks between it and the bottom are walked as well
+    back_edge = {}
+    for t, k, _ in loops:
+        if all(not (t2 == t and k2 > k) for t2, k2, _ in loops):
+            back_edge[k] = t
+    walks = {}
+    incoming = {}  # label -> what an unconditional FORWARD branch to it had pending (the walk itself goes on below the branch)
+
+    def per_trip(k):  # B of the loops around instruction k (the widest one: an outer trip contains the inner ones)
+        return max([b for t, j, b in loops if t <= k <= j] or [0])
+
+    k = 0
+    while k < len(lines):
+        ln, raw = lines[k]
+        k += 1
         if "#ASMSTART" in raw:
             in_asm = True
         elif "#ASMEND" in raw:
@@ -41,6 +86,11 @@ def check(lines, name, linear=False):
         l = raw.split(";")[0].strip()
         if l.endswith(":") and not linear and last_op in ("s_branch", "s_endpgm", "s_setpc_b64"):
             pend = {"lgkm": [], "vm": []}  # not reachable by falling through: what is pending here came from elsewhere
+        if l.endswith(":") and l[:-1] in incoming:  # ... e.g. from a forward branch over this point: the longer lists count
+            inc = incoming.pop(l[:-1])              # (once: the next time round the loop the branch saves its state again)
+            for key in ("lgkm", "vm"):
+                if len(inc[key]) > len(pend[key]):
+                    pend[key] = inc[key]
         if not l or l.endswith(":") or l.startswith("."):
             continue
         op = l.split()[0]
@@ -53,21 +103,39 @@ def check(lines, name, linear=False):
                     n = int(m.group(1))
                     pend[key] = pend[key][len(pend[key]) - n:] if n > 0 else []
             continue
+        if op.startswith("s_cbranch") or op == "s_branch":
+            t = back_edge.get(k - 1)
+            if t is not None and walks.get(k - 1, 0) < LOOP_WALKS - 1:
+                walks[k - 1] = walks.get(k - 1, 0) + 1
+                k = t  # once more round the loop, with the LDS-direct loads this trip left in flight.  Register loads are not
+                last_op = ""  # carried: the linear walk conflates the paths of a loop body, and what it believes pending at the
+                pend = {"lgkm": [], "vm": [e for e in pend["vm"] if e[3]]}  # bottom would meet the top's register writes
+            elif op == "s_branch" and label_at.get(l.split()[-1], -1) >= k:
+                incoming[l.split()[-1]] = {key: list(v) for key, v in pend.items()}
+            continue
         if op == "s_barrier" or op.startswith("s_"):
             continue
         touched = set()
         for p_ in parts:
             touched |= regs(p_)
         for key in ("lgkm", "vm"):
-            for dst, src, from_asm in pend[key]:
-                if from_asm and dst & touched:
+            for dst, src, from_asm, _ in pend[key]:
+                if from_asm and dst & touched and (ln, src) not in seen:
+                    seen.add((ln, src))
                     bad.append((ln, l, src))
+        if in_asm and op.startswith("ds_read"):
+            inflight = sum(1 for e in pend["vm"] if e[3])
+            if inflight > nmax + per_trip(k - 1) and (ln, "lds-direct") not in seen:
+                seen.add((ln, "lds-direct"))
+                bad.append((ln, l, "%d LDS-direct loads in flight at an asm LDS read (largest counted wait %d + %d per trip)"
+                            % (inflight, nmax, per_trip(k - 1))))
         if op.startswith("ds_read") or op.startswith("ds_bpermute") or op.startswith("ds_swizzle") or op.startswith("ds_permute"):
-            pend["lgkm"].append((regs(parts[0]), l, in_asm))
+            pend["lgkm"].append((regs(parts[0]), l, in_asm, False))
         elif op.startswith("ds_"):
-            pend["lgkm"].append((set(), l, in_asm))
+            pend["lgkm"].append((set(), l, in_asm, False))
         elif op.startswith("buffer_load") or op.startswith("global_load") or op.startswith("flat_load"):
-            pend["vm"].append((set() if " lds" in l else regs(parts[0]), l, in_asm))
+            direct = " lds" in l
+            pend["vm"].append((set() if direct else regs(parts[0]), l, in_asm, direct))
     return bad
 
 
@@ -88,7 +156,7 @@ def main():
             if want in name:
                 bad = check([(k - i, txt[k]) for k in range(i, j)], name, linear)
                 if bad:
-                    print("%s: %d touches of a pending load's registers" % (name[:100], len(bad)))
+                    print("%s: %d reports (a pending load's registers touched / LDS-direct loads in flight at an asm LDS read)" % (name[:100], len(bad)))
                     for ln, l, src in bad[:6]:
                         print("    +%d  %s    <- pending: %s" % (ln, l, src))
                 total += len(bad)
