@@ -1,11 +1,13 @@
 #!/bin/bash
-# A/B of the spread weight chain of widem::pair_cov_kernel (run on the GPU box): the library in the tree against
-# ab/libassx_nospread.so (assx_widem.hip built with -DASSX_PAIR_CHAIN_SPREAD=0): digests, kernel times, wide-channel tests.
+# A/B of two builds of widem::pair_cov_kernel (run on the GPU box): the library in the tree (a) against $OLD_LIB (b, default
+# csrc/ab/libassx_nospread.so: assx_widem.hip of the reference build linked with the tree's other objects, see
+# paircov_knockout.sh for the recipe) -- digests, kernel times under rocprofv3, wide-channel tests.  Used for the two
+# re-orderings of the weight chain that profiles/r04_paircov_spread_ab.txt records (both removed again).
 cd /tmp && export TMPDIR=/tmp
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/pcspread; mkdir -p $OUT
 cd $ROOT
-OLD=$ROOT/audio_source_separation_amd/csrc/ab/libassx_nospread.so
+OLD=${OLD_LIB:-$ROOT/audio_source_separation_amd/csrc/ab/libassx_nospread.so}
 python tools/probes/ip_dpp_ab.py > $OUT/a.txt 2>&1
 ASSX_LIB_PATH=$OLD python tools/probes/ip_dpp_ab.py > $OUT/b.txt 2>&1
 diff <(sed 's/ *#.*//' $OUT/a.txt) <(sed 's/ *#.*//' $OUT/b.txt) > $OUT/diff.txt && echo "all digests equal" >> $OUT/diff.txt
