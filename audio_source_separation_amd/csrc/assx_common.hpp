@@ -314,6 +314,29 @@ __device__ __forceinline__ void cfma(Cx<R>& acc, Cx<R> a, Cx<R> b) {
   acc.y = fma(a.x, b.y, acc.y);
   acc.y = fma(a.y, b.x, acc.y);
 }
+// y += w x with w WAVE-UNIFORM (a demixing coefficient out of scalar loads).  float32: two packed fused multiply-adds
+//   (y.re, y.im) += w.re * (x.re, x.im);   (y.re, y.im) += w.im * (-x.im, x.re)
+// instead of four scalar ones -- the operand selects (op_sel / op_sel_hi / neg_lo) pick the halves, so nothing else is
+// issued; per component the same two IEEE operations in the same order as cfma: no result changes.  ASSX_PK_DEMIX=0: cfma.
+#ifndef ASSX_PK_DEMIX
+#define ASSX_PK_DEMIX 1
+#endif
+__device__ __forceinline__ void demix_mac(Cx<double>& y, Cx<double> w, Cx<double> x) { cfma(y, w, x); }
+__device__ __forceinline__ void demix_mac(Cx<float>& y, Cx<float> w, Cx<float> x) {
+#if ASSX_PK_DEMIX && defined(__HIP_DEVICE_COMPILE__)
+  Vec2<float> yy = {y.x, y.y};
+  const Vec2<float> ww = {w.x, w.y}, xx = {x.x, x.y};
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "+v"(yy)
+      : "s"(ww), "v"(xx));
+  y.x = yy.x;
+  y.y = yy.y;
+#else
+  cfma(y, w, x);
+#endif
+}
+
 template <typename R>
 __device__ __forceinline__ R cabs2(Cx<R> a) { return fma(a.x, a.x, a.y * a.y); }
 template <typename R>

@@ -811,7 +811,7 @@ __global__ void __launch_bounds__(64, MINW)
           for (int n = 0; n < N; ++n) {
             Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
-            for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+            for (int m = 0; m < M; ++m) demix_mac(y, w[n][m], x[m]);
             R P = cabs2(y);
             R tv = 0;
             if (K4) {
@@ -986,7 +986,7 @@ __global__ void __launch_bounds__(64, MINW)
     for (int n = 0; n < N; ++n) {
       Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
-      for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+      for (int m = 0; m < M; ++m) demix_mac(y, w[n][m], x[m]);
       R P = cabs2(y);
       R v[KU];
 #pragma unroll
@@ -1221,7 +1221,7 @@ __global__ void __launch_bounds__(64, MINW)
           for (int n = 0; n < N; ++n) {
             Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
-            for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+            for (int m = 0; m < M; ++m) demix_mac(y, w[n][m], x[m]);
             R tv = 0;
             if (K4) {
 #pragma unroll
@@ -1370,7 +1370,7 @@ __global__ void __launch_bounds__(64, MINW)
       for (int n = 0; n < N; ++n) {
         Cx<R> y = cmake<R>(0, 0);
 #pragma unroll
-        for (int m = 0; m < M; ++m) cfma(y, w[n][m], x[m]);
+        for (int m = 0; m < M; ++m) demix_mac(y, w[n][m], x[m]);
         R tv = 0;
 #pragma unroll
         for (int kk = 0; kk < KU; kk += 2) {

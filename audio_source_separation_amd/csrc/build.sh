@@ -41,6 +41,13 @@ for srcpath in $SRCS; do
     # 16 x 16 sub-tile (config 2: 65 -> 61 us per update).  Not for assx_bss.hip: two cov_mfma_kernel variants spill with it.
     SRCFLAGS=""
     [ "$src" = assx_nmf ] && SRCFLAGS="-mllvm -amdgpu-mfma-vgpr-form"
+    # the streaming kernels: no SLP vectorisation.  In the float32 instantiations the vectoriser pairs independent
+    # multiply-adds of two sources into v_pk_fma_f32 and pays four v_mov_b32 per pair to line the operands up (5
+    # instructions for 2): basis_stream_vd_kernel<float> 34.7 -> 29.7 us, the float32 bench line +8.5 % (profiles/
+    # r04_f32_slp_ab.txt).  float64 code and results are untouched (same digests, same times); float32 results move in the
+    # last bit on two covariance shapes (packed multiply + add where the scalar form contracts to a fused multiply-add).  Not
+    # for assx_nmf (config 1 in float32 is 4 % faster WITH it) and not needed for assx_widem (neutral).
+    [ "$src" = assx_bss ] && SRCFLAGS="-fno-slp-vectorize"
     rm -f "$OBJ/$src.checked"
     if [ "$CHECK" = 1 ]; then
       rm -rf "$OBJ/temps_$src"; mkdir -p "$OBJ/temps_$src"
