@@ -916,13 +916,29 @@ __global__ void __launch_bounds__(64, MINW)
   Cx<R> w[N][M];  // demixing rows of the bin: wave-uniform, SGPRs (scalar loads)
   R tbr[N][KU];   // basis rows of the bin: wave-uniform too, but held in VGPRs (broadcast vector loads) -- together
                   // with w they would overflow the scalar file and come back as two v_readlane per use
+  // ASSX_W_VGPR_ROWS (experiment): the last so many rows of w held in VGPRs as well (float64: 16 SGPRs per row)
+#ifndef ASSX_W_VGPR_ROWS
+#define ASSX_W_VGPR_ROWS 0
+#endif
+  constexpr int WVN = sizeof(R) == 8 ? (ASSX_W_VGPR_ROWS < N ? ASSX_W_VGPR_ROWS : N) : 0;
   const unsigned zero_v = order_after(0u, lane);  // a zero the compiler cannot prove uniform
   auto load_rows = [&](const Cursor& cu) {  // once per bin
     const Cx<R>* wp = W + ((size_t)cu.b * F + cu.f) * (N * M);
 #pragma unroll
-    for (int n = 0; n < N; ++n)
+    for (int n = 0; n < N - WVN; ++n)
 #pragma unroll
       for (int m = 0; m < M; ++m) w[n][m] = wp[n * M + m];
+    if (WVN > 0) {
+      const BufRsrc rw = make_rsrc(reinterpret_cast<const R*>(W + (size_t)cu.b * F * (N * M)));
+      const unsigned so = (unsigned)(cu.f * (N * M)) * (unsigned)sizeof(Cx<R>);
+#pragma unroll
+      for (int n = N - WVN; n < N; ++n)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          w[n][m].x = buf_ld<R>(rw, zero_v + (unsigned)((n * M + m) * 2 * (int)sizeof(R)), so);
+          w[n][m].y = buf_ld<R>(rw, zero_v + (unsigned)(((n * M + m) * 2 + 1) * (int)sizeof(R)), so);
+        }
+    }
     const BufRsrc rt = make_rsrc(Tb + (size_t)cu.b * N * F * K);
 #pragma unroll
     for (int n = 0; n < N; ++n) {
