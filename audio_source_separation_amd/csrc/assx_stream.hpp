@@ -916,11 +916,15 @@ __global__ void __launch_bounds__(64, MINW)
   Cx<R> w[N][M];  // demixing rows of the bin: wave-uniform, SGPRs (scalar loads)
   R tbr[N][KU];   // basis rows of the bin: wave-uniform too, but held in VGPRs (broadcast vector loads) -- together
                   // with w they would overflow the scalar file and come back as two v_readlane per use
-  // ASSX_W_VGPR_ROWS (experiment): the last so many rows of w held in VGPRs as well (float64: 16 SGPRs per row)
+  // ASSX_W_VGPR_ROWS: the last so many rows of w are held in VGPRs as well (float64 only: a row is 16 SGPRs).  The kernel
+  // sits at the 106-SGPR ceiling and the spills come back as v_readlane_b32 -- ~45 per trip of the steady loop with all of
+  // w in SGPRs, a third of that with two rows in VGPRs: 295 / 210 / 88 / 40 v_readlane for 0 / 1 / 2 / 3 rows at 202 / 225 /
+  // 249 / 256 VGPRs, kernel 50.6 / 50.7 / 49.1 / 49.3 us (profiles/r04_sched_flags.txt).  Same values, same arithmetic.
 #ifndef ASSX_W_VGPR_ROWS
-#define ASSX_W_VGPR_ROWS 0
+#define ASSX_W_VGPR_ROWS 2
 #endif
-  constexpr int WVN = sizeof(R) == 8 ? (ASSX_W_VGPR_ROWS < N ? ASSX_W_VGPR_ROWS : N) : 0;
+  // (the plain domain-2 variant only: with the loss or the t-ILRMA statistic on board the extra 32 VGPRs do not fit)
+  constexpr int WVN = (sizeof(R) == 8 && D2 && !TD && !LOSS && MINW == 2) ? (ASSX_W_VGPR_ROWS < N ? ASSX_W_VGPR_ROWS : N) : 0;
   const unsigned zero_v = order_after(0u, lane);  // a zero the compiler cannot prove uniform
   auto load_rows = [&](const Cursor& cu) {  // once per bin
     const Cx<R>* wp = W + ((size_t)cu.b * F + cu.f) * (N * M);
