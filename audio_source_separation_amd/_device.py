@@ -4,6 +4,7 @@ All arithmetic of the hot path happens in libassx.so (hand-written HIP); nothing
 """
 import ctypes
 import threading
+import weakref
 
 import numpy as np
 
@@ -57,7 +58,10 @@ class _ThreadContexts:
 
 
 _TLS = threading.local()
-_ALL_HELD = []  # every thread's _ThreadContexts, for the interpreter-exit hook below
+# every LIVE thread's _ThreadContexts, for the interpreter-exit hook below.  Weak references: the thread-local slot is the
+# only owner, so a thread that ends takes its contexts (pinned staging ring, host thread pool, device ticket buffers)
+# with it -- a server that spawns worker threads does not accumulate one context per finished thread.
+_ALL_HELD = weakref.WeakSet()
 
 
 def _destroy_all_contexts():
@@ -80,7 +84,7 @@ def context(dev):
     held = getattr(_TLS, "held", None)
     if held is None:
         held = _TLS.held = _ThreadContexts()
-        _ALL_HELD.append(held)
+        _ALL_HELD.add(held)
     h = held.by_device.get(dev.index)
     if h is None:
         h = ctypes.c_void_p()

@@ -37,6 +37,7 @@ SIGNATURES = {
     "assx_version": (ctypes.c_char_p, []),
     "assx_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "assx_launch_order": (_i, [_i, _i, _i, _i, _vp, _i]),
+    "assx_nmf_partition_query": (_i, [_i, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_demix": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_cov_accumulate": (_i, [_vp, _vp, _vp, _i, _d, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "assx_ip_update": (_i, [_vp, _vp, _vp, _d, _vp, _i, _i, _i, _i, _vp]),

@@ -16,12 +16,29 @@ from ._device import to_device, to_numpy, torch
 
 
 class _Entry:
-    __slots__ = ("host", "dev", "owner")
+    __slots__ = ("host", "dev", "owner", "sig")
 
     def __init__(self, host=None, dev=None, owner=None):
         self.host = host
         self.dev = dev
         self.owner = owner  # the model: an edit of state invalidates a loss value parked for the next pass
+        self.sig = None  # _signature(host) when host and dev were last known to agree
+
+
+def _signature(a):
+    """Cheap content signature of a host array (two reductions over its 64-bit words, ~0.1 ms per MB).  TrackedArray sees
+    writes made THROUGH it; a write through a plain view of the same memory (np.asarray(a), a.view(np.ndarray),
+    torch.from_numpy(a)) or into an array the caller assigned and kept does not pass any hook -- the signature taken when
+    host and device agreed is compared before the device copy is reused (DeviceState._dev), so such an edit still reaches
+    the next kernel, as it would in the reference (plain NumPy attributes, src/bss/ilrma.py:97-104)."""
+    try:
+        b = np.ascontiguousarray(a).reshape(-1).view(np.uint8)
+        n8 = b.size // 8
+        w = b[:n8 * 8].view(np.uint64)
+        tail = int(b[n8 * 8:].astype(np.uint64).sum())
+        return (a.shape, str(a.dtype), int(w.sum(dtype=np.uint64)), int(np.bitwise_xor.reduce(w)) if n8 else 0, tail)
+    except (TypeError, ValueError, AttributeError):
+        return None
 
 
 class TrackedArray(np.ndarray):
@@ -49,7 +66,45 @@ class TrackedArray(np.ndarray):
         self._edited()  # before the write: a deferred loss must still see the old values on the device (it does: dev is intact until dropped)
         super().__setitem__(key, value)
 
+    # the other in-place methods of ndarray
+    def fill(self, value):
+        self._edited()
+        return super().fill(value)
+
+    def sort(self, *args, **kwargs):
+        self._edited()
+        return super().sort(*args, **kwargs)
+
+    def partition(self, *args, **kwargs):
+        self._edited()
+        return super().partition(*args, **kwargs)
+
+    def put(self, *args, **kwargs):
+        self._edited()
+        return super().put(*args, **kwargs)
+
+    def setfield(self, *args, **kwargs):
+        self._edited()
+        return super().setfield(*args, **kwargs)
+
+    def byteswap(self, inplace=False):
+        if inplace:
+            self._edited()
+        return super().byteswap(inplace)
+
+    # functions of the NumPy API that write into their first argument (np.copyto(a, ..), np.put(a, ..), ...)
+    _WRITES_FIRST_ARG = ("copyto", "put", "place", "putmask", "put_along_axis", "fill_diagonal")
+
+    def __array_function__(self, func, types, args, kwargs):
+        if getattr(func, "__name__", "") in self._WRITES_FIRST_ARG:
+            dst = args[0] if args else kwargs.get("dst", kwargs.get("a", kwargs.get("arr")))
+            if isinstance(dst, TrackedArray):
+                dst._edited()
+        return super().__array_function__(func, types, args, kwargs)
+
     def __array_ufunc__(self, ufunc, method, *inputs, out=None, **kwargs):
+        if method == "at" and inputs and isinstance(inputs[0], TrackedArray):
+            inputs[0]._edited()  # np.add.at(a, idx, v) writes into its first input and has no out=
         plain = tuple(np.asarray(x) if isinstance(x, TrackedArray) else x for x in inputs)
         if out is not None:
             for o in out:
@@ -91,6 +146,7 @@ class DeviceArray:
             a._entry, a._root = ent, a
             ent.owner = obj
             ent.host = a
+            ent.sig = _signature(a)
         return ent.host
 
     def __set__(self, obj, value):
@@ -118,12 +174,19 @@ class DeviceState:
     def _dev(self, name, complex_):
         """Device tensor for `name` (uploads the host value on first use, adding the batch axis)."""
         ent = self.__dict__["_arrays"][name]
+        if ent.dev is not None and ent.host is not None and ent.sig is not None and _signature(ent.host) != ent.sig:
+            # the host array changed behind the hooks (a write through a plain view of its memory): it is the newer copy
+            resolve = getattr(self, "_resolve_deferred_loss", None)
+            if resolve is not None:
+                resolve()
+            ent.dev = None
         if ent.dev is None:
             prec = self._engine.prec
             a = np.asarray(ent.host)
             if not self._batched:
                 a = a[None]
             ent.dev = to_device(a, prec.cplx if complex_ else prec.real, self._engine.dev).clone()
+            ent.sig = _signature(ent.host)
         return ent.dev
 
     def _set_dev(self, name, tensor):

@@ -3,33 +3,84 @@
 
 namespace assx {
 
-int* ensure_tickets(assx_ctx* ctx, size_t n, hipStream_t st) {
-  if (ctx->tickets && ctx->n_tickets >= n) return ctx->tickets;
-  if (ctx->n_old_tickets >= (int)(sizeof(ctx->old_tickets) / sizeof(ctx->old_tickets[0]))) {
-    fail(ctx, ASSX_E_UNSUPPORTED, "ticket buffer regrown too often");
-    return nullptr;
-  }
-  size_t want = ctx->n_tickets ? ctx->n_tickets * 2 : 8192;  // geometric growth: at most a handful of buffers per context
-  while (want < n) want *= 2;
+static int tickets_alloc(assx_ctx* ctx, size_t want, hipStream_t st, int** out) {
   int* p = nullptr;
   hipError_t e = hipMalloc((void**)&p, want * sizeof(int));
   if (e == hipSuccess) e = hipMemsetAsync(p, 0, want * sizeof(int), st);
   if (e != hipSuccess) {
     if (p) (void)hipFree(p);
-    hip_fail(ctx, e, "ensure_tickets");
-    return nullptr;
+    *out = nullptr;
+    return hip_fail(ctx, e, "ensure_tickets");
   }
-  if (ctx->tickets) ctx->old_tickets[ctx->n_old_tickets++] = ctx->tickets;  // launches in flight may still use it
-  ctx->tickets = p;
-  ctx->n_tickets = want;
-  return p;
+  *out = p;
+  return 0;
+}
+
+// every launch that could still count on a retired buffer has finished once the device is idle
+static int tickets_drain_old(assx_ctx* ctx) {
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) return hip_fail(ctx, e, "ensure_tickets (synchronise before recycling ticket buffers)");
+  for (int i = 0; i < ctx->n_old_tickets; ++i) (void)hipFree(ctx->old_tickets[i]);
+  ctx->n_old_tickets = 0;
+  return 0;
+}
+
+int ensure_tickets(assx_ctx* ctx, size_t n, hipStream_t st, int** out) {
+  *out = nullptr;
+  constexpr int NSLOT = (int)(sizeof(ctx->tk) / sizeof(ctx->tk[0]));
+  constexpr int NOLD = (int)(sizeof(ctx->old_tickets) / sizeof(ctx->old_tickets[0]));
+  ++ctx->tk_clock;
+  assx_ctx::TicketSlot* s = nullptr;
+  for (int i = 0; i < ctx->n_tk; ++i)
+    if (ctx->tk[i].st == st) s = &ctx->tk[i];
+  if (s && s->n >= n) {
+    s->used = ctx->tk_clock;
+    *out = s->p;
+    return 0;
+  }
+  if (!s) {
+    if (ctx->n_tk < NSLOT) {
+      s = &ctx->tk[ctx->n_tk++];
+      s->p = nullptr;
+      s->n = 0;
+    } else {
+      // more streams than slots: the least recently used slot changes hands.  Its words are zero and unused once the
+      // device is idle (a rare, slow path: a context serves one host thread and normally one or two streams).
+      int rc = tickets_drain_old(ctx);
+      if (rc) return rc;
+      s = &ctx->tk[0];
+      for (int i = 1; i < NSLOT; ++i)
+        if (ctx->tk[i].used < s->used) s = &ctx->tk[i];
+    }
+    s->st = st;
+    s->used = ctx->tk_clock;
+    if (s->n >= n) {
+      *out = s->p;
+      return 0;
+    }
+  }
+  size_t want = s->n ? s->n * 2 : 8192;  // geometric growth: a handful of buffers per stream at most
+  while (want < n) want *= 2;
+  if (s->p && ctx->n_old_tickets >= NOLD) {
+    int rc = tickets_drain_old(ctx);
+    if (rc) return rc;
+  }
+  int* p = nullptr;
+  int rc = tickets_alloc(ctx, want, st, &p);
+  if (rc) return rc;
+  if (s->p) ctx->old_tickets[ctx->n_old_tickets++] = s->p;  // launches in flight on `st` may still use it
+  s->p = p;
+  s->n = want;
+  s->used = ctx->tk_clock;
+  *out = p;
+  return 0;
 }
 
 void tickets_destroy(assx_ctx* ctx) {
-  if (ctx->tickets) (void)hipFree(ctx->tickets);
+  for (int i = 0; i < ctx->n_tk; ++i)
+    if (ctx->tk[i].p) (void)hipFree(ctx->tk[i].p);
   for (int i = 0; i < ctx->n_old_tickets; ++i) (void)hipFree(ctx->old_tickets[i]);
-  ctx->tickets = nullptr;
-  ctx->n_tickets = 0;
+  ctx->n_tk = 0;
   ctx->n_old_tickets = 0;
 }
 

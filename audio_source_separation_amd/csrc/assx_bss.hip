@@ -2145,8 +2145,8 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
     const int fold = env_int("ASSX_AUX_FOLD", 0);
     int* tickets = nullptr;
     if (fold && FS > 1) {
-      tickets = ensure_tickets(ctx, (size_t)B * TBk + B, st);
-      if (!tickets) return ASSX_E_UNSUPPORTED;
+      const int trc = ensure_tickets(ctx, (size_t)B * TBk + B, st, &tickets);
+      if (trc) return trc;  // the hipError_t of the allocation, message in ctx
     }
     const bool folded = tickets != nullptr;
     hipLaunchKernelGGL((auxiva_stat_partial_kernel<R, MM>), dim3(TBk, FS, B), dim3(256), 0, st, (const Cx<R>*)X,

@@ -23,20 +23,31 @@ struct assx_ctx {
   // pinned staging ring + host thread pool of assx_upload / assx_download (csrc/assx_xfer.hip), created on first use
   void* xfer;
   // zeroed device words for the "last workgroup done" tickets of kernels that fold their finalize step (assx_common.hpp:
-  // take_ticket); grown on demand by ensure_tickets(), outgrown buffers are kept until the context is destroyed
-  // (launches that still use them may be in flight)
-  int* tickets;
-  size_t n_tickets;
-  void* old_tickets[16];
+  // take_ticket).  ONE BUFFER PER STREAM: launches on different streams of one context may overlap on the device, and
+  // two kernels counting on the same words would see each other's arrivals (a partial sum applied, counters left
+  // non-zero for every later call).  ensure_tickets() finds / creates / grows the buffer of the stream it is called
+  // for; outgrown buffers are kept (launches that still use them may be in flight) and freed behind a device
+  // synchronisation when their list is full or the context is destroyed.
+  struct TicketSlot {
+    hipStream_t st;
+    int* p;
+    size_t n;
+    unsigned long long used;  // value of tk_clock at the last use (least recently used slot is recycled)
+  } tk[16];
+  int n_tk;
+  unsigned long long tk_clock;
+  void* old_tickets[32];
   int n_old_tickets;
 };
 
 namespace assx {
 
 void xfer_destroy(assx_ctx* ctx);  // csrc/assx_xfer.hip
-// at least n zeroed ticket words, zeroing ordered on `st` before the caller's launch (csrc/assx_api.hip); nullptr + error
-// message on failure.  Kernels leave the words zero, so the buffer is only ever cleared when it is (re)allocated.
-int* ensure_tickets(assx_ctx* ctx, size_t n, hipStream_t st);
+// at least n zeroed ticket words private to stream `st`, zeroing ordered on `st` before the caller's launch (csrc/
+// assx_api.hip).  Returns 0 and the buffer in *out, or the hipError_t of the failed allocation (message recorded in ctx).
+// Kernels leave the words zero, so a buffer is only ever cleared when it is (re)allocated.  A context used from more
+// streams than it has slots recycles the least recently used slot behind a hipDeviceSynchronize().
+int ensure_tickets(assx_ctx* ctx, size_t n, hipStream_t st, int** out);
 void tickets_destroy(assx_ctx* ctx);
 
 struct NmfGroupScope {  // sets assx_ctx::nmf_group for the NMF calls made inside the scope

@@ -42,6 +42,8 @@ int assx_auxiva_iterate(assx_ctx* ctx, int n_iter, int kind, int spatial, int pa
   ASSX_REQUIRE(ctx, r, ASSX_E_NULL, "assx_auxiva_iterate: NULL weight scratch");
   ASSX_REQUIRE(ctx, spatial >= ASSX_SPATIAL_IP && spatial <= ASSX_SPATIAL_IP2, ASSX_E_ARG, "bad spatial algorithm %d",
                spatial);
+  ASSX_REQUIRE(ctx, spatial != ASSX_SPATIAL_IP2 || (M >= 2 && pair_m >= 0 && pair_m < M && pair_n >= 0 && pair_n < M && pair_m != pair_n),
+               ASSX_E_ARG, "IP2 needs a pair of two different sources in [0, %d), got (%d, %d)", M, pair_m, pair_n);
   for (int i = 0; i < n_iter; ++i) {
     int rc = assx_auxiva_weights(ctx, X, W, kind, eps, r, loss ? loss + (size_t)i * B : nullptr, ws, B, M, F, T, dtype,
                                  stream);
@@ -69,7 +71,10 @@ int assx_ilrma_iterate(assx_ctx* ctx, int n_iter, int spatial, int pair_m, int p
   ASSX_REQUIRE(ctx, normalize != 2 || scale, ASSX_E_NULL, "assx_ilrma_iterate: 'projection-back' normalisation needs the scale scratch");
   ASSX_REQUIRE(ctx, spatial >= ASSX_SPATIAL_IP && spatial <= ASSX_SPATIAL_IP2, ASSX_E_ARG, "bad spatial algorithm %d",
                spatial);
-  ASSX_REQUIRE(ctx, M >= 1 && M <= 32, ASSX_E_UNSUPPORTED, "2 <= M <= 32 channels are supported, got %d", M);
+  ASSX_REQUIRE(ctx, M >= 2 && M <= 32, ASSX_E_UNSUPPORTED, "2 <= M <= 32 channels are supported, got %d", M);
+  // the pair is turned into a source mask below (a shift) BEFORE the spatial update would reject it
+  ASSX_REQUIRE(ctx, spatial != ASSX_SPATIAL_IP2 || (pair_m >= 0 && pair_m < M && pair_n >= 0 && pair_n < M && pair_m != pair_n),
+               ASSX_E_ARG, "IP2 needs a pair of two different sources in [0, %d), got (%d, %d)", M, pair_m, pair_n);
   const bool with_stat = normalize == 1;
   for (int i = 0; i < n_iter; ++i) {
     const unsigned mask = spatial == ASSX_SPATIAL_IP2 ? ((1u << pair_m) | (1u << pair_n)) : ~0u;

@@ -309,6 +309,7 @@ inline int pick_splits(int tiles, int Kg) {
 
 struct NmfWs {
   size_t ab, part, lpart, total;
+  size_t part_elems;  // elements reserved at `part`: every launcher checks its slab count against it
 };
 
 constexpr int NMF_MFMA_MAX_K = 64;
@@ -364,6 +365,19 @@ inline void small_splits(int group, int KC, int F, int T, int* TS, int* tchunk, 
   *FS = (F + *fchunk - 1) / *fchunk;
 }
 
+// partitions of the X-fed source-model halves (assx_nmf_xfed.hpp; launched by nmf_update_xfed_t below)
+inline NmfPart xfed_basis_part(int F, int T, int KT) {
+  // one utterance = one partition; every step is done by the M waves (sources) of a workgroup at once.
+  // three workgroups per CU where their LDS (tile double buffer + staging, < 54 KB at n_basis <= 16) allows it, two
+  // otherwise (profiles/r04_xfed_wgs_sweep.txt: 256 / 384 / 512 / 640 / 768 / 1024 -> 0.253 / 0.263 / 0.227 / 0.248 /
+  // 0.224 / 0.247 ms per n_basis = 10 iteration)
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
+}
+inline NmfPart xfed_act_part(int F, int T, int KT) {
+  return make_nmf_part((T + 15) / 16, (F + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
+}
+constexpr int XFED_MAX_K = 32;
+
 inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   NmfWs w;
@@ -383,6 +397,14 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
     const NmfPart pa = dtype == ASSX_F64 ? mfma_act_part<double>(1, F, T, KTv) : mfma_act_part<float>(1, F, T, KTv);
     if ((size_t)pb.maxslots * 2 * B * F * K > pmax) pmax = (size_t)pb.maxslots * 2 * B * F * K;
     if ((size_t)pa.maxslots * 2 * B * K * T > pmax) pmax = (size_t)pa.maxslots * 2 * B * K * T;
+    if (K <= XFED_MAX_K) {
+      // the X-fed halves have their own (larger) workgroup budget: a shorter range per workgroup means MORE workgroups
+      // meet one block, hence more slabs than the map-fed partitions above (F = 1025, T = 660, n_basis = 10: 12
+      // against 11 -- round 4 sized the area without them and the 12th slab landed past it)
+      const NmfPart xb = xfed_basis_part(F, T, KTv), xa = xfed_act_part(F, T, KTv);
+      if ((size_t)xb.maxslots * 2 * B * F * K > pmax) pmax = (size_t)xb.maxslots * 2 * B * F * K;
+      if ((size_t)xa.maxslots * 2 * B * K * T > pmax) pmax = (size_t)xa.maxslots * 2 * B * K * T;
+    }
     if (K <= SMALL_K) {  // small-rank kernels; group = 1 gives the most slabs
       int TS, tchunk, FS, fchunk;
       small_splits(1, small_kc(K), F, T, &TS, &tchunk, &FS, &fchunk);
@@ -390,6 +412,7 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
       if ((size_t)FS * 2 * B * K * T > pmax) pmax = (size_t)FS * 2 * B * K * T;
     }
   }
+  w.part_elems = pmax;
   off += align_up(pmax * r, 256);
   w.lpart = off;
   {
@@ -416,8 +439,12 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   const NmfPart pb = mfma_basis_part<R>(nmf_group(ctx), F, T, KT), pa = mfma_act_part<R>(nmf_group(ctx), F, T, KT);
-  int* tickets = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st);
-  if (!tickets) return ASSX_E_UNSUPPORTED;
+  if ((size_t)pb.maxslots * 2 * B * F * K > L.part_elems || (size_t)pa.maxslots * 2 * B * K * T > L.part_elems)
+    return fail(ctx, ASSX_E_UNSUPPORTED, "NMF halves: %d / %d slabs per block exceed the workspace's slab area", pb.maxslots,
+                pa.maxslots);
+  int* tickets = nullptr;
+  const int trc = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st, &tickets);
+  if (trc) return trc;  // the hipError_t of the allocation, message in ctx
   const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
   hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X,      \
@@ -619,19 +646,9 @@ static int nmf_half_launch(assx_ctx* ctx, const TermSpec& ts, int half, const vo
   return 0;
 }
 
-static NmfPart xfed_basis_part(int F, int T, int KT) {
-  // one utterance = one partition; every step is done by the M waves (sources) of a workgroup at once.
-  // three workgroups per CU where their LDS (tile double buffer + staging, < 54 KB at n_basis <= 16) allows it, two
-  // otherwise (profiles/r04_xfed_wgs_sweep.txt: 256 / 384 / 512 / 640 / 768 / 1024 -> 0.253 / 0.263 / 0.227 / 0.248 /
-  // 0.224 / 0.247 ms per n_basis = 10 iteration)
-  return make_nmf_part((F + 15) / 16, (T + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
-}
-static NmfPart xfed_act_part(int F, int T, int KT) {
-  return make_nmf_part((T + 15) / 16, (F + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
-}
 static bool xfed_applies(int kind, int M, int K) {
   static const int on = nmf_env_int("ASSX_NMF_XFED", 1);  // 0: the power-map route of rounds 1-3 (A/B runs)
-  return on && M >= 2 && M <= 4 && K <= 32 && (kind == ASSX_NMF_IS_MM || kind == ASSX_NMF_T_RAW);
+  return on && M >= 2 && M <= 4 && K <= XFED_MAX_K && (kind == ASSX_NMF_IS_MM || kind == ASSX_NMF_T_RAW);
 }
 
 template <typename R, int M, int KT>
@@ -643,8 +660,13 @@ static int nmf_update_xfed_t(assx_ctx* ctx, int kind, double domain, double para
   const TermSpec ts = make_terms(kind, domain, param);
   const PowSpec pe = update_exponent(kind, domain);
   const NmfPart pb = xfed_basis_part(F, T, KT), pa = xfed_act_part(F, T, KT);
-  int* tickets = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st);
-  if (!tickets) return ASSX_E_ARG;
+  // the slab area is sized by nmf_ws from these very partitions; refuse rather than write past it if the two ever disagree
+  if ((size_t)pb.maxslots * 2 * B * M * F * K > L.part_elems || (size_t)pa.maxslots * 2 * B * M * K * T > L.part_elems)
+    return fail(ctx, ASSX_E_UNSUPPORTED, "X-fed source model: %d / %d slabs per block exceed the workspace's slab area",
+                pb.maxslots, pa.maxslots);
+  int* tickets = nullptr;
+  const int trc = ensure_tickets(ctx, (size_t)B * (pb.nblk > pa.nblk ? pb.nblk : pa.nblk), st, &tickets);
+  if (trc) return trc;
   const bool d2 = domain == 2.0 && kind == ASSX_NMF_IS_MM;
 #define XFED(D2K)                                                                                                        \
   do {                                                                                                                   \
@@ -762,6 +784,34 @@ extern "C" {
 size_t assx_nmf_workspace_bytes(int B, int F, int T, int K, int dtype) {
   if (B < 1 || F < 1 || T < 1 || K < 1) return 0;
   return nmf_ws(B, F, T, K, dtype).total;
+}
+
+int assx_nmf_partition_query(int feed, int half, int group, int F, int T, int K, int dtype, int32_t out[6]) {
+  if (!out || F < 1 || T < 1 || K < 1 || K > NMF_MFMA_MAX_K || (dtype != ASSX_F64 && dtype != ASSX_F32)) return ASSX_E_ARG;
+  if ((feed != 0 && feed != 1) || (half != 0 && half != 1) || group < 1) return ASSX_E_ARG;
+  if (feed == 1 && K > XFED_MAX_K) return ASSX_E_ARG;
+  const int KT = (K + 15) / 16;
+  NmfPart p;
+  if (feed == 1) p = half == 0 ? xfed_basis_part(F, T, KT) : xfed_act_part(F, T, KT);
+  else if (dtype == ASSX_F64) p = half == 0 ? mfma_basis_part<double>(group, F, T, KT) : mfma_act_part<double>(group, F, T, KT);
+  else p = half == 0 ? mfma_basis_part<float>(group, F, T, KT) : mfma_act_part<float>(group, F, T, KT);
+  // workgroup g owns steps [lo(g), lo(g + 1)) of the flattened (block, step) space and writes slab g - (first workgroup
+  // of the block) for every block its range meets
+  int worst = 0;
+  for (int blk = 0; blk < p.nblk; ++blk) {
+    const unsigned first = (unsigned)blk * (unsigned)p.nstep, last = first + (unsigned)p.nstep - 1u;
+    const int n = nmf_part_owner(p, last) - nmf_part_owner(p, first) + 1;
+    if (n > worst) worst = n;
+  }
+  const NmfWs L = nmf_ws(1, F, T, K, dtype);
+  const size_t per_slab = half == 0 ? (size_t)2 * F * K : (size_t)2 * K * T;
+  out[0] = p.G;
+  out[1] = p.nblk;
+  out[2] = p.nstep;
+  out[3] = p.maxslots;
+  out[4] = worst;
+  out[5] = (int32_t)(L.part_elems / per_slab);
+  return 0;
 }
 
 int assx_nmf_update_ex(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb,

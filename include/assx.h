@@ -37,7 +37,10 @@
  *   - Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default).
  *   - Return: 0 ok; <0 invalid argument (ASSX_E_*); >0 a hipError_t.  Nothing throws across the
  *     boundary; assx_last_error(ctx) returns the message of the last failure on that context.
- *   - One context per (device, host thread); contexts are not thread-safe.
+ *   - One context per (device, host thread); contexts are not thread-safe.  One thread may drive several streams through
+ *     its context at once (independent problems, each with its own `ws`): the only device state a context owns -- the
+ *     words the matrix-core NMF / X-fed source-model kernels count their "last workgroup done" tickets on -- is kept
+ *     per stream.  Two calls that share a `ws` must be ordered by the caller (same stream or an event), as ever.
  *   - The library never changes the calling thread's current device.  The caller makes the context's device current
  *     (hipSetDevice) before every call; a call made with another device current is refused with ASSX_E_ARG.
  */
@@ -282,6 +285,15 @@ int assx_compute_demix_filter(assx_ctx* ctx, const void* Y, const void* X, void*
 /* EUCNMF/KLNMF/ISNMF.update_once_mm, ISNMF.update_once_me (src/algorithm/nmf.py:182-207,
  * 241-266, 302-356).  X (B,F,T) real >= 0, Tb (B,F,K), V (B,K,T); Tb, V updated in place. */
 size_t assx_nmf_workspace_bytes(int B, int F, int T, int K, int dtype);
+/* Host-side query (no GPU): the work partition of one matrix-core half update and the slab area the workspace holds
+ * for it.  feed 0 = the map-fed halves of assx_nmf_update (group = matrices per independent problem, 1 for plain
+ * NMF), 1 = the X-fed halves of the ILRMA source model (5 <= n_basis <= 32, M <= 4; `group` unused); half 0 = basis,
+ * 1 = activation.  out[0] = workgroups G, out[1] = blocks, out[2] = steps per block, out[3] = the slab bound the
+ * launchers use, out[4] = the largest number of workgroups that actually meet one block (enumerated: each writes
+ * its own slab), out[5] = slabs per block that fit the area assx_nmf_workspace_bytes reserves.  out[4] <= out[3] <=
+ * out[5] must hold for every shape (tests/test_cabi_and_host.py sweeps it: round 4 sized the area without the X-fed
+ * partitions).  Returns 0, or ASSX_E_ARG.  No reference counterpart (the reference is NumPy). */
+int assx_nmf_partition_query(int feed, int half, int group, int F, int T, int K, int dtype, int32_t out[6]);
 int assx_nmf_update(assx_ctx* ctx, int kind, double domain, double eps, const void* X, void* Tb, void* V,
                     void* ws, int B, int F, int T, int K, int dtype, void* stream);
 /* criterion((Tb V)^(2/domain), X).sum() (src/algorithm/nmf.py:170-174, 229-233, 288-292;

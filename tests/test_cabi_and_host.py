@@ -39,6 +39,45 @@ def test_workspace_queries_need_no_gpu():
     assert _lib.lib.assx_nmf_workspace_bytes(1, 1025, 4096, 32, _lib.F64) > 2 * 1025 * 4096 * 8
 
 
+def _partition_query(feed, half, group, F, T, K, dtype):
+    from audio_source_separation_amd import _lib
+    out = (ctypes.c_int32 * 6)()
+    rc = _lib.lib.assx_nmf_partition_query(feed, half, group, F, T, K, dtype, out)
+    assert rc == 0, (rc, feed, half, group, F, T, K)
+    return list(out)
+
+
+def test_nmf_slab_area_holds_every_partition():
+    """Round 4's advisor finding: the X-fed source-model halves cut their ranges with a larger workgroup budget than the
+    map-fed ones, so more workgroups meet one block and write more slabs -- F = 1025, T = 660, n_basis = 10: 12 -- than
+    the workspace had room for (11).  For every shape: workgroups that meet a block <= the launchers' bound <= slabs the
+    workspace reserves; on both feeds, both halves, both precisions."""
+    from audio_source_separation_amd import _lib
+    g, nblk, nstep, bound, worst, room = _partition_query(1, 0, 1, 1025, 660, 10, _lib.F64)
+    assert (nblk, nstep) == (65, 42) and worst == 12 and worst <= bound <= room  # the advisor's example
+    rng = np.random.default_rng(5)
+    shapes = [(F, T) for F in (129, 257, 513, 1025, 2049, 4097) for T in range(16, 6000, 97)]
+    shapes += [(int(F), int(T)) for F, T in zip(rng.integers(1, 5000, 300), rng.integers(1, 7000, 300))]
+    shapes += [(1025, T) for T in range(640, 680)] + [(1, 1), (16, 16), (17, 15), (1025, 4096), (513, 256)]
+    bad = []
+    for F, T in shapes:
+        for K in (5, 10, 16, 17, 32, 33, 64):
+            for feed in (0, 1):
+                if feed == 1 and K > 32:
+                    continue
+                for half in (0, 1):
+                    for dtype in (_lib.F64, _lib.F32):
+                        for group in ((1,) if feed else (1, 4)):
+                            g, nblk, nstep, bound, worst, room = _partition_query(feed, half, group, F, T, K, dtype)
+                            if not (1 <= worst <= bound <= room and g >= 1):
+                                bad.append((feed, half, group, F, T, K, dtype, worst, bound, room))
+    assert not bad, bad[:10]
+    out = (ctypes.c_int32 * 6)()
+    assert _lib.lib.assx_nmf_partition_query(1, 0, 1, 1025, 660, 33, _lib.F64, out) == -1  # no X-fed halves there
+    assert _lib.lib.assx_nmf_partition_query(2, 0, 1, 1025, 660, 10, _lib.F64, out) == -1
+    assert _lib.lib.assx_nmf_partition_query(0, 0, 1, 1025, 660, 10, _lib.F64, None) == -1
+
+
 @pytest.mark.parametrize("forced_g", [0, 1, 3, 7, 8, 9, 100])
 @pytest.mark.parametrize("B,F,T", [(1, 1025, 4096), (2, 1025, 4096), (8, 1025, 4096), (3, 33, 200), (5, 7, 64), (2, 1, 1)])
 def test_launch_order_is_a_permutation(monkeypatch, forced_g, B, F, T):
@@ -241,6 +280,83 @@ def test_tracked_snapshot_marks_the_device_copy_stale_on_write():
     ent.host = None                                                # the model moved on: `a` is an old snapshot
     a[0, 0] = 7
     assert ent.dev == "again"
+
+
+def test_tracked_snapshot_other_in_place_routes():
+    """Round 4's advisor: fill / sort / put / np.copyto / np.add.at / np.put ... also write in place and must drop the
+    device copy; a write through a PLAIN view of the snapshot's memory passes no hook and is caught by the content
+    signature that DeviceState._dev compares before it reuses the device copy."""
+    from audio_source_separation_amd._state import DeviceState, TrackedArray, _Entry, _signature
+
+    def fresh():
+        ent = _Entry(dev="device tensor")
+        a = np.arange(12.0).reshape(3, 4).view(TrackedArray)
+        a._entry, a._root = ent, a
+        ent.host = a
+        ent.sig = _signature(a)
+        return ent, a
+
+    routes = {
+        "fill": lambda a: a.fill(1.0),
+        "sort": lambda a: a[:, ::-1].sort(axis=1),
+        "put": lambda a: a.put([0, 1], [9.0, 8.0]),
+        "np.put": lambda a: np.put(a, [2], [7.0]),
+        "np.copyto": lambda a: np.copyto(a, np.ones((3, 4))),
+        "np.copyto view": lambda a: np.copyto(a[1], np.ones(4)),
+        "np.add.at": lambda a: np.add.at(a, (0, 0), 5.0),
+        "np.putmask": lambda a: np.putmask(a, a > 5, 0.0),
+        "np.place": lambda a: np.place(a, a > 5, [0.0]),
+        "np.fill_diagonal": lambda a: np.fill_diagonal(a, -1.0),
+        "partition": lambda a: a.reshape(-1)[::-1].partition(3),
+    }
+    for name, edit in routes.items():
+        ent, a = fresh()
+        before = a.copy()
+        edit(a)
+        assert ent.dev is None, name
+        assert not np.array_equal(np.asarray(a), before) or name == "partition", name
+    ent, a = fresh()
+    assert float(np.sum(a)) == 66.0 and np.array_equal(np.sort(a, axis=None), np.arange(12.0)) and ent.dev is not None
+    # behind the hooks: plain views of the same memory
+
+    class Model(DeviceState):
+        class _engine:  # what _dev needs to upload: never reached here (the upload is patched below)
+            pass
+
+    import audio_source_separation_amd._state as st
+    uploads = []
+    orig = st.to_device
+    st.to_device = lambda arr, dt, dev: type("T", (), {"clone": lambda self: uploads.append(np.array(arr)) or "uploaded"})()
+    try:
+        for write in (lambda a: np.asarray(a).__setitem__((0, 0), 100.0), lambda a: a.view(np.ndarray).fill(2.0)):
+            ent, a = fresh()
+            m = Model()
+            m._engine = type("E", (), {"prec": type("P", (), {"cplx": None, "real": None})(), "dev": None})()
+            m.__dict__["_arrays"] = {"basis": ent}
+            assert m._dev("basis", False) == "device tensor" and not uploads  # unchanged host: the device copy is reused
+            write(a)
+            assert ent.dev == "device tensor"  # no hook saw it ...
+            assert m._dev("basis", False) == "uploaded" and uploads  # ... the signature did
+            assert np.array_equal(uploads[-1][0], np.asarray(a))
+            del uploads[:]
+            assert m._dev("basis", False) == "uploaded" and not uploads  # and agrees again afterwards
+    finally:
+        st.to_device = orig
+
+
+def test_thread_contexts_are_not_kept_alive_by_the_exit_hook():
+    """The interpreter-exit hook holds WEAK references to the per-thread context sets (round 4's advisor: a strong list kept
+    every finished thread's contexts -- pinned staging, host thread pool, ticket buffers -- until exit)."""
+    import gc
+    import weakref
+    from audio_source_separation_amd import _device
+    assert isinstance(_device._ALL_HELD, weakref.WeakSet)
+    held = _device._ThreadContexts()
+    _device._ALL_HELD.add(held)
+    n = len(_device._ALL_HELD)
+    del held
+    gc.collect()
+    assert len(_device._ALL_HELD) == n - 1
 
 
 def test_stft_geometry_matches_scipy_semantics():

@@ -171,6 +171,70 @@ def test_ilrma_source_update(eng, M, K, domain):
     assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("M,F,T,K", [(4, 1025, 660, 10), (2, 1025, 657, 10), (3, 513, 330, 12)])
+def test_xfed_source_model_stays_inside_its_workspace(eng, M, F, T, K):
+    """Round 4's advisor finding, on the device: at F = 1025, T = 657..664, n_basis = 10 twelve workgroups of the X-fed basis
+    half meet one block while the workspace held eleven slabs -- the twelfth was written past the slab area, for some T
+    past the end of the buffer.  The call runs on a workspace of exactly assx_workspace_bytes followed by a guard band:
+    the band must come back untouched and the update must equal the oracle's."""
+    from audio_source_separation_amd._device import ptr, stream_ptr
+    X, W = mixture(M, F, T, 700 + M), rand_filters(M, F, 701)
+    rng = np.random.default_rng(702)
+    Tb, V = rng.random((M, F, K)) + 0.05, rng.random((M, K, T)) + 0.05
+    Xd, Wd, Td, Vd = dev_c(eng, X[None]), dev_c(eng, W[None]), dev_r(eng, Tb[None]), dev_r(eng, V[None])
+    n = int(eng._L.assx_workspace_bytes(1, M, F, T, K, eng.prec.code))
+    guard = 1 << 22
+    buf = torch.full((n + guard,), 0x5A, dtype=torch.uint8, device=eng.dev)
+    rc = eng._L.assx_ilrma_source_update(eng.ctx, ptr(Xd), ptr(Wd), ptr(Td), ptr(Vd), 2.0, 1e-12, (1 << M) - 1, ptr(None),
+                                         ptr(buf), 1, M, F, T, K, eng.prec.code, stream_ptr(eng.dev))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert bool((buf[n:] == 0x5A).all()), "the source update wrote past assx_workspace_bytes"
+    T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(X, W)) ** 2, Tb, V, 2)
+    assert rel_err(host(Td)[0], T1) < tol(eng, 1e-11, 5e-5)
+    assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
+
+
+def test_ticket_kernels_on_two_streams_of_one_context(eng):
+    """The "last workgroup done" tickets are device words owned by the context -- one buffer PER STREAM (round 4's advisor:
+    with one shared buffer two NMF updates issued from one thread on two torch streams counted on the same words: a
+    partial sum applied, counters left non-zero for every later call).  Two different problems alternate on two streams
+    without any synchronisation between them; each must equal its own serial run bit for bit, and so must a run afterwards."""
+    F, T, K = 257, 1200, 16
+    rng = np.random.default_rng(710)
+    probs = []
+    for i in range(2):
+        X = rng.random((1, F + 16 * i, T)) ** 2 + 1e-3
+        probs.append((X, rng.random((1, F + 16 * i, K)) + 0.1, rng.random((1, K, T)) + 0.1))
+    from audio_source_separation_amd import _lib
+    from audio_source_separation_amd.ops import Engine
+    kind = _lib.NMF_IS_MM
+    engs = [eng, Engine(dtype=eng.prec.name)]  # a workspace each (as two models have), ONE context: same thread, same device
+    assert engs[0].ctx is engs[1].ctx or engs[0].ctx.value == engs[1].ctx.value
+
+    def serial(p, n):
+        Xd, Td, Vd = dev_r(eng, p[0]), dev_r(eng, p[1]), dev_r(eng, p[2])
+        for _ in range(n):
+            eng.nmf_update(kind, Xd, Td, Vd)
+        torch.cuda.synchronize()
+        return Td.clone(), Vd.clone()
+
+    n_it = 12
+    want = [serial(p, n_it) for p in probs]
+    streams = [torch.cuda.Stream(device=eng.dev), torch.cuda.Stream(device=eng.dev)]
+    state = [(dev_r(eng, p[0]), dev_r(eng, p[1]), dev_r(eng, p[2])) for p in probs]
+    torch.cuda.synchronize()
+    for _ in range(n_it):
+        for e, st, (Xd, Td, Vd) in zip(engs, streams, state):
+            with torch.cuda.stream(st):
+                e.nmf_update(kind, Xd, Td, Vd)
+    torch.cuda.synchronize()
+    for (Tw, Vw), (_, Td, Vd) in zip(want, state):
+        assert torch.equal(Tw, Td) and torch.equal(Vw, Vd)
+    again = serial(probs[0], n_it)
+    assert torch.equal(again[0], want[0][0]) and torch.equal(again[1], want[0][1])
+
+
 @pytest.mark.parametrize("M,K,G", [(4, 10, 0), (4, 10, 3), (2, 5, 2), (3, 8, 5), (4, 12, 1), (4, 16, 7), (3, 13, 4), (2, 7, 0)])
 def test_source_model_wide_basis(eng, M, K, G):
     """The n_basis 5..16 source model (demixed-power map + matrix-core NMF halves) without a loss request, ragged T, zero
