@@ -509,6 +509,45 @@ __device__ __forceinline__ R slab_sum4(const R* p, size_t stride, int S) {
   return (q[0] + q[1]) + (q[2] + q[3]);
 }
 
+// Numerator and denominator sums of NO outputs at once, every one in slab_sum4's order (same additions, same bits):
+// the loads of all 2 NO sums travel together -- one memory round trip per 8 slabs for everything a thread finalizes,
+// instead of one per sum (the holder of the last ticket is the tail of its kernel: in-kernel stamps showed its four
+// dependent round trips of ~1.5 us each).  Slab s of the numerator of output u is pn[s * stride + idx[u]], the
+// denominator pd[...] (pn, pd wave-uniform, idx < 2^29 elements: scalar base + 32-bit lane offset addressing, and 8
+// slabs per trip, keep the registers of the in-flight loads at 32 values).  on[u] = false: the output is skipped (sums 0).
+template <typename R, int NO, int CW = 8>  // CW slabs per trip (a multiple of 4: the strands keep their order)
+__device__ __forceinline__ void slab_sum4_n(const R* pn, const R* pd, const unsigned (&idx)[NO], const bool (&on)[NO],
+                                            size_t stride, int S, R (&out)[2 * NO]) {
+  static_assert(CW % 4 == 0, "whole strand groups per trip");
+  R q[2 * NO][4];
+#pragma unroll
+  for (int i = 0; i < 2 * NO; ++i)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) q[i][c] = 0;
+  for (int s0 = 0; s0 < S; s0 += CW) {
+    R v[2 * NO][CW];
+#pragma unroll
+    for (int c = 0; c < CW; ++c) {
+      const size_t so = (size_t)min(s0 + c, S - 1) * stride;  // wave-uniform
+      const R* sn = pn + so;
+      const R* sd = pd + so;
+#pragma unroll
+      for (int u = 0; u < NO; ++u) {
+        v[2 * u][c] = on[u] ? ld_agent(sn + idx[u]) : (R)0;
+        v[2 * u + 1][c] = on[u] ? ld_agent(sd + idx[u]) : (R)0;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CW; ++c)
+      if (s0 + c < S) {
+#pragma unroll
+        for (int i = 0; i < 2 * NO; ++i) q[i][c & 3] += v[i][c];
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * NO; ++i) out[i] = (q[i][0] + q[i][1]) + (q[i][2] + q[i][3]);
+}
+
 // ------------------------------------------------------------------------------------------
 // wave-level reductions (wave64)
 // ------------------------------------------------------------------------------------------

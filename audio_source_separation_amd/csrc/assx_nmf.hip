@@ -319,6 +319,9 @@ inline int nmf_env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
+// extra dynamic LDS per workgroup of the matrix-core halves (bytes): occupancy experiments
+inline unsigned nmf_lds_pad() { return (unsigned)nmf_env_int("ASSX_NMF_LDS_PAD", 0); }
+
 // split counts of the MFMA path (deterministic: no device query)
 inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ? ctx->nmf_group : 1; }
 
@@ -329,7 +332,8 @@ inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ?
 constexpr int MFMA_WG_BUDGET = 512;  // two workgroups per CU (profiles/r04_nmf_wgs_sweep.txt)
 template <typename R>
 inline NmfPart mfma_basis_part(int group, int F, int T, int KT) {
-  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET));
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET),
+                       KT <= NMF_RAG_MAX_KT ? F % 16 : 0);
 }
 template <typename R>
 inline NmfPart mfma_act_part(int group, int F, int T, int KT) {
@@ -420,7 +424,9 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
     mfma_loss_split(1, F, T, &FS, &fchunk);
     size_t nl = (size_t)B * F * ((T + 255) / 256);
     if ((size_t)B * FS * ((T + 15) / 16) > nl) nl = (size_t)B * FS * ((T + 15) / 16);
-    const size_t fused = (size_t)B * 4 * (size_t)nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET);  // loss on the basis half
+    // loss on the basis half: one partial per (workgroup, wave); group = 1 has the most workgroups
+    const size_t fused = (size_t)B * 4 * (size_t)(dtype == ASSX_F64 ? mfma_basis_part<double>(1, F, T, (K + 15) / 16).G
+                                                                     : mfma_basis_part<float>(1, F, T, (K + 15) / 16).G);
     if (fused > nl) nl = fused;
     off += align_up(nl * 8, 256);
   }
@@ -447,13 +453,13 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   if (trc) return trc;  // the hipError_t of the allocation, message in ctx
   const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
-  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X,      \
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), nmf_lds_pad(), st, (const R*)X,      \
                      (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe, (double*)nullptr, 0, 0.0)
 #define NMF_BASIS_LOSS(D2K)                                                                                    \
-  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K, true>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X, \
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K, true>), dim3(pb.G, 1, B), dim3(256), nmf_lds_pad(), st, (const R*)X, \
                      (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe, lpart, 4 * pb.G, eps)
 #define NMF_ACT(D2K)                                                                                           \
-  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pa.G, 1, B), dim3(256), 0, st, (const R*)X,         \
+  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pa.G, 1, B), dim3(256), nmf_lds_pad(), st, (const R*)X,         \
                      (const R*)Tb, (R*)V, part, tickets, 1, pa, B, F, T, K, (R)eps, ts, pe)
   if (loss_prev && !d2) return fail(ctx, ASSX_E_UNSUPPORTED, "nmf_update_mfma: the fused loss needs domain 2 and EUC / KL / IS");
   if (loss_prev) {
@@ -797,8 +803,8 @@ int assx_nmf_partition_query(int feed, int half, int group, int F, int T, int K,
   else p = half == 0 ? mfma_basis_part<float>(group, F, T, KT) : mfma_act_part<float>(group, F, T, KT);
   // workgroup g owns steps [lo(g), lo(g + 1)) of the flattened (block, step) space and writes slab g - (first workgroup
   // of the block) for every block its range meets
-  int worst = 0;
-  for (int blk = 0; blk < p.nblk; ++blk) {
+  int worst = p.rag ? p.rag_w : 0;  // the ragged last block has rag_w members (vector-ALU workgroups past the partition)
+  for (int blk = 0; blk < p.nblk - (p.rag ? 1 : 0); ++blk) {
     const unsigned first = (unsigned)blk * (unsigned)p.nstep, last = first + (unsigned)p.nstep - 1u;
     const int n = nmf_part_owner(p, last) - nmf_part_owner(p, first) + 1;
     if (n > worst) worst = n;
@@ -949,3 +955,16 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
 }
 
 }  // extern "C"
+
+#if NMF_TRACE
+// timing-experiment builds only (tools/probes/nmf_trace.py); not part of include/assx.h
+extern "C" int assx_debug_nmf_trace(unsigned long long* host, int clear) {
+  using assx::g_nmf_trace;
+  constexpr size_t N = 8192 + 4 * 512;
+  if (clear) {
+    static unsigned long long zeros[N];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nmf_trace), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_nmf_trace), sizeof(unsigned long long) * N);
+}
+#endif

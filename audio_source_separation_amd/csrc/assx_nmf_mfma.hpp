@@ -140,21 +140,82 @@ __device__ __forceinline__ R nmf_apply(R old, R num, R den, R eps, PowSpec p) {
 // ---------------------------------------------------------------------------------------------------------
 struct NmfPart {
   int nblk, nstep, G, maxslots;
+  int w;  // > 0: block-aligned partition, w workgroups per block; 0: the flat partition of round 4
+  // Ragged last block on the vector ALU (basis halves, aligned partition only).  F = 2^n + 1 bins leave ONE valid row in
+  // the last 16-row block: as a matrix-core block it costs what a full one costs (config 2: 65 blocks for 64.06 blocks
+  // of work, and 65 x 8 workgroups do not fit the 512 resident ones).  With rag > 0 the matrix-core partition covers
+  // the nblk - 1 full blocks with Gf = (nblk - 1) w workgroups, and rag_w more workgroups (g >= Gf) take a slice of the
+  // frames each for the `rag` bins of block nblk - 1: a few multiply-adds per element on the vector ALU.  Same records,
+  // tickets and finalize as any block (members = rag_w).
+  int Gf, rag, rag_w;
 };
+constexpr int NMF_RAG_MAX = 2;  // more valid rows than this: the last block stays a matrix-core block
+constexpr int NMF_RAG_MAX_KT = 2;  // n_basis > 32: the kernels have no registers to spare for the side path (host: no rag)
+// Block-aligned since round 5: in-kernel stamps of config 2 showed the workgroups whose flat range crossed a block
+// boundary (64 of 512) paying two block prologues (cold operand loads, ~3 us) and two epilogues (combine, records,
+// ticket, ~5 us): they left 8 us after the median workgroup, and they are the last members of their blocks, so every
+// block's finalize waited for them.  With w workgroups per block every workgroup has one prologue and one epilogue,
+// every block exactly w members (slabs), and a block's members are consecutive workgroups.
 // 32-bit arithmetic: make_nmf_part guarantees (nblk * nstep + 1) * G < 2^32 (a matrix below 4 GiB has < 2^22 steps)
 __host__ __device__ inline unsigned nmf_part_lo(const NmfPart& p, int g) {
+  if (p.w > 0) {
+    const unsigned blk = (unsigned)g / (unsigned)p.w, sl = (unsigned)g % (unsigned)p.w;
+    return blk * (unsigned)p.nstep + sl * (unsigned)p.nstep / (unsigned)p.w;
+  }
   return (unsigned)g * ((unsigned)p.nblk * (unsigned)p.nstep) / (unsigned)p.G;
 }
 // the workgroup whose range holds step x (inverse of nmf_part_lo)
 __host__ __device__ inline int nmf_part_owner(const NmfPart& p, unsigned x) {
+  if (p.w > 0) {
+    const unsigned blk = x / (unsigned)p.nstep, r = x % (unsigned)p.nstep;
+    return (int)(blk * (unsigned)p.w + ((r + 1u) * (unsigned)p.w - 1u) / (unsigned)p.nstep);
+  }
   return (int)(((x + 1u) * (unsigned)p.G - 1u) / ((unsigned)p.nblk * (unsigned)p.nstep));
 }
-inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
+inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs, int rag_rows = 0) {
   NmfPart p;
   p.nblk = nblk;
   p.nstep = nstep;
+  p.rag = 0;
+  p.rag_w = 0;
   const long long wt = (long long)nblk * nstep;
   long long G = target_wgs / (group < 1 ? 1 : group);
+  static const int aligned = [] {
+    const char* v = getenv("ASSX_NMF_ALIGNED");  // 0: round 4's flat partition (A/B runs)
+    return (v && *v) ? atoi(v) : 1;
+  }();
+  static const int rag_on = [] {
+    const char* v = getenv("ASSX_NMF_RAGGED");  // 0: the last block is always a matrix-core block
+    return (v && *v) ? atoi(v) : 0;
+  }();
+  // Aligned only where a block gets at least two workgroups: with fewer the flat partition wastes nothing (a range is
+  // then whole blocks plus one boundary) and keeps G inside the budget -- one workgroup per block would launch nblk of
+  // them, a few more than fit at once when nblk is just above the budget (wide-channel source model: 65 blocks x 8
+  // matrices against 512: the 8 late workgroups were the tail of the kernel).
+  if (aligned && G / nblk >= 2) {
+    const bool rag = rag_on && rag_rows > 0 && rag_rows <= NMF_RAG_MAX && nblk >= 2;
+    if (rag) --nblk;                       // the matrix-core partition covers the full blocks
+    long long w = G / nblk;                // never more workgroups than the budget ...
+    if (w > 16) w = 16;                    // ... at most 16 slabs for the holder of the last ticket to sum
+    if (w > nstep / 4) w = nstep / 4;      // every wave gets a step
+    if (w < 1) w = 1;                      // more blocks than budget: one workgroup per block, several rounds
+    while (w > 1 && (wt + 1) * (nblk * w) >= (1ll << 32)) --w;
+    p.w = (int)w;
+    p.Gf = (int)(nblk * w);
+    p.G = p.Gf;
+    p.maxslots = (int)w;
+    if (rag) {
+      p.rag = rag_rows;
+      long long rw = ((long long)nstep * 16 + 511) / 512;  // >= 512 frames per ragged workgroup
+      if (rw > w) rw = w;
+      if (rw < 1) rw = 1;
+      p.rag_w = (int)rw;
+      p.G = p.Gf + p.rag_w;
+    }
+    return p;
+  }
+  p.w = 0;
+  p.Gf = 0;
   if (G > (long long)nblk * 16) G = (long long)nblk * 16;  // at most ~16 slabs for the holder of the last ticket to sum
   if (G > wt / 4) G = wt / 4;  // every wave gets a step (a 513 x 256 matrix: 132 workgroups of one step per wave; one
                                // workgroup per block with 4 steps per wave and no tickets at all measured slower)
@@ -162,15 +223,139 @@ inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
   while (G > 1 && (wt + 1) * G >= (1ll << 32)) G /= 2;  // 32-bit partition arithmetic in the kernels
   if (G < 1) G = 1;
   p.G = (int)G;
+  p.Gf = p.G;
   const long long per = wt / G;  // shortest range
   p.maxslots = (int)((nstep + per - 1) / per) + 1;
   return p;
 }
 
+#ifndef NMF_FIN_NO1
+#define NMF_FIN_NO1 0
+#endif
+#ifndef NMF_TRACE
+#define NMF_TRACE 0  // 1: shader-clock stamps of the basis half (tools/probes/nmf_trace.py): every workgroup's entry / exit on the
+                     // 100 MHz clock, every step of the waves of workgroup NMF_TRACE_WG on the shader clock
+#endif
+#if NMF_TRACE && !defined(ASSX_PROBE_BUILD)
+#error "NMF_TRACE adds a debug entry point and stamps: build it with -DASSX_PROBE_BUILD into a probe library, never into libassx.so"
+#endif
+#if NMF_TRACE
+#ifndef NMF_TRACE_WG
+#define NMF_TRACE_WG 100
+#endif
+__device__ unsigned long long g_nmf_trace[8192 + 4 * 512];
+#define NMF_STAMP(id)                                                                                              \
+  do {                                                                                                             \
+    if (g == NMF_TRACE_WG && b == 0 && lane == 0 && tr_n < 512)                                                    \
+      g_nmf_trace[8192 + wv * 512 + tr_n++] = ((unsigned long long)(id) << 56) | (__builtin_readcyclecounter() & 0xffffffffffffffull); \
+  } while (0)
+#else
+#define NMF_STAMP(id) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------
 // basis half: num|den (F,K) = [A|Bm] (F,T) . V^T.   grid (G, 1, B), 4 waves; block = 16 bins, step = 16 frames.
 //   part[slab][b*2 + s][f*K + k]
 // ---------------------------------------------------------------------------------------------------------
+// The ragged rows of the last block on the vector ALU (NmfPart::rag): workgroup `r` of `rw` takes the frames
+// [r, r + 1) * ceil(T / rw) of the `nb` bins f0 .. f0 + nb - 1 of one matrix.  Per 256 frames: (1) a thread per frame
+// forms T V (k ascending), the two terms and -- LOSS -- the criterion, (2) wave v sums a V^T / bm V^T for k = v, v + 4,
+// ..., lanes over the frames; the waves' lanes are combined by a fixed butterfly at the end.  Results go to
+// res[(s * nb + j) * K + k] (s = 0 numerator, 1 denominator) in LDS; `as`, `bs` hold the 256 terms of a trip.
+template <typename R, int KP, int D2K, bool LOSS>
+__device__ __forceinline__ void nmf_basis_ragged(const R* __restrict__ xb, const R* tbb, const R* __restrict__ vb, R* as,
+                                                 R* bs, R* res, int r, int rw, int f0, int nb, int T, int K, R eps,
+                                                 const TermSpec& s, double leps, double& ltot) {
+  constexpr int KK = KP / 4;  // k's per wave
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int chunk = (T + rw - 1) / rw, ta = r * chunk, te = min(T, ta + chunk);
+  R* tbs = res + 2 * NMF_RAG_MAX * KP;  // the bin's basis row, zero-padded to KP
+  for (int j = 0; j < nb; ++j) {
+    const int f = f0 + j;
+    const R* xr = xb + (size_t)f * T;
+    __syncthreads();  // the previous bin's row has been consumed
+    if ((int)threadIdx.x < KP) tbs[threadIdx.x] = ((int)threadIdx.x < K) ? tbb[(size_t)f * K + threadIdx.x] : (R)0;
+    R pn[KK], pd[KK];
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      pn[q] = 0;
+      pd[q] = 0;
+    }
+    double lacc = 0.0, lm = 1.0;
+    int le = 0;
+    for (int tc = ta; tc < te; tc += 256) {
+      const int t = min(tc + (int)threadIdx.x, te - 1);  // threads past the range repeat its last frame and drop out below
+      const bool live = tc + (int)threadIdx.x < te;
+      const R x = xr[t];
+      __syncthreads();  // the row is in place; the previous trip's terms have been consumed
+      R tv = 0;
+#pragma unroll
+      for (int k0 = 0; k0 < KP; k0 += 16) {  // 16 loads in flight (a loop with a run-time bound made it one round trip per k)
+        R vv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) vv[q] = vb[(size_t)min(k0 + q, K - 1) * T + t];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) tv = fma(tbs[k0 + q], vv[q], tv);  // rows past K meet zeros
+      }
+      R a, bm;
+      nmf_terms<R, D2K>(s, x, tv, eps, a, bm);
+      if (LOSS && live) {  // criterion((Tb V)^(2/2), x): Tb V as the product gave it, NOT floored (as in the matrix-core blocks)
+        const double in = (double)tv, xx = (double)x;
+        if (D2K == ASSX_NMF_EUC) {
+          lacc = fma(xx - in, xx - in, lacc);
+        } else {
+          const double in_ = in + leps, tg_ = xx + leps;
+          const double ratio = tg_ * fast_rcp(in_);
+          if (D2K == ASSX_NMF_KL) {
+            lacc += tg_ * log(ratio) + in_ - tg_;
+          } else {
+            int e;
+            lacc += ratio - 1.0;
+            lm = frexp(lm * ratio, &e);
+            le += e;
+          }
+        }
+      }
+      as[threadIdx.x] = live ? a : (R)0;
+      bs[threadIdx.x] = live ? bm : (R)0;
+      __syncthreads();
+      R au[4], bu[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        au[u] = as[lane + 64 * u];
+        bu[u] = bs[lane + 64 * u];
+      }
+#pragma unroll
+      for (int q0 = 0; q0 < KK; q0 += 4) {  // 16 loads in flight
+        R vq[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int u = 0; u < 4; ++u)  // rows past K repeat row K - 1 and are never written; frames past the range meet zeros
+            vq[q][u] = vb[(size_t)min(wv + 4 * (q0 + q), K - 1) * T + min(tc + lane + 64 * u, te - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            pn[q0 + q] = fma(au[u], vq[q][u], pn[q0 + q]);
+            pd[q0 + q] = fma(bu[u], vq[q][u], pd[q0 + q]);
+          }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < KK; ++q) {
+      const R n = wave_allreduce_sum<R>(pn[q]), d = wave_allreduce_sum<R>(pd[q]);
+      const int k = wv + 4 * q;
+      if (lane == 0 && k < K) {
+        res[(size_t)(0 * nb + j) * K + k] = n;
+        res[(size_t)(1 * nb + j) * K + k] = d;
+      }
+    }
+    if (LOSS) ltot += (D2K == ASSX_NMF_IS_MM) ? lacc - ((double)le * 0.6931471805599453 + log(lm)) : lacc;
+  }
+  __syncthreads();
+}
+
 // LOSS (domain 2, EUC / KL / IS: D2K >= 0): the half also accumulates criterion(Tb V, X) of the model it READS (nmf.py:
 // 170-174, 229-233, 288-292; divergence.py:21-45) -- the loss the reference records after the PREVIOUS update -- from the
 // very Tb V and X it holds, every (f, t) exactly once: one partial per (workgroup, wave) at lpart[b * lstride + 4 g + wave],
@@ -197,6 +382,17 @@ __global__ void __launch_bounds__(256)
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.z, g = blockIdx.x;
+#if NMF_TRACE
+  int tr_n = 0;
+  if (b == 0 && threadIdx.x == 0 && g < 1024) {
+    g_nmf_trace[8 * g + 0] = __builtin_amdgcn_s_memrealtime();
+    g_nmf_trace[8 * g + 4] = __builtin_readcyclecounter();
+    g_nmf_trace[8 * g + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4);   // HW_ID
+    g_nmf_trace[8 * g + 7] = __builtin_amdgcn_s_getreg((31 << 11) | 20);  // XCC_ID
+  }
+  int tr_fin = 0;
+  NMF_STAMP(1);
+#endif
   R(*vt)[LD] = reinterpret_cast<R(*)[LD]>(smem + wv * KP * LD);
   R(*red)[KT * 8][64] = reinterpret_cast<R(*)[KT * 8][64]>(smem);
   const R* vb = V + (size_t)b * K * T;
@@ -215,7 +411,144 @@ __global__ void __launch_bounds__(256)
   const BufRsrc vrs = make_rsrc(vb), xrs = make_rsrc(xb);
   double ltot = 0.0;  // LOSS: this wave's share
 
+  // ---- end of a block's share of this workgroup: records (or the direct update), ticket, finalize.  ns / ds: wave 0's
+  // lanes hold the workgroup's sums in the accumulator layout D[row = f0 + crow][col = kb].
+  auto block_tail = [&](int blk, int f0, int slot, int members, auto&& sums) {  // sums(c, r, n, d): one (c, r) pair of them
+    R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * FK;
+    const bool direct = apply && members == 1;
+    if (wv == 0) {
+      // Three straight-line forms of the output: in one loop body the `direct` path's read of Tb made the compiler wait
+      // for ALL memory operations before every LDS read of the next (c, r) -- the 8 record stores of a lane went out one
+      // round trip after the other (3.5 us of every workgroup's life, in-kernel stamps).
+      if (direct) {
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
+            if (fo < F && kb < K) {
+              R n, d;
+              sums(c, r, n, d);
+              R* tp = Tb + (size_t)b * FK + (size_t)fo * K + kb;
+              *tp = nmf_apply<R, D2K>(*tp, n, d, eps, pe);
+            }
+          }
+      } else if (apply) {
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
+            if (fo < F && kb < K) {
+              R n, d;
+              sums(c, r, n, d);
+              const size_t o = (size_t)fo * K + kb;
+              st_agent(pn + o, n);
+              st_agent(pn + FK + o, d);
+            }
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
+            if (fo < F && kb < K) {
+              R n, d;
+              sums(c, r, n, d);
+              const size_t o = (size_t)fo * K + kb;
+              pn[o] = n;
+              pn[FK + o] = d;
+            }
+          }
+      }
+      NMF_STAMP(6);
+      if (apply && !direct) {
+        const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
+        if (lane == 0) s_last = last;
+      }
+      NMF_STAMP(7);
+#if NMF_TRACE
+      if (b == 0 && threadIdx.x == 0 && g < 1024) g_nmf_trace[8 * g + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+    const size_t slab = (size_t)B * 2 * FK;
+    if (!apply) {
+      // callers that combine the slabs themselves sum maxslots of them: the last member clears the unused ones
+      if (slot == members - 1)
+        for (int sl = members; sl < pt.maxslots; ++sl)
+          for (int o = threadIdx.x; o < 16 * K; o += 256) {
+            const int fo = f0 + o / K;
+            if (fo >= F) break;
+            R* q = part + (size_t)sl * slab + (size_t)b * 2 * FK + (size_t)fo * K + o % K;
+            q[0] = 0;
+            q[FK] = 0;
+          }
+    } else if (!direct) {
+      __syncthreads();
+      if (s_last) {
+        // ---- holder of the last ticket: sum the slabs of this 16 x K block and update Tb in place.  Every member
+        // read its rows of Tb at the top of the block, i.e. before it took its ticket.
+        // Two outputs per thread and trip, their four slab sums in flight together (slab_sum4_n).
+        constexpr int NO = (D2K < 0 || KT >= 3 || NMF_FIN_NO1) ? 1 : 2;  // the pow() / wide variants have no registers to spare for a second output
+        const R* p0 = part + (size_t)b * 2 * FK;
+        R* tbo = Tb + (size_t)b * FK;
+        for (int o = threadIdx.x; o < 16 * K; o += 256 * NO) {
+          unsigned idx[NO];
+          bool on[NO];
+          R old[NO];
+#pragma unroll
+          for (int u = 0; u < NO; ++u) {
+            const int ou = o + 256 * u, fo = f0 + ou / K;
+            on[u] = ou < 16 * K && fo < F;
+            idx[u] = on[u] ? (unsigned)fo * (unsigned)K + (unsigned)(ou % K) : 0u;
+            old[u] = on[u] ? tbo[idx[u]] : (R)0;  // requested with the slabs
+          }
+          R sum[2 * NO];
+          slab_sum4_n<R, NO>(p0, p0 + FK, idx, on, slab, members, sum);
+#pragma unroll
+          for (int u = 0; u < NO; ++u)
+            if (on[u]) tbo[idx[u]] = nmf_apply<R, D2K>(old[u], sum[2 * u], sum[2 * u + 1], eps, pe);
+        }
+      }
+    }
+    __syncthreads();  // the combine memory becomes staging memory again (next block of this range)
+    NMF_STAMP(s_last ? 9 : 8);
+#if NMF_TRACE
+    tr_fin += (apply && members > 1 && s_last) ? 1 : 0;
+#endif
+  };
+
+  // ---- workgroups past the matrix-core partition: the ragged rows of the last block on the vector ALU (NmfPart::rag).
+  // Its own branch, before anything of the matrix-core path is live: as a side path of the block loop below it cost
+  // that loop a quarter of its registers.
+  if (KT <= NMF_RAG_MAX_KT && pt.rag > 0 && g >= pt.Gf) {
+    const int blk = pt.nblk - 1, f0 = blk * 16, slot = g - pt.Gf, members = pt.rag_w;
+    double lr = 0.0;
+    nmf_basis_ragged<R, KP, D2K, LOSS>(xb, Tb + (size_t)b * FK, vb, smem, smem + 256, smem + 512, slot, members, f0, pt.rag, T,
+                                       K, eps, s, (double)leps, lr);
+    block_tail(blk, f0, slot, members, [&](int c, int r, R& n, R& d) {  // the ragged rows' sums, in the layout the tail expects
+      const int j = MM::crow(r, lane), kb = 16 * c + li;
+      const bool in = j < pt.rag && kb < K;
+      n = in ? smem[512 + (size_t)(0 * pt.rag + j) * K + kb] : (R)0;
+      d = in ? smem[512 + (size_t)(1 * pt.rag + j) * K + kb] : (R)0;
+    });
+    if (LOSS) {
+      lr = wave_allreduce_sum<double>(lr);  // every thread's own elements
+      if (lane == 0) lpart[(size_t)b * lstride + (size_t)g * 4 + wv] = lr;
+    }
+#if NMF_TRACE
+    if (b == 0 && threadIdx.x == 0 && g < 1024) {
+      g_nmf_trace[8 * g + 1] = __builtin_amdgcn_s_memrealtime();
+      g_nmf_trace[8 * g + 3] = (unsigned long long)tr_fin;
+      g_nmf_trace[8 * g + 5] = __builtin_readcyclecounter();
+    }
+#endif
+    return;
+  }
+
   const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  NMF_STAMP(11);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
     const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
     const int s0 = lo > base ? (int)(lo - base) : 0;
@@ -321,15 +654,18 @@ __global__ void __launch_bounds__(256)
       for (int i = 0; i < NLD; ++i) vt[(i * 64 + lane) >> 4][lane & 15] = stage[i];
       if (t0 + 64 < te) fetch(t0 + 64);  // the next tile travels while this one is consumed
       __builtin_amdgcn_wave_barrier();
+      NMF_STAMP(3);
       compute(masked, t0, xc);
       __builtin_amdgcn_wave_barrier();
     };
     // whole sub-tiles in the loop, the (at most one) ragged sub-tile of the matrix after it: one loop body with both
     // forms made the accumulators of the two paths meet in copies at the back-edge (16 v_mov_b64 behind the last MFMA)
     int t0 = (s0 + wv) * 16;
+    NMF_STAMP(2);
     if (t0 < te) fetch(t0);
     for (; t0 + 16 <= te; t0 += 64) step(IntC<0>(), t0);
     if (t0 < te) step(IntC<1>(), t0);
+    NMF_STAMP(4);
 
     if (LOSS && f0 + li < F)  // a lane's elements belong to one bin: rows past F (copies of row F-1) drop out here
       ltot += lacc - ((double)le * 0.6931471805599453 + log(lm));
@@ -345,77 +681,29 @@ __global__ void __launch_bounds__(256)
         }
     }
     __syncthreads();
-    R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * FK;
-    const bool direct = apply && members == 1;
-    if (wv == 0) {
-      // D[row = f0 + crow][col = kb]
+    NMF_STAMP(5);
+    NMF_STAMP(10);
+    block_tail(blk, f0, slot, members, [&](int c, int r, R& n, R& d) {  // wave 0: its own sums + the other waves'
+      n = num[c][r];
+      d = den[c][r];
 #pragma unroll
-      for (int c = 0; c < KT; ++c) {
-        const int kb = 16 * c + li;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          R n = num[c][r], d = den[c][r];
-#pragma unroll
-          for (int w = 0; w < 3; ++w) {
-            n += red[w][(c * 2 + 0) * 4 + r][lane];
-            d += red[w][(c * 2 + 1) * 4 + r][lane];
-          }
-          const int fo = f0 + MM::crow(r, lane);
-          if (fo < F && kb < K) {
-            const size_t o = (size_t)fo * K + kb;
-            if (direct) {
-              R* tp = Tb + (size_t)b * FK + o;
-              *tp = nmf_apply<R, D2K>(*tp, n, d, eps, pe);
-            } else if (apply) {
-              st_agent(pn + o, n);
-              st_agent(pn + FK + o, d);
-            } else {
-              pn[o] = n;
-              pn[FK + o] = d;
-            }
-          }
-        }
+      for (int w = 0; w < 3; ++w) {
+        n += red[w][(c * 2 + 0) * 4 + r][lane];
+        d += red[w][(c * 2 + 1) * 4 + r][lane];
       }
-      if (apply && !direct) {
-        const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
-        if (lane == 0) s_last = last;
-      }
-    }
-    const size_t slab = (size_t)B * 2 * FK;
-    if (!apply) {
-      // callers that combine the slabs themselves sum maxslots of them: the last member clears the unused ones
-      if (slot == members - 1)
-        for (int sl = members; sl < pt.maxslots; ++sl)
-          for (int o = threadIdx.x; o < 16 * K; o += 256) {
-            const int fo = f0 + o / K;
-            if (fo >= F) break;
-            R* q = part + (size_t)sl * slab + (size_t)b * 2 * FK + (size_t)fo * K + o % K;
-            q[0] = 0;
-            q[FK] = 0;
-          }
-    } else if (!direct) {
-      __syncthreads();
-      if (s_last) {
-        // ---- holder of the last ticket: sum the slabs of this 16 x K block and update Tb in place.  Every member
-        // read its rows of Tb at the top of the block, i.e. before it took its ticket.
-        const R* p0 = part + (size_t)b * 2 * FK;
-        for (int o = threadIdx.x; o < 16 * K; o += 256) {
-          const int fo = f0 + o / K;
-          if (fo >= F) break;
-          const size_t idx = (size_t)fo * K + o % K;
-          R* tp = Tb + (size_t)b * FK + idx;
-          const R old = *tp;
-          const R n = slab_sum4(p0 + idx, slab, members), d = slab_sum4(p0 + FK + idx, slab, members);
-          *tp = nmf_apply<R, D2K>(old, n, d, eps, pe);
-        }
-      }
-    }
-    __syncthreads();  // the combine memory becomes staging memory again (next block of this range)
+    });
   }
   if (LOSS) {
     ltot = wave_allreduce_sum<double>(ltot);
     if (lane == 0) lpart[(size_t)b * lstride + (size_t)g * 4 + wv] = ltot;
   }
+#if NMF_TRACE
+  if (b == 0 && threadIdx.x == 0 && g < 1024) {
+    g_nmf_trace[8 * g + 1] = __builtin_amdgcn_s_memrealtime();
+    g_nmf_trace[8 * g + 3] = (unsigned long long)tr_fin;
+    g_nmf_trace[8 * g + 5] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -567,31 +855,58 @@ __global__ void __launch_bounds__(256)
     R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * KTt;
     const bool direct = apply && members == 1;
     if (wv == 0) {
+      // three straight-line forms of the output, as in the basis half (no wait between the record stores)
+      auto sums = [&](int c, int r, R& n, R& d) {  // wave 0: its own sums + the other waves'
+        n = num[c][r];
+        d = den[c][r];
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
+        for (int w = 0; w < 3; ++w) {
+          n += red[w][(c * 2 + 0) * 4 + r][lane];
+          d += red[w][(c * 2 + 1) * 4 + r][lane];
+        }
+      };
+      if (direct) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          R n = num[c][r], d = den[c][r];
+        for (int c = 0; c < KT; ++c)
 #pragma unroll
-          for (int w = 0; w < 3; ++w) {
-            n += red[w][(c * 2 + 0) * 4 + r][lane];
-            d += red[w][(c * 2 + 1) * 4 + r][lane];
-          }
-          const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
-          if (kb < K && tvalid) {
-            const size_t o = (size_t)kb * T + t;
-            if (direct) {
-              R* vp = V + (size_t)b * KTt + o;
+          for (int r = 0; r < 4; ++r) {
+            const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
+            if (kb < K && tvalid) {
+              R n, d;
+              sums(c, r, n, d);
+              R* vp = V + (size_t)b * KTt + (size_t)kb * T + t;
               *vp = nmf_apply<R, D2K>(*vp, n, d, eps, pe);
-            } else if (apply) {
+            }
+          }
+      } else if (apply) {
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kb = 16 * c + MM::crow(r, lane);
+            if (kb < K && tvalid) {
+              R n, d;
+              sums(c, r, n, d);
+              const size_t o = (size_t)kb * T + t;
               st_agent(pn + o, n);
               st_agent(pn + KTt + o, d);
-            } else {
+            }
+          }
+      } else {
+#pragma unroll
+        for (int c = 0; c < KT; ++c)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kb = 16 * c + MM::crow(r, lane);
+            if (kb < K && tvalid) {
+              R n, d;
+              sums(c, r, n, d);
+              const size_t o = (size_t)kb * T + t;
               pn[o] = n;
               pn[KTt + o] = d;
             }
           }
-        }
+      }
       if (apply && !direct) {
         const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
         if (lane == 0) s_last = last;
@@ -614,14 +929,24 @@ __global__ void __launch_bounds__(256)
         // ---- holder of the last ticket: sum the slabs of this K x 16 block and update V in place (every member read
         // its columns of V at the top of the block, before it took its ticket)
         const R* p0 = part + (size_t)b * 2 * KTt;
-        for (int o = threadIdx.x; o < 16 * K; o += 256) {
-          const int tc = t0 + (o & 15);
-          if (tc >= T) continue;
-          const size_t idx = (size_t)(o >> 4) * T + tc;
-          R* vp = V + (size_t)b * KTt + idx;
-          const R old = *vp;
-          const R n = slab_sum4(p0 + idx, slab, members), d = slab_sum4(p0 + KTt + idx, slab, members);
-          *vp = nmf_apply<R, D2K>(old, n, d, eps, pe);
+        R* vo = V + (size_t)b * KTt;
+        constexpr int NO = (D2K < 0 || KT >= 3 || NMF_FIN_NO1) ? 1 : 2;
+        for (int o = threadIdx.x; o < 16 * K; o += 256 * NO) {
+          unsigned idx[NO];
+          bool on[NO];
+          R old[NO];
+#pragma unroll
+          for (int u = 0; u < NO; ++u) {
+            const int ou = o + 256 * u, tc = t0 + (ou & 15);
+            on[u] = ou < 16 * K && tc < T;
+            idx[u] = on[u] ? (unsigned)(ou >> 4) * (unsigned)T + (unsigned)tc : 0u;
+            old[u] = on[u] ? vo[idx[u]] : (R)0;
+          }
+          R sum[2 * NO];
+          slab_sum4_n<R, NO>(p0, p0 + KTt, idx, on, slab, members, sum);
+#pragma unroll
+          for (int u = 0; u < NO; ++u)
+            if (on[u]) vo[idx[u]] = nmf_apply<R, D2K>(old[u], sum[2 * u], sum[2 * u + 1], eps, pe);
         }
       }
     }

@@ -179,23 +179,31 @@ __global__ void __launch_bounds__(64 * M)
     // ---- end of this workgroup's share of the block: every wave holds its own source's sums
     R* pn = part + ((size_t)slot * BN * 2 + bn * 2) * FK;
     const bool direct = members == 1;
+    // two straight-line forms of the output: in one loop body the `direct` path's read of Tb made the compiler wait for
+    // ALL memory operations between the record stores -- they went out one round trip after the other (assx_nmf_mfma.hpp)
+    if (direct) {
 #pragma unroll
-    for (int c = 0; c < KT; ++c) {
-      const int kb = 16 * c + li;
+      for (int c = 0; c < KT; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int fo = f0 + MM::crow(r, lane);
-        if (fo < F && kb < K) {
-          const size_t o = (size_t)fo * K + kb;
-          if (direct) {
-            R* tp = Tb + bn * FK + o;
+        for (int r = 0; r < 4; ++r) {
+          const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
+          if (fo < F && kb < K) {
+            R* tp = Tb + bn * FK + (size_t)fo * K + kb;
             *tp = nmf_apply<R, D2K>(*tp, num[c][r], den[c][r], eps, pe);
-          } else {
+          }
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
+          if (fo < F && kb < K) {
+            const size_t o = (size_t)fo * K + kb;
             st_agent(pn + o, num[c][r]);
             st_agent(pn + FK + o, den[c][r]);
           }
         }
-      }
     }
     if (!direct) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's records are out ...
@@ -208,16 +216,21 @@ __global__ void __launch_bounds__(64 * M)
       if (s_last) {
         // holder of the last ticket: wave n sums the slabs of source n's 16 x K block and updates Tb in place (every
         // member read its rows of Tb at the top of the block, before it took its ticket)
+        // numerator and denominator sums of an output in flight together (slab_sum4_n: same additions, same bits; 16 loads
+        // per trip as before -- this kernel runs three workgroups per CU and has no registers to spare for more)
         const R* p0 = part + bn * 2 * FK;
+        R* tbo = Tb + bn * FK;
         const size_t slab = BN * 2 * FK;
         for (int o = lane; o < 16 * K; o += 64) {
           const int fo = f0 + o / K;
-          if (fo >= F) break;
-          const size_t idx = (size_t)fo * K + o % K;
-          R* tp = Tb + bn * FK + idx;
-          const R old = *tp;
-          const R nn = slab_sum4(p0 + idx, slab, members), dd = slab_sum4(p0 + FK + idx, slab, members);
-          *tp = nmf_apply<R, D2K>(old, nn, dd, eps, pe);
+          unsigned idx[1];
+          bool on[1];
+          on[0] = fo < F;
+          idx[0] = on[0] ? (unsigned)fo * (unsigned)K + (unsigned)(o % K) : 0u;
+          const R old = on[0] ? tbo[idx[0]] : (R)0;
+          R sum[2];
+          slab_sum4_n<R, 1, 8>(p0, p0 + FK, idx, on, slab, members, sum);
+          if (on[0]) tbo[idx[0]] = nmf_apply<R, D2K>(old, sum[0], sum[1], eps, pe);
         }
       }
     }
@@ -378,22 +391,30 @@ __global__ void __launch_bounds__(64 * M)
 
     R* pn = part + ((size_t)slot * BN * 2 + bn * 2) * KTt;
     const bool direct = members == 1;
+    if (direct) {  // two straight-line forms, as in the basis half
 #pragma unroll
-    for (int c = 0; c < KT; ++c)
+      for (int c = 0; c < KT; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
-        if (kb < K && tvalid) {
-          const size_t o = (size_t)kb * T + t;
-          if (direct) {
-            R* vp = V + bn * KTt + o;
+        for (int r = 0; r < 4; ++r) {
+          const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
+          if (kb < K && tvalid) {
+            R* vp = V + bn * KTt + (size_t)kb * T + t;
             *vp = nmf_apply<R, D2K>(*vp, num[c][r], den[c][r], eps, pe);
-          } else {
+          }
+        }
+    } else {
+#pragma unroll
+      for (int c = 0; c < KT; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kb = 16 * c + MM::crow(r, lane);
+          if (kb < K && tvalid) {
+            const size_t o = (size_t)kb * T + t;
             st_agent(pn + o, num[c][r]);
             st_agent(pn + KTt + o, den[c][r]);
           }
         }
-      }
+    }
     if (!direct) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -404,15 +425,24 @@ __global__ void __launch_bounds__(64 * M)
       __syncthreads();
       if (s_last) {
         const R* p0 = part + bn * 2 * KTt;
+        R* vo = V + bn * KTt;
         const size_t slab = BN * 2 * KTt;
-        for (int o = lane; o < 16 * K; o += 64) {
-          const int tc = t0 + (o & 15);
-          if (tc >= T) continue;
-          const size_t idx = (size_t)(o >> 4) * T + tc;
-          R* vp = V + bn * KTt + idx;
-          const R old = *vp;
-          const R nn = slab_sum4(p0 + idx, slab, members), dd = slab_sum4(p0 + KTt + idx, slab, members);
-          *vp = nmf_apply<R, D2K>(old, nn, dd, eps, pe);
+        for (int o = lane; o < 16 * K; o += 128) {
+          unsigned idx[2];
+          bool on[2];
+          R old[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int ou = o + 64 * u, tc = t0 + (ou & 15);
+            on[u] = ou < 16 * K && tc < T;
+            idx[u] = on[u] ? (unsigned)(ou >> 4) * (unsigned)T + (unsigned)tc : 0u;
+            old[u] = on[u] ? vo[idx[u]] : (R)0;
+          }
+          R sum[4];
+          slab_sum4_n<R, 2, 4>(p0, p0 + KTt, idx, on, slab, members, sum);  // 16 loads per trip, as before
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+            if (on[u]) vo[idx[u]] = nmf_apply<R, D2K>(old[u], sum[2 * u], sum[2 * u + 1], eps, pe);
         }
       }
     }

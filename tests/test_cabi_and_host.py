@@ -54,7 +54,9 @@ def test_nmf_slab_area_holds_every_partition():
     workspace reserves; on both feeds, both halves, both precisions."""
     from audio_source_separation_amd import _lib
     g, nblk, nstep, bound, worst, room = _partition_query(1, 0, 1, 1025, 660, 10, _lib.F64)
-    assert (nblk, nstep) == (65, 42) and worst == 12 and worst <= bound <= room  # the advisor's example
+    # the advisor's example: 12 workgroups met a block under round 4's flat partition (ASSX_NMF_ALIGNED=0), 10 do since
+    # the partition is block-aligned; either way the area must hold them
+    assert (nblk, nstep) == (65, 42) and worst in (10, 12) and worst <= bound <= room
     rng = np.random.default_rng(5)
     shapes = [(F, T) for F in (129, 257, 513, 1025, 2049, 4097) for T in range(16, 6000, 97)]
     shapes += [(int(F), int(T)) for F, T in zip(rng.integers(1, 5000, 300), rng.integers(1, 7000, 300))]
