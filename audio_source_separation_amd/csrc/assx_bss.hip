@@ -2246,3 +2246,16 @@ int assx_projection_back(assx_ctx* ctx, const void* Y, const void* reference, vo
 }
 
 }  // extern "C"
+
+#if STREAM_TRACE
+// timing-experiment builds only (tools/probes/stream_trace.py); not part of include/assx.h
+extern "C" int assx_debug_stream_trace(unsigned long long* host, int clear) {
+  using assx::g_stream_trace;
+  constexpr size_t N = 8 * 4096;
+  if (clear) {
+    static unsigned long long zeros[N];
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stream_trace), zeros, sizeof(zeros));
+  }
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stream_trace), sizeof(unsigned long long) * N);
+}
+#endif

@@ -395,12 +395,17 @@ inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
   size_t pmax = sb * 2 * B * F * K;
   if (sa * 2 * B * K * T > pmax) pmax = sa * 2 * B * K * T;
   {
-    // matrix-core halves: group = 1 has the most workgroups per matrix, hence the most slabs per block
+    // matrix-core halves: the slab bound of every group size a caller may set (assx_ctx::nmf_group: 1 for plain NMF, the
+    // number of sources for the ILRMA source models).  Until round 4 group = 1 had the most slabs; since the partition is
+    // block-aligned where a block gets two workgroups and flat otherwise, a larger group can fall back to the flat form
+    // with a (loose) bound above the aligned one of group 1.
     const int KTv = (K + 15) / 16;
-    const NmfPart pb = dtype == ASSX_F64 ? mfma_basis_part<double>(1, F, T, KTv) : mfma_basis_part<float>(1, F, T, KTv);
-    const NmfPart pa = dtype == ASSX_F64 ? mfma_act_part<double>(1, F, T, KTv) : mfma_act_part<float>(1, F, T, KTv);
-    if ((size_t)pb.maxslots * 2 * B * F * K > pmax) pmax = (size_t)pb.maxslots * 2 * B * F * K;
-    if ((size_t)pa.maxslots * 2 * B * K * T > pmax) pmax = (size_t)pa.maxslots * 2 * B * K * T;
+    for (int grp = 1; grp <= 32; ++grp) {
+      const NmfPart pb = dtype == ASSX_F64 ? mfma_basis_part<double>(grp, F, T, KTv) : mfma_basis_part<float>(grp, F, T, KTv);
+      const NmfPart pa = dtype == ASSX_F64 ? mfma_act_part<double>(grp, F, T, KTv) : mfma_act_part<float>(grp, F, T, KTv);
+      if ((size_t)pb.maxslots * 2 * B * F * K > pmax) pmax = (size_t)pb.maxslots * 2 * B * F * K;
+      if ((size_t)pa.maxslots * 2 * B * K * T > pmax) pmax = (size_t)pa.maxslots * 2 * B * K * T;
+    }
     if (K <= XFED_MAX_K) {
       // the X-fed halves have their own (larger) workgroup budget: a shorter range per workgroup means MORE workgroups
       // meet one block, hence more slabs than the map-fed partitions above (F = 1025, T = 660, n_basis = 10: 12

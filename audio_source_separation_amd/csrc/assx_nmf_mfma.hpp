@@ -164,6 +164,18 @@ __host__ __device__ inline unsigned nmf_part_lo(const NmfPart& p, int g) {
   }
   return (unsigned)g * ((unsigned)p.nblk * (unsigned)p.nstep) / (unsigned)p.G;
 }
+// range [lo, hi) of workgroup g (aligned: three divisions by w instead of the eight of lo(g), lo(g + 1) and two owners --
+// scalar division is a long dependent chain, and it sits in front of the first operand request of every workgroup)
+__host__ __device__ inline void nmf_part_range(const NmfPart& p, int g, unsigned& lo, unsigned& hi) {
+  if (p.w > 0) {
+    const unsigned blk = (unsigned)g / (unsigned)p.w, sl = (unsigned)g - blk * (unsigned)p.w;
+    lo = blk * (unsigned)p.nstep + sl * (unsigned)p.nstep / (unsigned)p.w;
+    hi = blk * (unsigned)p.nstep + (sl + 1u) * (unsigned)p.nstep / (unsigned)p.w;
+  } else {
+    lo = nmf_part_lo(p, g);
+    hi = nmf_part_lo(p, g + 1);
+  }
+}
 // the workgroup whose range holds step x (inverse of nmf_part_lo)
 __host__ __device__ inline int nmf_part_owner(const NmfPart& p, unsigned x) {
   if (p.w > 0) {
@@ -375,7 +387,7 @@ __global__ void __launch_bounds__(256)
   // The V tile (KP x 16 frames) of a sub-tile is read in two layouts -- as A operand of (1) and as B operand of (3).
   // Each wave stages it once through its private LDS slice with coalesced 128-byte row reads.  At the end of a block
   // the same memory carries the cross-wave combine.
-  constexpr int VT_ELEMS = 4 * KP * LD, RED_ELEMS = 3 * KT * 8 * 64;
+  constexpr int VT_ELEMS = 4 * KP * LD, RED_ELEMS = 4 * KT * 8 * 64;
   __shared__ R smem[VT_ELEMS > RED_ELEMS ? VT_ELEMS : RED_ELEMS];
   __shared__ int s_last;
   // wave index as a scalar: loop counters, base pointers and the fast-path tests below then live on the scalar unit
@@ -416,54 +428,54 @@ __global__ void __launch_bounds__(256)
   auto block_tail = [&](int blk, int f0, int slot, int members, auto&& sums) {  // sums(c, r, n, d): one (c, r) pair of them
     R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * FK;
     const bool direct = apply && members == 1;
-    if (wv == 0) {
-      // Three straight-line forms of the output: in one loop body the `direct` path's read of Tb made the compiler wait
-      // for ALL memory operations before every LDS read of the next (c, r) -- the 8 record stores of a lane went out one
-      // round trip after the other (3.5 us of every workgroup's life, in-kernel stamps).
+    // Every wave puts out its share of the block -- accumulator register r = wave index, every column tile c -- instead of
+    // wave 0 all of it: the address arithmetic and the stores of a lone wave are one dependent chain (1.7 us in the
+    // stamps), four waves do a quarter each.  Three straight-line forms: in one loop body the `direct` path's read of Tb
+    // made the compiler wait for ALL memory operations between the record stores (3.5 us, round 4's form).
+    {
+      const int r = wv, fo = f0 + MM::crow(r, lane);
       if (direct) {
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
-            if (fo < F && kb < K) {
-              R n, d;
-              sums(c, r, n, d);
-              R* tp = Tb + (size_t)b * FK + (size_t)fo * K + kb;
-              *tp = nmf_apply<R, D2K>(*tp, n, d, eps, pe);
-            }
+        for (int c = 0; c < KT; ++c) {
+          const int kb = 16 * c + li;
+          if (fo < F && kb < K) {
+            R n, d;
+            sums(c, r, n, d);
+            R* tp = Tb + (size_t)b * FK + (size_t)fo * K + kb;
+            *tp = nmf_apply<R, D2K>(*tp, n, d, eps, pe);
           }
+        }
       } else if (apply) {
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
-            if (fo < F && kb < K) {
-              R n, d;
-              sums(c, r, n, d);
-              const size_t o = (size_t)fo * K + kb;
-              st_agent(pn + o, n);
-              st_agent(pn + FK + o, d);
-            }
+        for (int c = 0; c < KT; ++c) {
+          const int kb = 16 * c + li;
+          if (fo < F && kb < K) {
+            R n, d;
+            sums(c, r, n, d);
+            const size_t o = (size_t)fo * K + kb;
+            st_agent(pn + o, n);
+            st_agent(pn + FK + o, d);
           }
+        }
       } else {
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kb = 16 * c + li, fo = f0 + MM::crow(r, lane);
-            if (fo < F && kb < K) {
-              R n, d;
-              sums(c, r, n, d);
-              const size_t o = (size_t)fo * K + kb;
-              pn[o] = n;
-              pn[FK + o] = d;
-            }
+        for (int c = 0; c < KT; ++c) {
+          const int kb = 16 * c + li;
+          if (fo < F && kb < K) {
+            R n, d;
+            sums(c, r, n, d);
+            const size_t o = (size_t)fo * K + kb;
+            pn[o] = n;
+            pn[FK + o] = d;
           }
+        }
       }
-      NMF_STAMP(6);
-      if (apply && !direct) {
+    }
+    NMF_STAMP(6);
+    if (apply && !direct) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's records are out ...
+      __syncthreads();                                   // ... and so are the other waves'
+      if (wv == 0) {
         const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
         if (lane == 0) s_last = last;
       }
@@ -547,13 +559,15 @@ __global__ void __launch_bounds__(256)
     return;
   }
 
-  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  unsigned lo, hi;
+  nmf_part_range(pt, g, lo, hi);
   NMF_STAMP(11);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
     const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
     const int s0 = lo > base ? (int)(lo - base) : 0;
     const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
-    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int gf = pt.w > 0 ? blk * pt.w : nmf_part_owner(pt, base);  // aligned: the block's w workgroups
+    const int members = pt.w > 0 ? pt.w : nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
     const int slot = g - gf;
     const int f0 = blk * 16;
     const int f = min(f0 + li, F - 1);  // rows past F feed only output rows that are never written
@@ -671,23 +685,20 @@ __global__ void __launch_bounds__(256)
       ltot += lacc - ((double)le * 0.6931471805599453 + log(lm));
     // ---- end of the block's share of this workgroup: the 4 waves in ascending order (wave 0 holds the total)
     __syncthreads();  // every wave is done with its staging slice: the memory now carries the combine
-    if (wv > 0) {
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
+    for (int c = 0; c < KT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[c][r];
-          red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[c][r];
-        }
-    }
+      for (int r = 0; r < 4; ++r) {
+        red[wv][(c * 2 + 0) * 4 + r][lane] = num[c][r];
+        red[wv][(c * 2 + 1) * 4 + r][lane] = den[c][r];
+      }
     __syncthreads();
     NMF_STAMP(5);
-    NMF_STAMP(10);
-    block_tail(blk, f0, slot, members, [&](int c, int r, R& n, R& d) {  // wave 0: its own sums + the other waves'
-      n = num[c][r];
-      d = den[c][r];
+    block_tail(blk, f0, slot, members, [&](int c, int r, R& n, R& d) {  // the four waves' sums, wave 0 first (as ever)
+      n = red[0][(c * 2 + 0) * 4 + r][lane];
+      d = red[0][(c * 2 + 1) * 4 + r][lane];
 #pragma unroll
-      for (int w = 0; w < 3; ++w) {
+      for (int w = 1; w < 4; ++w) {
         n += red[w][(c * 2 + 0) * 4 + r][lane];
         d += red[w][(c * 2 + 1) * 4 + r][lane];
       }
@@ -720,7 +731,7 @@ __global__ void __launch_bounds__(256)
   constexpr int KP = KT * 16;
   constexpr int LD = KP + 4;          // padded row of the staged 16 x KP basis tile
   constexpr int NLD = KP * 16 / 64;   // staged elements per lane and sub-tile
-  constexpr int TT_ELEMS = 4 * 16 * LD, RED_ELEMS = 3 * KT * 8 * 64;
+  constexpr int TT_ELEMS = 4 * 16 * LD, RED_ELEMS = 4 * KT * 8 * 64;
   __shared__ R smem[TT_ELEMS > RED_ELEMS ? TT_ELEMS : RED_ELEMS];  // wave-private basis tiles, then the combine
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -745,12 +756,14 @@ __global__ void __launch_bounds__(256)
   const unsigned tstep = (unsigned)(64 / KP) * (unsigned)K * (unsigned)sizeof(R);
   const BufRsrc trs = make_rsrc(tbb), xrs = make_rsrc(xb);  // buffer addressing, as in the basis half
 
-  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  unsigned lo, hi;
+  nmf_part_range(pt, g, lo, hi);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
     const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
     const int s0 = lo > base ? (int)(lo - base) : 0;
     const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
-    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int gf = pt.w > 0 ? blk * pt.w : nmf_part_owner(pt, base);  // aligned: the block's w workgroups
+    const int members = pt.w > 0 ? pt.w : nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
     const int slot = g - gf;
     const int t0 = blk * 16;
     const int t = min(t0 + li, T - 1);  // columns past T feed only output columns that are never written
@@ -840,74 +853,71 @@ __global__ void __launch_bounds__(256)
     for (; f0 + 16 <= fe; f0 += 64) step(IntC<0>(), f0);  // whole sub-tiles; the ragged one (at most) after the loop
     if (f0 < fe) step(IntC<1>(), f0);
 
-    // ---- end of the block's share of this workgroup: the 4 waves in ascending order
+    // ---- end of the block's share of this workgroup: the 4 waves' sums in ascending order, every wave puts out its
+    // quarter of the block (accumulator register r = wave index; see the basis half)
     __syncthreads();
-    if (wv > 0) {
 #pragma unroll
-      for (int c = 0; c < KT; ++c)
+    for (int c = 0; c < KT; ++c)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          red[wv - 1][(c * 2 + 0) * 4 + r][lane] = num[c][r];
-          red[wv - 1][(c * 2 + 1) * 4 + r][lane] = den[c][r];
-        }
-    }
+      for (int r = 0; r < 4; ++r) {
+        red[wv][(c * 2 + 0) * 4 + r][lane] = num[c][r];
+        red[wv][(c * 2 + 1) * 4 + r][lane] = den[c][r];
+      }
     __syncthreads();
     R* pn = part + ((size_t)slot * B * 2 + (size_t)b * 2) * KTt;
     const bool direct = apply && members == 1;
-    if (wv == 0) {
-      // three straight-line forms of the output, as in the basis half (no wait between the record stores)
-      auto sums = [&](int c, int r, R& n, R& d) {  // wave 0: its own sums + the other waves'
-        n = num[c][r];
-        d = den[c][r];
+    {
+      const int r = wv;
+      auto sums = [&](int c, R& n, R& d) {
+        n = red[0][(c * 2 + 0) * 4 + r][lane];
+        d = red[0][(c * 2 + 1) * 4 + r][lane];
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {
+        for (int w = 1; w < 4; ++w) {
           n += red[w][(c * 2 + 0) * 4 + r][lane];
           d += red[w][(c * 2 + 1) * 4 + r][lane];
         }
       };
       if (direct) {
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
-            if (kb < K && tvalid) {
-              R n, d;
-              sums(c, r, n, d);
-              R* vp = V + (size_t)b * KTt + (size_t)kb * T + t;
-              *vp = nmf_apply<R, D2K>(*vp, n, d, eps, pe);
-            }
+        for (int c = 0; c < KT; ++c) {
+          const int kb = 16 * c + MM::crow(r, lane);  // D[row = kb][col = t]
+          if (kb < K && tvalid) {
+            R n, d;
+            sums(c, n, d);
+            R* vp = V + (size_t)b * KTt + (size_t)kb * T + t;
+            *vp = nmf_apply<R, D2K>(*vp, n, d, eps, pe);
           }
+        }
       } else if (apply) {
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kb = 16 * c + MM::crow(r, lane);
-            if (kb < K && tvalid) {
-              R n, d;
-              sums(c, r, n, d);
-              const size_t o = (size_t)kb * T + t;
-              st_agent(pn + o, n);
-              st_agent(pn + KTt + o, d);
-            }
+        for (int c = 0; c < KT; ++c) {
+          const int kb = 16 * c + MM::crow(r, lane);
+          if (kb < K && tvalid) {
+            R n, d;
+            sums(c, n, d);
+            const size_t o = (size_t)kb * T + t;
+            st_agent(pn + o, n);
+            st_agent(pn + KTt + o, d);
           }
+        }
       } else {
 #pragma unroll
-        for (int c = 0; c < KT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int kb = 16 * c + MM::crow(r, lane);
-            if (kb < K && tvalid) {
-              R n, d;
-              sums(c, r, n, d);
-              const size_t o = (size_t)kb * T + t;
-              pn[o] = n;
-              pn[KTt + o] = d;
-            }
+        for (int c = 0; c < KT; ++c) {
+          const int kb = 16 * c + MM::crow(r, lane);
+          if (kb < K && tvalid) {
+            R n, d;
+            sums(c, n, d);
+            const size_t o = (size_t)kb * T + t;
+            pn[o] = n;
+            pn[KTt + o] = d;
           }
+        }
       }
-      if (apply && !direct) {
+    }
+    if (apply && !direct) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's records are out ...
+      __syncthreads();                                   // ... and so are the other waves'
+      if (wv == 0) {
         const bool last = take_ticket(tickets + (size_t)b * pt.nblk + blk, members);
         if (lane == 0) s_last = last;
       }

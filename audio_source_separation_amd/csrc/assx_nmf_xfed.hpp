@@ -64,12 +64,14 @@ __global__ void __launch_bounds__(64 * M)
 
   double ltot = 0.0;  // LOSS: this wave's share, summed over the blocks of its range
 
-  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  unsigned lo, hi;
+  nmf_part_range(pt, g, lo, hi);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
     const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
     const int s0 = lo > base ? (int)(lo - base) : 0;
     const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
-    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int gf = pt.w > 0 ? blk * pt.w : nmf_part_owner(pt, base);  // aligned: the block's w workgroups
+    const int members = pt.w > 0 ? pt.w : nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
     const int slot = g - gf;
     const int f0 = blk * 16;
     const int f = min(f0 + li, F - 1);  // rows past F feed only output rows that are never written
@@ -282,12 +284,14 @@ __global__ void __launch_bounds__(64 * M)
   const unsigned xrow4 = 4u * (unsigned)T * (unsigned)sizeof(Cx<R>);
   const BufRsrc trs = make_rsrc(tbb), xrs = make_rsrc(xm);
 
-  const unsigned lo = nmf_part_lo(pt, g), hi = nmf_part_lo(pt, g + 1);
+  unsigned lo, hi;
+  nmf_part_range(pt, g, lo, hi);
   for (int blk = (int)(lo / (unsigned)pt.nstep); (unsigned)blk * (unsigned)pt.nstep < hi; ++blk) {
     const unsigned base = (unsigned)blk * (unsigned)pt.nstep;
     const int s0 = lo > base ? (int)(lo - base) : 0;
     const int s1 = hi - base < (unsigned)pt.nstep ? (int)(hi - base) : pt.nstep;
-    const int gf = nmf_part_owner(pt, base), members = nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
+    const int gf = pt.w > 0 ? blk * pt.w : nmf_part_owner(pt, base);  // aligned: the block's w workgroups
+    const int members = pt.w > 0 ? pt.w : nmf_part_owner(pt, base + pt.nstep - 1) - gf + 1;
     const int slot = g - gf;
     const int t0 = blk * 16;
     const int t = min(t0 + li, T - 1);

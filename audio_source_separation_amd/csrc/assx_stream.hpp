@@ -343,6 +343,16 @@ struct CovArgs {
 // and 8 weight inputs per lane instead of 64 and 16, which is what lets the TV-weighted f64 kernel keep 2 waves
 // per SIMD without spilling.  The unit of the flat partition is a block of FB = 64 / LS frames.
 // Latency is covered by the DXT-deep X prefetch ring (and a DWT-deep ring of the weight inputs), not by occupancy.
+#ifndef STREAM_TRACE
+#define STREAM_TRACE 0  // 1: entry / first block / exit of every workgroup of cov_stream_kernel on the 100 MHz clock (tools/probes/stream_trace.py)
+#endif
+#if STREAM_TRACE && !defined(ASSX_PROBE_BUILD)
+#error "STREAM_TRACE adds a debug entry point and stamps: build it with -DASSX_PROBE_BUILD into a probe library, never into libassx.so"
+#endif
+#if STREAM_TRACE
+__device__ unsigned long long g_stream_trace[8 * 4096];
+#endif
+
 template <typename R, int M, int WK, bool K4, bool D2, int LS, int DXT, int DWT, int MINW = 1, bool VDMA = false>
 __global__ void __launch_bounds__(64, MINW)
     cov_stream_kernel(const Cx<R>* __restrict__ X, const R* __restrict__ rw /* WK_NT (B,N,T) | WK_NFT (B,N,F,T) */,
@@ -371,6 +381,15 @@ __global__ void __launch_bounds__(64, MINW)
   Cursor cc;                             // consume cursor
   int nblk;
   if (!flat_start(a.fp, g, cc.b, cc.f, cc.tb, nblk)) return;
+#if STREAM_TRACE
+  if (lane == 0 && g < 4096) {
+    g_stream_trace[8 * g + 0] = __builtin_amdgcn_s_memrealtime();
+    g_stream_trace[8 * g + 2] = (unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf) | ((unsigned long long)nblk << 8) |
+                                ((unsigned long long)blockIdx.x << 32);
+    g_stream_trace[8 * g + 4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  // HW_ID
+    g_stream_trace[8 * g + 5] = __builtin_readcyclecounter();
+  }
+#endif
   const int bf_first = cc.b * F + cc.f;
   Cursor px = cc, pw = cc;               // prefetch cursors (X ring, weight ring)
   const bool ragged = (T % FB) != 0;     // only then can a lane fall beyond the last frame
@@ -636,6 +655,9 @@ __global__ void __launch_bounds__(64, MINW)
     static_for<DXT>([&](auto jc) { block(jc, IntC<2>(), decltype(jc)::value); });
     it0 = DXT;
   }
+#if STREAM_TRACE
+  if (lane == 0 && g < 4096) g_stream_trace[8 * g + 3] = __builtin_amdgcn_s_memrealtime();
+#endif
   for (; it0 + 2 * DXT <= nblk; it0 += DXT)
     static_for<DXT>([&](auto jc) { block(jc, IntC<1>(), it0 + decltype(jc)::value); });
   // drain: the last blocks, refills guarded
@@ -643,6 +665,13 @@ __global__ void __launch_bounds__(64, MINW)
     static_for<DXT>([&](auto jc) {
       if (it0 + decltype(jc)::value < nblk) block(jc, IntC<0>(), it0 + decltype(jc)::value);
     });
+#if STREAM_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0 && g < 4096) {
+    g_stream_trace[8 * g + 1] = __builtin_amdgcn_s_memrealtime();
+    g_stream_trace[8 * g + 6] = __builtin_readcyclecounter();
+  }
+#endif
 }
 
 // sum the records covering each bin, scale by 1/T, expand packed Hermitian -> dense U (B,N,F,M,M)

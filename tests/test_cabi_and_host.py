@@ -69,7 +69,7 @@ def test_nmf_slab_area_holds_every_partition():
                     continue
                 for half in (0, 1):
                     for dtype in (_lib.F64, _lib.F32):
-                        for group in ((1,) if feed else (1, 4)):
+                        for group in ((1,) if feed else (1, 2, 4, 8)):
                             g, nblk, nstep, bound, worst, room = _partition_query(feed, half, group, F, T, K, dtype)
                             if not (1 <= worst <= bound <= room and g >= 1):
                                 bad.append((feed, half, group, F, T, K, dtype, worst, bound, room))
