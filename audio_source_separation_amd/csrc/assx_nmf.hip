@@ -319,9 +319,6 @@ inline int nmf_env_int(const char* name, int dflt) {
   return (v && *v) ? atoi(v) : dflt;
 }
 
-// extra dynamic LDS per workgroup of the matrix-core halves (bytes): occupancy experiments
-inline unsigned nmf_lds_pad() { return (unsigned)nmf_env_int("ASSX_NMF_LDS_PAD", 0); }
-
 // split counts of the MFMA path (deterministic: no device query)
 inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ? ctx->nmf_group : 1; }
 
@@ -332,8 +329,7 @@ inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ?
 constexpr int MFMA_WG_BUDGET = 512;  // two workgroups per CU (profiles/r04_nmf_wgs_sweep.txt)
 template <typename R>
 inline NmfPart mfma_basis_part(int group, int F, int T, int KT) {
-  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET),
-                       KT <= NMF_RAG_MAX_KT ? F % 16 : 0);
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET));
 }
 template <typename R>
 inline NmfPart mfma_act_part(int group, int F, int T, int KT) {
@@ -458,13 +454,13 @@ int nmf_update_mfma(assx_ctx* ctx, int kind, double domain, double param, double
   if (trc) return trc;  // the hipError_t of the allocation, message in ctx
   const bool d2 = domain == 2.0 && kind < ASSX_NMF_T;  // every exponent is 0, 1 or 2: pow()-free instantiations
 #define NMF_BASIS(D2K)                                                                                         \
-  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), nmf_lds_pad(), st, (const R*)X,      \
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X,      \
                      (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe, (double*)nullptr, 0, 0.0)
 #define NMF_BASIS_LOSS(D2K)                                                                                    \
-  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K, true>), dim3(pb.G, 1, B), dim3(256), nmf_lds_pad(), st, (const R*)X, \
+  hipLaunchKernelGGL((nmf_basis_mfma_kernel<R, KT, D2K, true>), dim3(pb.G, 1, B), dim3(256), 0, st, (const R*)X, \
                      (R*)Tb, (const R*)V, part, tickets, 1, pb, B, F, T, K, (R)eps, ts, pe, lpart, 4 * pb.G, eps)
 #define NMF_ACT(D2K)                                                                                           \
-  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pa.G, 1, B), dim3(256), nmf_lds_pad(), st, (const R*)X,         \
+  hipLaunchKernelGGL((nmf_act_mfma_kernel<R, KT, D2K>), dim3(pa.G, 1, B), dim3(256), 0, st, (const R*)X,         \
                      (const R*)Tb, (R*)V, part, tickets, 1, pa, B, F, T, K, (R)eps, ts, pe)
   if (loss_prev && !d2) return fail(ctx, ASSX_E_UNSUPPORTED, "nmf_update_mfma: the fused loss needs domain 2 and EUC / KL / IS");
   if (loss_prev) {
@@ -808,8 +804,8 @@ int assx_nmf_partition_query(int feed, int half, int group, int F, int T, int K,
   else p = half == 0 ? mfma_basis_part<float>(group, F, T, KT) : mfma_act_part<float>(group, F, T, KT);
   // workgroup g owns steps [lo(g), lo(g + 1)) of the flattened (block, step) space and writes slab g - (first workgroup
   // of the block) for every block its range meets
-  int worst = p.rag ? p.rag_w : 0;  // the ragged last block has rag_w members (vector-ALU workgroups past the partition)
-  for (int blk = 0; blk < p.nblk - (p.rag ? 1 : 0); ++blk) {
+  int worst = 0;
+  for (int blk = 0; blk < p.nblk; ++blk) {
     const unsigned first = (unsigned)blk * (unsigned)p.nstep, last = first + (unsigned)p.nstep - 1u;
     const int n = nmf_part_owner(p, last) - nmf_part_owner(p, first) + 1;
     if (n > worst) worst = n;

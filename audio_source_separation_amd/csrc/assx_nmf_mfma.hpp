@@ -141,16 +141,7 @@ __device__ __forceinline__ R nmf_apply(R old, R num, R den, R eps, PowSpec p) {
 struct NmfPart {
   int nblk, nstep, G, maxslots;
   int w;  // > 0: block-aligned partition, w workgroups per block; 0: the flat partition of round 4
-  // Ragged last block on the vector ALU (basis halves, aligned partition only).  F = 2^n + 1 bins leave ONE valid row in
-  // the last 16-row block: as a matrix-core block it costs what a full one costs (config 2: 65 blocks for 64.06 blocks
-  // of work, and 65 x 8 workgroups do not fit the 512 resident ones).  With rag > 0 the matrix-core partition covers
-  // the nblk - 1 full blocks with Gf = (nblk - 1) w workgroups, and rag_w more workgroups (g >= Gf) take a slice of the
-  // frames each for the `rag` bins of block nblk - 1: a few multiply-adds per element on the vector ALU.  Same records,
-  // tickets and finalize as any block (members = rag_w).
-  int Gf, rag, rag_w;
 };
-constexpr int NMF_RAG_MAX = 2;  // more valid rows than this: the last block stays a matrix-core block
-constexpr int NMF_RAG_MAX_KT = 2;  // n_basis > 32: the kernels have no registers to spare for the side path (host: no rag)
 // Block-aligned since round 5: in-kernel stamps of config 2 showed the workgroups whose flat range crossed a block
 // boundary (64 of 512) paying two block prologues (cold operand loads, ~3 us) and two epilogues (combine, records,
 // ticket, ~5 us): they left 8 us after the median workgroup, and they are the last members of their blocks, so every
@@ -184,50 +175,32 @@ __host__ __device__ inline int nmf_part_owner(const NmfPart& p, unsigned x) {
   }
   return (int)(((x + 1u) * (unsigned)p.G - 1u) / ((unsigned)p.nblk * (unsigned)p.nstep));
 }
-inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs, int rag_rows = 0) {
+inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
   NmfPart p;
   p.nblk = nblk;
   p.nstep = nstep;
-  p.rag = 0;
-  p.rag_w = 0;
   const long long wt = (long long)nblk * nstep;
   long long G = target_wgs / (group < 1 ? 1 : group);
   static const int aligned = [] {
     const char* v = getenv("ASSX_NMF_ALIGNED");  // 0: round 4's flat partition (A/B runs)
     return (v && *v) ? atoi(v) : 1;
   }();
-  static const int rag_on = [] {
-    const char* v = getenv("ASSX_NMF_RAGGED");  // 0: the last block is always a matrix-core block
-    return (v && *v) ? atoi(v) : 0;
-  }();
   // Aligned only where a block gets at least two workgroups: with fewer the flat partition wastes nothing (a range is
   // then whole blocks plus one boundary) and keeps G inside the budget -- one workgroup per block would launch nblk of
   // them, a few more than fit at once when nblk is just above the budget (wide-channel source model: 65 blocks x 8
   // matrices against 512: the 8 late workgroups were the tail of the kernel).
   if (aligned && G / nblk >= 2) {
-    const bool rag = rag_on && rag_rows > 0 && rag_rows <= NMF_RAG_MAX && nblk >= 2;
-    if (rag) --nblk;                       // the matrix-core partition covers the full blocks
     long long w = G / nblk;                // never more workgroups than the budget ...
     if (w > 16) w = 16;                    // ... at most 16 slabs for the holder of the last ticket to sum
     if (w > nstep / 4) w = nstep / 4;      // every wave gets a step
     if (w < 1) w = 1;                      // more blocks than budget: one workgroup per block, several rounds
     while (w > 1 && (wt + 1) * (nblk * w) >= (1ll << 32)) --w;
     p.w = (int)w;
-    p.Gf = (int)(nblk * w);
-    p.G = p.Gf;
+    p.G = (int)(nblk * w);
     p.maxslots = (int)w;
-    if (rag) {
-      p.rag = rag_rows;
-      long long rw = ((long long)nstep * 16 + 511) / 512;  // >= 512 frames per ragged workgroup
-      if (rw > w) rw = w;
-      if (rw < 1) rw = 1;
-      p.rag_w = (int)rw;
-      p.G = p.Gf + p.rag_w;
-    }
     return p;
   }
   p.w = 0;
-  p.Gf = 0;
   if (G > (long long)nblk * 16) G = (long long)nblk * 16;  // at most ~16 slabs for the holder of the last ticket to sum
   if (G > wt / 4) G = wt / 4;  // every wave gets a step (a 513 x 256 matrix: 132 workgroups of one step per wave; one
                                // workgroup per block with 4 steps per wave and no tickets at all measured slower)
@@ -235,15 +208,11 @@ inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs, int
   while (G > 1 && (wt + 1) * G >= (1ll << 32)) G /= 2;  // 32-bit partition arithmetic in the kernels
   if (G < 1) G = 1;
   p.G = (int)G;
-  p.Gf = p.G;
   const long long per = wt / G;  // shortest range
   p.maxslots = (int)((nstep + per - 1) / per) + 1;
   return p;
 }
 
-#ifndef NMF_FIN_NO1
-#define NMF_FIN_NO1 0
-#endif
 #ifndef NMF_TRACE
 #define NMF_TRACE 0  // 1: shader-clock stamps of the basis half (tools/probes/nmf_trace.py): every workgroup's entry / exit on the
                      // 100 MHz clock, every step of the waves of workgroup NMF_TRACE_WG on the shader clock
@@ -269,105 +238,6 @@ __device__ unsigned long long g_nmf_trace[8192 + 4 * 512];
 // basis half: num|den (F,K) = [A|Bm] (F,T) . V^T.   grid (G, 1, B), 4 waves; block = 16 bins, step = 16 frames.
 //   part[slab][b*2 + s][f*K + k]
 // ---------------------------------------------------------------------------------------------------------
-// The ragged rows of the last block on the vector ALU (NmfPart::rag): workgroup `r` of `rw` takes the frames
-// [r, r + 1) * ceil(T / rw) of the `nb` bins f0 .. f0 + nb - 1 of one matrix.  Per 256 frames: (1) a thread per frame
-// forms T V (k ascending), the two terms and -- LOSS -- the criterion, (2) wave v sums a V^T / bm V^T for k = v, v + 4,
-// ..., lanes over the frames; the waves' lanes are combined by a fixed butterfly at the end.  Results go to
-// res[(s * nb + j) * K + k] (s = 0 numerator, 1 denominator) in LDS; `as`, `bs` hold the 256 terms of a trip.
-template <typename R, int KP, int D2K, bool LOSS>
-__device__ __forceinline__ void nmf_basis_ragged(const R* __restrict__ xb, const R* tbb, const R* __restrict__ vb, R* as,
-                                                 R* bs, R* res, int r, int rw, int f0, int nb, int T, int K, R eps,
-                                                 const TermSpec& s, double leps, double& ltot) {
-  constexpr int KK = KP / 4;  // k's per wave
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int chunk = (T + rw - 1) / rw, ta = r * chunk, te = min(T, ta + chunk);
-  R* tbs = res + 2 * NMF_RAG_MAX * KP;  // the bin's basis row, zero-padded to KP
-  for (int j = 0; j < nb; ++j) {
-    const int f = f0 + j;
-    const R* xr = xb + (size_t)f * T;
-    __syncthreads();  // the previous bin's row has been consumed
-    if ((int)threadIdx.x < KP) tbs[threadIdx.x] = ((int)threadIdx.x < K) ? tbb[(size_t)f * K + threadIdx.x] : (R)0;
-    R pn[KK], pd[KK];
-#pragma unroll
-    for (int q = 0; q < KK; ++q) {
-      pn[q] = 0;
-      pd[q] = 0;
-    }
-    double lacc = 0.0, lm = 1.0;
-    int le = 0;
-    for (int tc = ta; tc < te; tc += 256) {
-      const int t = min(tc + (int)threadIdx.x, te - 1);  // threads past the range repeat its last frame and drop out below
-      const bool live = tc + (int)threadIdx.x < te;
-      const R x = xr[t];
-      __syncthreads();  // the row is in place; the previous trip's terms have been consumed
-      R tv = 0;
-#pragma unroll
-      for (int k0 = 0; k0 < KP; k0 += 16) {  // 16 loads in flight (a loop with a run-time bound made it one round trip per k)
-        R vv[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) vv[q] = vb[(size_t)min(k0 + q, K - 1) * T + t];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) tv = fma(tbs[k0 + q], vv[q], tv);  // rows past K meet zeros
-      }
-      R a, bm;
-      nmf_terms<R, D2K>(s, x, tv, eps, a, bm);
-      if (LOSS && live) {  // criterion((Tb V)^(2/2), x): Tb V as the product gave it, NOT floored (as in the matrix-core blocks)
-        const double in = (double)tv, xx = (double)x;
-        if (D2K == ASSX_NMF_EUC) {
-          lacc = fma(xx - in, xx - in, lacc);
-        } else {
-          const double in_ = in + leps, tg_ = xx + leps;
-          const double ratio = tg_ * fast_rcp(in_);
-          if (D2K == ASSX_NMF_KL) {
-            lacc += tg_ * log(ratio) + in_ - tg_;
-          } else {
-            int e;
-            lacc += ratio - 1.0;
-            lm = frexp(lm * ratio, &e);
-            le += e;
-          }
-        }
-      }
-      as[threadIdx.x] = live ? a : (R)0;
-      bs[threadIdx.x] = live ? bm : (R)0;
-      __syncthreads();
-      R au[4], bu[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        au[u] = as[lane + 64 * u];
-        bu[u] = bs[lane + 64 * u];
-      }
-#pragma unroll
-      for (int q0 = 0; q0 < KK; q0 += 4) {  // 16 loads in flight
-        R vq[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int u = 0; u < 4; ++u)  // rows past K repeat row K - 1 and are never written; frames past the range meet zeros
-            vq[q][u] = vb[(size_t)min(wv + 4 * (q0 + q), K - 1) * T + min(tc + lane + 64 * u, te - 1)];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            pn[q0 + q] = fma(au[u], vq[q][u], pn[q0 + q]);
-            pd[q0 + q] = fma(bu[u], vq[q][u], pd[q0 + q]);
-          }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < KK; ++q) {
-      const R n = wave_allreduce_sum<R>(pn[q]), d = wave_allreduce_sum<R>(pd[q]);
-      const int k = wv + 4 * q;
-      if (lane == 0 && k < K) {
-        res[(size_t)(0 * nb + j) * K + k] = n;
-        res[(size_t)(1 * nb + j) * K + k] = d;
-      }
-    }
-    if (LOSS) ltot += (D2K == ASSX_NMF_IS_MM) ? lacc - ((double)le * 0.6931471805599453 + log(lm)) : lacc;
-  }
-  __syncthreads();
-}
-
 // LOSS (domain 2, EUC / KL / IS: D2K >= 0): the half also accumulates criterion(Tb V, X) of the model it READS (nmf.py:
 // 170-174, 229-233, 288-292; divergence.py:21-45) -- the loss the reference records after the PREVIOUS update -- from the
 // very Tb V and X it holds, every (f, t) exactly once: one partial per (workgroup, wave) at lpart[b * lstride + 4 g + wave],
@@ -502,7 +372,7 @@ __global__ void __launch_bounds__(256)
         // ---- holder of the last ticket: sum the slabs of this 16 x K block and update Tb in place.  Every member
         // read its rows of Tb at the top of the block, i.e. before it took its ticket.
         // Two outputs per thread and trip, their four slab sums in flight together (slab_sum4_n).
-        constexpr int NO = (D2K < 0 || KT >= 3 || NMF_FIN_NO1) ? 1 : 2;  // the pow() / wide variants have no registers to spare for a second output
+        constexpr int NO = (D2K < 0 || KT >= 3) ? 1 : 2;  // the pow() / wide variants have no registers to spare for a second output
         const R* p0 = part + (size_t)b * 2 * FK;
         R* tbo = Tb + (size_t)b * FK;
         for (int o = threadIdx.x; o < 16 * K; o += 256 * NO) {
@@ -530,34 +400,6 @@ __global__ void __launch_bounds__(256)
     tr_fin += (apply && members > 1 && s_last) ? 1 : 0;
 #endif
   };
-
-  // ---- workgroups past the matrix-core partition: the ragged rows of the last block on the vector ALU (NmfPart::rag).
-  // Its own branch, before anything of the matrix-core path is live: as a side path of the block loop below it cost
-  // that loop a quarter of its registers.
-  if (KT <= NMF_RAG_MAX_KT && pt.rag > 0 && g >= pt.Gf) {
-    const int blk = pt.nblk - 1, f0 = blk * 16, slot = g - pt.Gf, members = pt.rag_w;
-    double lr = 0.0;
-    nmf_basis_ragged<R, KP, D2K, LOSS>(xb, Tb + (size_t)b * FK, vb, smem, smem + 256, smem + 512, slot, members, f0, pt.rag, T,
-                                       K, eps, s, (double)leps, lr);
-    block_tail(blk, f0, slot, members, [&](int c, int r, R& n, R& d) {  // the ragged rows' sums, in the layout the tail expects
-      const int j = MM::crow(r, lane), kb = 16 * c + li;
-      const bool in = j < pt.rag && kb < K;
-      n = in ? smem[512 + (size_t)(0 * pt.rag + j) * K + kb] : (R)0;
-      d = in ? smem[512 + (size_t)(1 * pt.rag + j) * K + kb] : (R)0;
-    });
-    if (LOSS) {
-      lr = wave_allreduce_sum<double>(lr);  // every thread's own elements
-      if (lane == 0) lpart[(size_t)b * lstride + (size_t)g * 4 + wv] = lr;
-    }
-#if NMF_TRACE
-    if (b == 0 && threadIdx.x == 0 && g < 1024) {
-      g_nmf_trace[8 * g + 1] = __builtin_amdgcn_s_memrealtime();
-      g_nmf_trace[8 * g + 3] = (unsigned long long)tr_fin;
-      g_nmf_trace[8 * g + 5] = __builtin_readcyclecounter();
-    }
-#endif
-    return;
-  }
 
   unsigned lo, hi;
   nmf_part_range(pt, g, lo, hi);
@@ -940,7 +782,7 @@ __global__ void __launch_bounds__(256)
         // its columns of V at the top of the block, before it took its ticket)
         const R* p0 = part + (size_t)b * 2 * KTt;
         R* vo = V + (size_t)b * KTt;
-        constexpr int NO = (D2K < 0 || KT >= 3 || NMF_FIN_NO1) ? 1 : 2;
+        constexpr int NO = (D2K < 0 || KT >= 3) ? 1 : 2;
         for (int o = threadIdx.x; o < 16 * K; o += 256 * NO) {
           unsigned idx[NO];
           bool on[NO];
