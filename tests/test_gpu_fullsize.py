@@ -78,6 +78,42 @@ def test_nmf_many_slabs_vs_oracle(nmf_many_slabs, dtype, kind, domain, K):
     np.testing.assert_allclose(got, orc.nmf_loss(kind, X, Tr, Vr, domain=domain), rtol=1e-10 if dtype == "float64" else 5e-4)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("F,T,K", [(530, 650, 10), (33, 4100, 32), (1025, 300, 16), (100, 100, 40)])
+@pytest.mark.parametrize("budget", [8, 40, 150, 512, 3000])
+def test_nmf_partition_forms_vs_oracle(dtype, F, T, K, budget, monkeypatch):
+    """The matrix-core halves under every form of their work partition (round 5): block-aligned with w = 1 ... 16
+    workgroups per block (w = 1: the direct update, no tickets), the flat fallback where a block would get fewer than two,
+    more blocks than the budget (several rounds of workgroups); a batch of two equals two single calls bit for bit (the
+    partition is a function of one matrix's geometry); the partition query agrees with what fits the workspace."""
+    import ctypes
+    from audio_source_separation_amd import _lib
+    from audio_source_separation_amd.ops import Engine
+    monkeypatch.setenv("ASSX_NMF_BASIS_WGS", str(budget))  # read on every call
+    monkeypatch.setenv("ASSX_NMF_ACT_WGS", str(budget))
+    eng = Engine(dtype)
+    out = (ctypes.c_int32 * 6)()
+    for half in (0, 1):
+        assert _lib.lib.assx_nmf_partition_query(0, half, 1, F, T, K, eng.prec.code, out) == 0
+        assert 1 <= out[4] <= out[3] <= out[5], list(out)
+    rng = np.random.default_rng(F + K + budget)
+    X = rng.random((2, F, T)) ** 2 + 1e-3
+    T0, V0 = rng.random((2, F, K)) + 0.05, rng.random((2, K, T)) + 0.05
+    Xd, Td, Vd = dev_r(eng, X), dev_r(eng, T0), dev_r(eng, V0)
+    for it in range(2):
+        eng.nmf_update(_lib.NMF_IS_MM, Xd, Td, Vd)
+    for b in range(2):
+        Tr, Vr = T0[b], V0[b]
+        for it in range(2):
+            Tr, Vr = orc.nmf_update_once("IS", X[b], Tr, Vr, domain=2)
+        tol = 2e-11 if dtype == "float64" else 4e-4
+        assert rel_err(host(Td)[b], Tr) < tol and rel_err(host(Vd)[b], Vr) < tol, (b, budget)
+        t1, v1 = dev_r(eng, T0[b:b + 1]), dev_r(eng, V0[b:b + 1])
+        for it in range(2):
+            eng.nmf_update(_lib.NMF_IS_MM, Xd[b:b + 1], t1, v1)
+        assert torch.equal(t1[0], Td[b]) and torch.equal(v1[0], Vd[b])
+
+
 # ------------------------------------------------------------------------------------------------ config 2
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_config2_isnmf_full_size_oracle_step(dtype):
