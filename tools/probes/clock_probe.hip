@@ -71,6 +71,22 @@ __global__ void __launch_bounds__(256) k_fma(double* out, Stamp* st, int iters) 
   out[blockIdx.x * blockDim.x + threadIdx.x] = (double)s;
   STAMP_OUT();
 }
+typedef float pk2_t __attribute__((ext_vector_type(2)));
+template <int CH>
+__global__ void __launch_bounds__(256) k_pkfma(double* out, Stamp* st, int iters) {  // v_pk_fma_f32: two multiply-adds per lane
+  STAMP_IN();
+  pk2_t c[CH];
+  for (int i = 0; i < CH; ++i) c[i] = pk2_t{(float)(i + threadIdx.x), (float)(i + 1)};
+  const pk2_t a = {1.0f + threadIdx.x * 1e-9f, 1.0f}, b = {1e-9f, 2e-9f};
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < CH; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(c[i]) : "v"(a), "v"(b));
+  }
+  float s = 0;
+  for (int i = 0; i < CH; ++i) s += c[i].x + c[i].y;
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (double)s;
+  STAMP_OUT();
+}
 __global__ void __launch_bounds__(256) k_sleep(double* out, Stamp* st, int iters) {
   STAMP_IN();
   for (int it = 0; it < iters; ++it) __builtin_amdgcn_s_sleep(64);
@@ -137,6 +153,10 @@ int main() {
   RUN("v_fma_f64", (k_fma<double, 8>), 8, 4, 100000, 128.0)
   RUN("v_fma_f32", (k_fma<float, 8>), 8, 2, 100000, 128.0)
   RUN("v_fma_f32", (k_fma<float, 8>), 8, 4, 100000, 128.0)
+  RUN("v_pk_fma_f32", (k_pkfma<8>), 8, 1, 100000, 256.0)
+  RUN("v_pk_fma_f32", (k_pkfma<8>), 8, 2, 100000, 256.0)
+  RUN("v_pk_fma_f32", (k_pkfma<8>), 8, 4, 100000, 256.0)
+  RUN("v_fma_f32", (k_fma<float, 8>), 8, 1, 100000, 128.0)
   RUN("v_mfma_f32_32x32x2", (k_mfma32<4>), 4, 2, 20000, 4096.0)
   RUN("s_sleep (idle chip)", k_sleep, 1, 1, 20000, 0.0)
   return 0;
