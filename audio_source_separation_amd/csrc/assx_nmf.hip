@@ -914,9 +914,17 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
     int FS, fchunk;
     mfma_loss_split(nmf_group(ctx), F, T, &FS, &fchunk);
     const dim3 g2((T + 15) / 16, FS, B);
-#define NMF_LOSS_LAUNCH(RT, KTV)                                                                                 \
-  hipLaunchKernelGGL((nmf_loss_mfma_kernel<RT, KTV>), g2, dim3(256), 0, st, (const RT*)X, (const RT*)Tb,          \
+    const bool d2 = domain == 2.0 && k2 <= ASSX_NMF_IS_MM;  // EUC / KL / IS at domain 2: the pow()- and (IS) log-free forms
+#define NMF_LOSS_LAUNCH_D(RT, KTV, D2KV)                                                                         \
+  hipLaunchKernelGGL((nmf_loss_mfma_kernel<RT, KTV, D2KV>), g2, dim3(256), 0, st, (const RT*)X, (const RT*)Tb,    \
                      (const RT*)V, lpart, F, T, K, fchunk, k2, eps, p2d, param)
+#define NMF_LOSS_LAUNCH(RT, KTV)                                         \
+  do {                                                                   \
+    if (!d2) NMF_LOSS_LAUNCH_D(RT, KTV, -1);                             \
+    else if (k2 == ASSX_NMF_EUC) NMF_LOSS_LAUNCH_D(RT, KTV, ASSX_NMF_EUC); \
+    else if (k2 == ASSX_NMF_KL) NMF_LOSS_LAUNCH_D(RT, KTV, ASSX_NMF_KL);   \
+    else NMF_LOSS_LAUNCH_D(RT, KTV, ASSX_NMF_IS_MM);                     \
+  } while (0)
 #define NMF_LOSS_BY_K(RT)                     \
   switch ((K + 15) / 16) {                    \
     case 1: NMF_LOSS_LAUNCH(RT, 1); break;    \
@@ -933,6 +941,7 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
     }
 #undef NMF_LOSS_BY_K
 #undef NMF_LOSS_LAUNCH
+#undef NMF_LOSS_LAUNCH_D
     ASSX_LAUNCH_CHECK(ctx, "nmf_loss_mfma_kernel");
     hipLaunchKernelGGL(sum_reduce_f64_kernel, dim3(B), dim3(256), 0, st, (const double*)lpart, loss,
                        (size_t)g2.x * g2.y);

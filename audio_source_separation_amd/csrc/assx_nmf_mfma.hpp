@@ -823,7 +823,10 @@ __device__ __forceinline__ double nmf_criterion(int kind, double in, double x, d
 //   Same tiling as the activation kernel (TV sub-tiles by MFMA, elementwise in the accumulator layout);
 //   one float64 partial per workgroup: lpart[b][blockIdx.y * gridDim.x + blockIdx.x]
 // ---------------------------------------------------------------------------------------------------------
-template <typename R, int KT>
+// D2K >= 0: domain 2 with the EUC / KL / IS criterion -- no pow(), and for IS no logarithm per element either: sum (ratio - 1)
+// and the product of the ratios (mantissa + exponent), as the criterion fused into the basis half does.  The operands of the
+// next 16 rows travel while the current ones are consumed (round 5: the kernel was load - wait - use per trip, 43 us at config 2).
+template <typename R, int KT, int D2K = -1>
 __global__ void __launch_bounds__(256)
     nmf_loss_mfma_kernel(const R* __restrict__ X, const R* __restrict__ Tb, const R* __restrict__ V,
                          double* __restrict__ lpart, int F, int T, int K, int fchunk, int kind, double eps,
@@ -848,31 +851,66 @@ __global__ void __launch_bounds__(256)
   }
   const int fa = fs * fchunk;
   const int fe = min(F, fa + fchunk);
-  double acc = 0.0;
-  for (int f0 = fa + 16 * wv; f0 < fe; f0 += 64) {
-    R xc[4];
+  double acc = 0.0, lm = 1.0;
+  int le = 0;
+  // rows past the matrix repeat its last row, basis columns past n_basis its last column (they meet zeros of vbr): no branches
+  auto fetch = [&](int f0, R(&xn)[4], R(&tn)[KS]) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) xc[r] = xb[(size_t)min(f0 + MM::crow(r, lane), F - 1) * T + t];
+    for (int r = 0; r < 4; ++r) xn[r] = xb[(size_t)min(f0 + MM::crow(r, lane), F - 1) * T + t];
+    const R* row = tbb + (size_t)min(f0 + li, F - 1) * K;
+#pragma unroll
+    for (int j = 0; j < KS; ++j) tn[j] = row[min(4 * j + lk, K - 1)];
+  };
+  R xc[4], ta[KS];
+  int f0 = fa + 16 * wv;
+  if (f0 < fe) fetch(f0, xc, ta);
+  for (; f0 < fe; f0 += 64) {
+    R xn[4], tn[KS];
+    const bool more = f0 + 64 < fe;  // wave-uniform
+    if (more) fetch(f0 + 64, xn, tn);
     acc_t tv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) tv[r] = 0;
-    const int fA = min(f0 + li, F - 1);
 #pragma unroll
-    for (int j = 0; j < KS; ++j) {
-      if (4 * j >= K) break;  // all-padding k-slice
-      const int k = 4 * j + lk;
-      const R ta = (k < K) ? tbb[(size_t)fA * K + k] : (R)0;
-      tv = MM::mma(ta, vbr[j], tv);
-    }
+    for (int j = 0; j < KS; ++j) tv = MM::mma(ta[j], vbr[j], tv);
+    double lprod = 1.0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int fr = f0 + MM::crow(r, lane);
-      if (tvalid && fr < fe) {
-        const double in = (double)powspec<R>(tv[r], p2d);  // (T V) ** (2 / domain), not floored
-        acc += nmf_criterion(kind, in, (double)xc[r], eps, p0);
+      const bool live = tvalid && f0 + MM::crow(r, lane) < fe;
+      if (D2K < 0) {
+        if (live) {
+          const double in = (double)powspec<R>(tv[r], p2d);  // (T V) ** (2 / domain), not floored
+          acc += nmf_criterion(kind, in, (double)xc[r], eps, p0);
+        }
+      } else {
+        const double in = (double)tv[r], xx = (double)xc[r];
+        if (D2K == ASSX_NMF_EUC) {
+          if (live) acc = fma(xx - in, xx - in, acc);
+        } else {
+          const double in_ = in + eps, tg_ = xx + eps;  // divergence.py:26-27, 39-40
+          const double ratio = live ? tg_ * fast_rcp(in_) : 1.0;
+          if (D2K == ASSX_NMF_KL) {
+            if (live) acc += tg_ * log(ratio) + in_ - tg_;
+          } else {
+            acc += ratio - 1.0;
+            lprod *= ratio;
+          }
+        }
       }
     }
+    if (D2K == ASSX_NMF_IS_MM) {
+      int e;
+      lm = frexp(lm * lprod, &e);
+      le += e;
+    }
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xc[r] = xn[r];
+#pragma unroll
+      for (int j = 0; j < KS; ++j) ta[j] = tn[j];
+    }
   }
+  if (D2K == ASSX_NMF_IS_MM) acc -= (double)le * 0.6931471805599453 + log(lm);
   acc = wave_allreduce_sum<double>(acc);
   if (lane == 0) red[wv] = acc;
   __syncthreads();
