@@ -49,6 +49,7 @@ __global__ void __launch_bounds__(64 * M)
   const int lane = threadIdx.x & 63, n = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave = source = channel fetched
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.z, g = blockIdx.x;
+  const bool last_slice = K > 4 * (KS - 1);  // the last k-slice of product (1) holds a basis vector (wave-uniform)
   const size_t bn = (size_t)b * N + n, BN = (size_t)B * N;
   R(*vt)[LD] = reinterpret_cast<R(*)[LD]>(vts + n * KP * LD);
   const R* vb = V + bn * K * T;
@@ -124,7 +125,8 @@ __global__ void __launch_bounds__(64 * M)
 #pragma unroll
       for (int r = 0; r < 4; ++r) tv[r] = 0;
 #pragma unroll
-      for (int j = 0; j < KS; ++j) tv = MM::mma(vt[4 * j + lk][li], tb[j], tv);
+      for (int j = 0; j < KS; ++j)
+        if (j < KS - 1 || last_slice) tv = MM::mma(vt[4 * j + lk][li], tb[j], tv);  // n_basis 9..12 (the reference's 10): 3 of 4 slices
       R a[4], bm[4];
       double lprod = 1.0;
 #pragma unroll
@@ -266,6 +268,7 @@ __global__ void __launch_bounds__(64 * M)
   const int lane = threadIdx.x & 63, n = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lk = lane >> 4;
   const int b = blockIdx.z, g = blockIdx.x;
+  const bool last_slice = K > 4 * (KS - 1);  // the last k-slice of product (1) holds a basis vector (wave-uniform)
   const size_t bn = (size_t)b * N + n, BN = (size_t)B * N;
   R(*tt_)[LD] = reinterpret_cast<R(*)[LD]>(tts + n * 16 * LD);
   const R* tbb = Tb + bn * F * K;
@@ -347,7 +350,8 @@ __global__ void __launch_bounds__(64 * M)
 #pragma unroll
       for (int r = 0; r < 4; ++r) tv[r] = 0;
 #pragma unroll
-      for (int j = 0; j < KS; ++j) tv = MM::mma(tt_[li][4 * j + lk], vbr[j], tv);
+      for (int j = 0; j < KS; ++j)
+        if (j < KS - 1 || last_slice) tv = MM::mma(tt_[li][4 * j + lk], vbr[j], tv);
       R a[4], bm[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
