@@ -195,6 +195,27 @@ def test_xfed_source_model_stays_inside_its_workspace(eng, M, F, T, K):
     assert rel_err(host(Vd)[0], V1) < tol(eng, 1e-11, 5e-5)
 
 
+@pytest.mark.parametrize("budget", [16, 150, 768, 4000])
+@pytest.mark.parametrize("M,F,T,K", [(4, 70, 700, 10), (2, 33, 2100, 16), (3, 300, 130, 7)])
+def test_xfed_source_model_partition_forms(eng, M, F, T, K, budget, monkeypatch):
+    """The X-fed halves under every form of the work partition (block-aligned with 1 ... 16 workgroups per block, the flat
+    fallback, more blocks than budget), against the oracle; two utterances in one call == one at a time, bit for bit."""
+    monkeypatch.setenv("ASSX_NMF_XFED_WGS", str(budget))  # read on every call
+    rng = np.random.default_rng(800 + budget + K)
+    Xs = np.stack([mixture(M, F, T, 801 + M), mixture(M, F, T, 802 + M)])
+    W = np.stack([rand_filters(M, F, 803), rand_filters(M, F, 804)])
+    Tb, V = rng.random((2, M, F, K)) + 0.05, rng.random((2, M, K, T)) + 0.05
+    Xb, Wb, Td, Vd = dev_c(eng, Xs), dev_c(eng, W), dev_r(eng, Tb), dev_r(eng, V)
+    eng.ilrma_source_update(Xb, Wb, Td, Vd)
+    for b in range(2):
+        T1, V1 = orc.ilrma_source_update(np.abs(orc.separate(Xs[b], W[b])) ** 2, Tb[b], V[b], 2)
+        assert rel_err(host(Td)[b], T1) < tol(eng, 1e-11, 5e-5)
+        assert rel_err(host(Vd)[b], V1) < tol(eng, 1e-11, 5e-5)
+        t1, v1 = dev_r(eng, Tb[b:b + 1]), dev_r(eng, V[b:b + 1])
+        eng.ilrma_source_update(Xb[b:b + 1], Wb[b:b + 1], t1, v1)
+        assert torch.equal(t1[0], Td[b]) and torch.equal(v1[0], Vd[b])
+
+
 def test_ticket_kernels_on_two_streams_of_one_context(eng):
     """The "last workgroup done" tickets are device words owned by the context -- one buffer PER STREAM (round 4's advisor:
     with one shared buffer two NMF updates issued from one thread on two torch streams counted on the same words: a
