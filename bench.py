@@ -66,6 +66,9 @@ def parse():
     p.add_argument("--with-default-basis", type=int, default=1,
                    help="1 (default): also time the reference's default n_basis = 10 (ilrma.py:183), loss off and on "
                         "(value_k10, value_k10_with_loss; < 1 s)")
+    p.add_argument("--with-other-configs", type=int, default=1,
+                   help="1 (default): also time BASELINE configs 1-3 on rank 0 (side lines other_configs: EUC-NMF 513x256 n_basis 8 "
+                        "and AuxLaplaceIVA M=2 1025x2048 as one library call each, IS-NMF 1025x4096 n_basis 32 per update; < 1 s)")
     p.add_argument("--prewarm-ms", type=float, default=150.0,
                    help="untimed load before the W warm-up steps: the clocks take ~100 ms of work to settle "
                         "(20 timed steps after 5 / 50 / 500 warm-up steps: 0.2025 / 0.1986 / 0.1945 ms per step)")
@@ -275,6 +278,68 @@ def config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K):
                     "RCCL send/recv root<->peers of X and Y" % iters}
 
 
+def other_configs_leg(torch, device):
+    """Side lines for BASELINE configs 1-3 (never `value`): synthetic inputs of the quoted shapes, float64, loss off.
+    config 1 / 3 run as ONE library call (what `model(X, iteration=k)` does without callbacks), config 2 is timed per
+    update with HIP events (20 updates after 3)."""
+    import gc
+    from audio_source_separation_amd import _lib
+    from audio_source_separation_amd.ops import Engine
+    eng = Engine("float64", device=device)
+    g = torch.Generator(device=eng.dev).manual_seed(0)
+    out = {}
+    gc.collect()
+    gc.disable()
+    try:
+        # config 2: IS-NMF, F = 1025, T = 4096, n_basis = 32 (12 F T K flop per update)
+        F, T, K = 1025, 4096, 32
+        X = torch.rand((1, F, T), dtype=torch.float64, device=eng.dev, generator=g) ** 2
+        Tb = torch.rand((1, F, K), dtype=torch.float64, device=eng.dev, generator=g)
+        V = torch.rand((1, K, T), dtype=torch.float64, device=eng.dev, generator=g)
+        for _ in range(3):
+            eng.nmf_update(_lib.NMF_IS_MM, X, Tb, V)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            eng.nmf_update(_lib.NMF_IS_MM, X, Tb, V)
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        out["config2_isnmf_update_us"] = round(us, 2)
+        out["config2_isnmf_tflops"] = round(12.0 * F * T * K / us / 1e6, 2)
+        # config 1: EUC-NMF 513 x 256, n_basis 8, 2000 updates in one call
+        F, T, K, n = 513, 256, 8, 2000
+        X = torch.rand((1, F, T), dtype=torch.float64, device=eng.dev, generator=g) ** 2
+        Tb = torch.rand((1, F, K), dtype=torch.float64, device=eng.dev, generator=g)
+        V = torch.rand((1, K, T), dtype=torch.float64, device=eng.dev, generator=g)
+        eng.nmf_iterate(50, _lib.NMF_EUC, X, Tb, V)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.nmf_iterate(n, _lib.NMF_EUC, X, Tb, V)
+        torch.cuda.synchronize()
+        out["config1_eucnmf_updates_per_s"] = round(n / (time.perf_counter() - t0), 1)
+        # config 3: AuxLaplaceIVA-IP, M = 2, F = 1025, T = 2048, 1000 iterations in one call
+        M, F, T, n = 2, 1025, 2048, 1000
+        S = torch.randn((M, F, T), dtype=torch.float64, device=eng.dev, generator=g) + \
+            1j * torch.randn((M, F, T), dtype=torch.float64, device=eng.dev, generator=g)
+        A = torch.randn((F, M, M), dtype=torch.complex128, device=eng.dev, generator=g)
+        X = torch.einsum("fmn,nft->mft", A, S).contiguous()[None]
+        W = torch.eye(M, dtype=torch.complex128, device=eng.dev).repeat(1, F, 1, 1).contiguous()
+        r = eng.empty((1, M, T))
+        st = eng.new_status(1)
+        eng.auxiva_iterate(20, _lib.IVA_LAPLACE, X, W, r, status=st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.auxiva_iterate(n, _lib.IVA_LAPLACE, X, W, r, status=st)
+        torch.cuda.synchronize()
+        out["config3_auxlaplaceiva_it_per_s"] = round(n / (time.perf_counter() - t0), 1)
+    except Exception as exc:  # a side line never takes the headline down
+        out["error"] = repr(exc)
+    finally:
+        gc.enable()
+    return out
+
+
 def main():
     args = parse()
     env_world = os.environ.get("WORLD_SIZE")
@@ -420,6 +485,8 @@ def main():
             extra[key + "_host_us_per_step"] = round(host_loop[0] * 1e6, 1)
             del mk
     torch.cuda.empty_cache()
+    if args.with_other_configs and rank == 0 and args.dtype == "float64":
+        extra["other_configs"] = other_configs_leg(torch, dev)
 
     # ---------------- CPU baseline: the NumPy oracle on the same workload (rank 0, N=1 only)
     cpu_baseline = None
