@@ -122,21 +122,17 @@ __device__ __forceinline__ R nmf_apply(R old, R num, R den, R eps, PowSpec p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Work partition of the two half kernels (round 4).  One matrix = nblk output blocks (basis half: 16 bins; activation
-// half: 16 frames) x nstep wave-steps (16-frame / 16-bin sub-tiles the block's sums run over).  The nblk * nstep steps
-// are cut into G contiguous ranges of equal length (+-1), one per workgroup; the 4 waves of a workgroup take the steps
-// of its range in turn.  F = 1025 against 256 CUs quantises badly in any (block, slab) grid -- round 3: 17 x 30 = 510
-// workgroups of 9 steps per wave, 18 steps per SIMD where 16.25 is the mean -- and the matrix-core kernels are bound by
-// the issue slots of a SIMD, so what a SIMD gets beyond the mean is the kernel's tail.
-// Measured (profiles/r04_nmf_wgs_sweep.txt): the update takes the same 61 us at config 2 for every budget that is a
-// multiple of the 256 CUs, 256 to 1024 workgroups, i.e. one to four waves per SIMD -- a SIMD spends ~3700 cycles per
-// step whoever issues it, and the fixed part of a launch (prologue, combine, ticket round trips) replaces what the
-// finalize launches cost; budgets that leave some CUs a workgroup more than others lose 5-10 %.
-// A range that crosses a block boundary finishes one block and starts the next; the workgroups whose ranges meet a
-// block are its GROUP: member i writes slab i of the block's records, and (apply != 0) the member that takes the last
-// ticket sums the slabs in ascending order and applies the multiplicative step -- the finalize launches of rounds 1-3
-// are gone.  G, hence every summation order, is a function of one matrix's geometry and the group size (assx_ctx::
-// nmf_group) only, never of the batch.
+// Work partition of the two half kernels.  One matrix = nblk output blocks (basis half: 16 bins; activation half: 16
+// frames) x nstep wave-steps (16-frame / 16-bin sub-tiles the block's sums run over); the 4 waves of a workgroup take the
+// steps of its range in turn.  The workgroups whose ranges meet a block are its GROUP: member i writes slab i of the
+// block's records, and (apply != 0) the member that takes the last ticket sums the slabs in ascending order and applies
+// the multiplicative step (no finalize launches since round 4).  G, hence every summation order, is a function of one
+// matrix's geometry and the group size (assx_ctx::nmf_group) only, never of the batch.
+// Round 4 cut the nblk * nstep steps into G contiguous ranges of equal length (the "flat" form, still used where a block
+// would get fewer than two workgroups); round 5's in-kernel stamps (tools/probes/nmf_trace.py) showed what that cost and
+// that round 4's reading of the sweep ("a SIMD spends ~3700 cycles per step whoever issues it") had divided the whole
+// kernel by the steps: the loop itself runs at ~1550 cycles per step and SIMD with two waves on it, the matrix cores' rate
+// (24 MFMA x 64 cycles); everything else is per-workgroup and per-launch skeleton.
 // ---------------------------------------------------------------------------------------------------------
 struct NmfPart {
   int nblk, nstep, G, maxslots;
