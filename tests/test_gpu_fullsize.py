@@ -114,6 +114,30 @@ def test_nmf_partition_forms_vs_oracle(dtype, F, T, K, budget, monkeypatch):
         assert torch.equal(t1[0], Td[b]) and torch.equal(v1[0], Vd[b])
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_nmf_random_shapes_vs_oracle(seed):
+    """Ten random (F, T, n_basis, kind) per seed, shapes down to a single row / column / basis vector, default budgets: the
+    matrix-core halves (n_basis > 4) and the small-rank kernels (n_basis <= 4) against the oracle, float64."""
+    from audio_source_separation_amd import _lib
+    from audio_source_separation_amd.ops import Engine
+    eng = Engine("float64")
+    rng = np.random.default_rng(9000 + seed)
+    for case in range(10):
+        F = int(rng.choice([1, 2, 15, 16, 17, 33, int(rng.integers(1, 400))]))
+        T = int(rng.choice([1, 3, 16, 64, 65, int(rng.integers(1, 3000))]))
+        K = int(rng.choice([1, 2, 4, 5, 16, 17, 33, 64, int(rng.integers(1, 65))]))
+        kind = ["EUC", "KL", "IS"][int(rng.integers(0, 3))]
+        X = rng.random((F, T)) ** 2 + 1e-3
+        T0, V0 = rng.random((F, K)) + 0.05, rng.random((K, T)) + 0.05
+        code = {"EUC": _lib.NMF_EUC, "KL": _lib.NMF_KL, "IS": _lib.NMF_IS_MM}[kind]
+        Xd, Td, Vd = dev_r(eng, X[None]), dev_r(eng, T0[None]), dev_r(eng, V0[None])
+        eng.nmf_update(code, Xd, Td, Vd)
+        Tr, Vr = orc.nmf_update_once(kind, X, T0, V0, domain=2)
+        assert rel_err(host(Td)[0], Tr) < 1e-11 and rel_err(host(Vd)[0], Vr) < 1e-11, (F, T, K, kind)
+        got = eng.nmf_loss(code, Xd, Td, Vd).item()
+        np.testing.assert_allclose(got, orc.nmf_loss(kind, X, Tr, Vr, domain=2), rtol=1e-9, atol=1e-9, err_msg=str((F, T, K, kind)))
+
+
 # ------------------------------------------------------------------------------------------------ config 2
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_config2_isnmf_full_size_oracle_step(dtype):
