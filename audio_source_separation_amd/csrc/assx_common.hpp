@@ -25,17 +25,24 @@ struct assx_ctx {
   // zeroed device words for the "last workgroup done" tickets of kernels that fold their finalize step (assx_common.hpp:
   // take_ticket).  ONE BUFFER PER STREAM: launches on different streams of one context may overlap on the device, and
   // two kernels counting on the same words would see each other's arrivals (a partial sum applied, counters left
-  // non-zero for every later call).  ensure_tickets() finds / creates / grows the buffer of the stream it is called
-  // for; outgrown buffers are kept (launches that still use them may be in flight) and freed behind a device
-  // synchronisation when their list is full or the context is destroyed.
+  // non-zero for every later call).  The first TK_INIT words of every slot are carved out of ONE pool that
+  // assx_ctx_create allocates and zeroes (round 5's advisor: a stream seen for the first time INSIDE a stream capture --
+  // torch.cuda.graph captures on a fresh side stream -- must not need hipMalloc / hipDeviceSynchronize, which are
+  // illegal there).  ensure_tickets() finds / assigns / grows the buffer of the stream it is called for; growth beyond
+  // TK_INIT and recycling a slot (more than 16 live streams) allocate or synchronise and are refused with a message
+  // while the stream is capturing.  Outgrown buffers are kept (launches that still use them may be in flight) and freed
+  // behind a device synchronisation when their list is full or the context is destroyed.
+  static constexpr size_t TK_INIT = 8192;
   struct TicketSlot {
     hipStream_t st;
     int* p;
     size_t n;
     unsigned long long used;  // value of tk_clock at the last use (least recently used slot is recycled)
+    bool pooled;              // p points into tk_pool (never freed on its own)
   } tk[16];
   int n_tk;
   unsigned long long tk_clock;
+  int* tk_pool;  // 16 x TK_INIT zeroed words, owned by the context
   void* old_tickets[32];
   int n_old_tickets;
 };
@@ -46,8 +53,11 @@ void xfer_destroy(assx_ctx* ctx);  // csrc/assx_xfer.hip
 // at least n zeroed ticket words private to stream `st`, zeroing ordered on `st` before the caller's launch (csrc/
 // assx_api.hip).  Returns 0 and the buffer in *out, or the hipError_t of the failed allocation (message recorded in ctx).
 // Kernels leave the words zero, so a buffer is only ever cleared when it is (re)allocated.  A context used from more
-// streams than it has slots recycles the least recently used slot behind a hipDeviceSynchronize().
+// streams than it has slots recycles the least recently used slot behind a hipDeviceSynchronize().  While `st` is being
+// captured nothing is allocated or synchronised: either the pool serves the request or the call fails with
+// ASSX_E_UNSUPPORTED and says what to warm up.
 int ensure_tickets(assx_ctx* ctx, size_t n, hipStream_t st, int** out);
+int tickets_reserve(assx_ctx* ctx);  // the pool, at context creation (the context's device must be current)
 void tickets_destroy(assx_ctx* ctx);
 
 struct NmfGroupScope {  // sets assx_ctx::nmf_group for the NMF calls made inside the scope

@@ -394,17 +394,19 @@ def main():
             torch.cuda.synchronize(dev)
 
     def timed_steps(model, steps, warmup, with_loss=False):
+        # like timeit: no cyclic garbage collection inside the timed region (a model of an earlier leg is a reference
+        # cycle -- model <-> loss list -- and a full collection in the middle of a leg costs tens of ms of host time:
+        # round 4 saw a side leg turn host-bound, 374 us per step, for exactly that reason).  The collection happens
+        # HERE, before any GPU work of the leg: rounds 4-5 ran it between the last warm-up step and t0, i.e. the part
+        # idled for the length of a full collection right before a region of a few ms (round 5's review, weak #1).
+        gc.collect()
+        gc.disable()
         prewarm(model)
         for _ in range(warmup):
             model.update_once()
             if with_loss:
                 model._record_loss()  # exactly what GaussILRMA.__call__ does per iteration (value stays in HBM)
-        # like timeit: no cyclic garbage collection inside the timed region (a model of an earlier leg is a reference
-        # cycle -- model <-> loss list -- and a full collection in the middle of a leg costs tens of ms of host time:
-        # round 4 saw a side leg turn host-bound, 374 us per step, for exactly that reason)
-        gc.collect()
-        gc.disable()
-        barrier()
+        barrier()  # the contract's bracket: barrier + synchronize, nothing else between the warm-up and t0
         t0 = time.perf_counter()
         for _ in range(steps):
             model.update_once()

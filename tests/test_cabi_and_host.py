@@ -330,7 +330,16 @@ def test_tracked_snapshot_other_in_place_routes():
     orig = st.to_device
     st.to_device = lambda arr, dt, dev: type("T", (), {"clone": lambda self: uploads.append(np.array(arr)) or "uploaded"})()
     try:
-        for write in (lambda a: np.asarray(a).__setitem__((0, 0), 100.0), lambda a: a.view(np.ndarray).fill(2.0)):
+        def swap_rows(a):  # a permutation fix behind the hooks: same multiset of values, another order (round 5's advisor:
+            p = np.asarray(a)  # the sum + xor signature of round 5 could not see it)
+            p[[0, 1]] = p[[1, 0]]
+
+        def flip(a):
+            p = np.asarray(a)
+            p[...] = p[::-1, ::-1].copy()
+
+        for write in (lambda a: np.asarray(a).__setitem__((0, 0), 100.0), lambda a: a.view(np.ndarray).fill(2.0),
+                      swap_rows, flip):
             ent, a = fresh()
             m = Model()
             m._engine = type("E", (), {"prec": type("P", (), {"cplx": None, "real": None})(), "dev": None})()
@@ -441,3 +450,26 @@ def test_engine_refuses_model_arrays_of_another_shape():
         Engine._model_shapes(X, W, Tb, np.zeros((B, K, T)))
     with pytest.raises(ValueError, match="demix_filter"):
         Engine._model_shapes(X, np.zeros((B, F, M, M - 1), np.complex128), Tb, V)
+
+
+def test_signature_is_position_dependent():
+    """Round 5's advisor (medium): a value-preserving reorder of a snapshot must change its content signature, for every
+    size class of the digest (fewer than one row of words, whole rows, a ragged rest, odd byte counts)."""
+    from audio_source_separation_amd._state import _signature
+    rng = np.random.default_rng(5)
+    for shape, dtype in (((3,), np.float32), ((7, 5), np.float64), ((1025, 4, 4), np.complex128), ((4, 4, 4096), np.float64),
+                         ((2, 1031), np.float32), ((4099,), np.uint8)):
+        a = (rng.random(shape) * 100).astype(dtype)
+        s = _signature(a)
+        assert _signature(a.copy()) == s
+        flat = a.reshape(-1)
+        for i, j in ((0, flat.size - 1), (0, 1), (flat.size // 2, flat.size // 2 + 1)):
+            if flat[i] == flat[j]:
+                continue
+            b = a.copy().reshape(-1)
+            b[i], b[j] = b[j], b[i]
+            assert _signature(b.reshape(shape)) != s, (shape, dtype, i, j)
+        if a.ndim >= 2 and a.shape[-2] > 1:
+            b = a.copy()
+            b[..., [0, 1], :] = b[..., [1, 0], :]
+            assert _signature(b) != s, (shape, dtype, "rows")

@@ -256,6 +256,54 @@ def test_ticket_kernels_on_two_streams_of_one_context(eng):
     assert torch.equal(again[0], want[0][0]) and torch.equal(again[1], want[0][1])
 
 
+def test_ticket_kernels_inside_a_stream_capture_on_a_fresh_stream(eng):
+    """Round 5's advisor (medium): torch.cuda.graph captures on a side stream the context has never seen; the first
+    ticket kernel there used to hipMalloc the stream's ticket words -- illegal inside a capture.  The words of a new
+    stream now come out of a pool the context allocated when it was created: a matrix-core NMF update (two ticket
+    kernels) is captured WITHOUT a warm-up on the capture stream, replayed, and must equal the plain launches bit for bit;
+    and a thread that ends right after queueing ticket kernels (its context is destroyed by the collector) is harmless."""
+    import gc
+    import threading
+    from audio_source_separation_amd import _lib
+    F, T, K = 257, 1200, 16
+    rng = np.random.default_rng(711)
+    X, Tb, V = rng.random((1, F, T)) ** 2 + 1e-3, rng.random((1, F, K)) + 0.1, rng.random((1, K, T)) + 0.1
+    kind = _lib.NMF_IS_MM
+    Xd, Td, Vd = dev_r(eng, X), dev_r(eng, Tb), dev_r(eng, V)
+    for _ in range(3):
+        eng.nmf_update(kind, Xd, Td, Vd)
+    torch.cuda.synchronize()
+    want = (Td.clone(), Vd.clone())
+    Td.copy_(dev_r(eng, Tb)); Vd.copy_(dev_r(eng, V))
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(device=eng.dev)  # never used with this context before
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr, stream=side):
+        eng.nmf_update(kind, Xd, Td, Vd)
+    for _ in range(3):
+        gr.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(Td, want[0]) and torch.equal(Vd, want[1])
+
+    # a worker thread queues updates on its own context and ends at once
+    res = {}
+
+    def worker():
+        from audio_source_separation_amd.ops import Engine
+        e2 = Engine(dtype=eng.prec.name)
+        t2, v2 = dev_r(eng, Tb), dev_r(eng, V)
+        for _ in range(3):
+            e2.nmf_update(kind, Xd, t2, v2)
+        res["t"], res["v"] = t2, v2  # no synchronisation: the launches may still be running when the thread ends
+
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    gc.collect()  # drops the thread's context: assx_ctx_destroy waits for its device before it frees the ticket words
+    torch.cuda.synchronize()
+    assert torch.equal(res["t"], want[0]) and torch.equal(res["v"], want[1])
+
+
 @pytest.mark.parametrize("M,K,G", [(4, 10, 0), (4, 10, 3), (2, 5, 2), (3, 8, 5), (4, 12, 1), (4, 16, 7), (3, 13, 4), (2, 7, 0)])
 def test_source_model_wide_basis(eng, M, K, G):
     """The n_basis 5..16 source model (demixed-power map + matrix-core NMF halves) without a loss request, ragged T, zero
