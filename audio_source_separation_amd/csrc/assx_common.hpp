@@ -245,16 +245,18 @@ __device__ __forceinline__ void buf_ld_tied(float& dst, buf_u4 rsrc, unsigned vo
   asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, %3 offen" : "+v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 // one dword per lane, global -> LDS (lane L lands at lds_addr + 4 L), invisible to the compiler's vmcnt model like
-// buf_ldv_tied.  M0 carries the LDS address; nothing else in these kernels uses M0.
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
+// buf_ldv_tied.  M0 carries the LDS address and is an INPUT operand pinned to the register ("{m0}"): the compiler writes
+// M0 itself, ahead of the block, and knows what it holds afterwards -- its own LDS-direct loads (the
+// __builtin_amdgcn_raw_ptr_buffer_load_lds calls next to this one in assx_widem_cov.hpp) get their own M0 write.  Rounds
+// 3-5 wrote M0 inside the asm and listed it as a clobber, which the backend answers with "reserved registers on the
+// clobber list may not be preserved" (round 5's review, weak #9); tools/asm_wait_check.py now refuses any inline-asm
+// block that writes M0.  The s_nop covers SALU-write -> VMEM-read of the descriptor / offset SGPRs and of M0.
 __device__ __forceinline__ void buf_dword_to_lds(unsigned lds_addr, buf_u4 rsrc, unsigned voff, unsigned soff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds"
+  asm volatile("s_nop 4\n\tbuffer_load_dword %1, %2, %3 offen lds"
                :
-               : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
-               : "memory", "m0");
+               : "{m0}"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+               : "memory");
 }
-#pragma clang diagnostic pop
 template <int N, typename R>
 __device__ __forceinline__ void wait_slot(Vec2<R> (&x)[2]) {
   asm volatile("s_waitcnt vmcnt(%2)" : "+v"(x[0]), "+v"(x[1]) : "n"(N) : "memory");

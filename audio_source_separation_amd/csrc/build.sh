@@ -68,7 +68,7 @@ if [ "$CHECK" = 1 ]; then
     asm="$OBJ/temps_$src/$src-hip-amdgcn-amd-amdhsa-gfx950.s"
     [ -f "$asm" ] || { echo "build.sh: no device assembly for $src ($asm)" >&2; exit 1; }
     if ! python3 "$CHECKER" "$asm" > "$OBJ/temps_$src/check.log" 2>&1; then
-      echo "build.sh: asm_wait_check FAILED for $src.hip -- an instruction touches an inline-asm load before its wait:" >&2
+      echo "build.sh: asm_wait_check FAILED for $src.hip (a pending inline-asm load touched before its wait, a ring without its counted wait, or inline asm that writes M0):" >&2
       tail -n 40 "$OBJ/temps_$src/check.log" >&2
       exit 1
     fi

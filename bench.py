@@ -60,7 +60,12 @@ def parse():
     p.add_argument("--cpu-iters", type=int, default=4, help="timed oracle iterations for cpu_baseline (0 = skip)")
     p.add_argument("--cpu-reference-form", default="quarter", choices=["quarter", "full", "off"],
                    help="reference-form (materialising XX/R) CPU leg: on T/4 frames (default), the full shape, or not")
-    p.add_argument("--with-loss", action="store_true", help="also report it/s with recordable_loss=True")
+    p.add_argument("--with-loss", type=int, default=1, nargs="?", const=1,
+                   help="1 (default): also report it/s with recordable_loss=True, the reference's default (value_with_loss; "
+                        "100-step side leg unless --steps is smaller)")
+    p.add_argument("--with-b8", type=int, default=1,
+                   help="1 (default): also time 8 utterances per launch -- BASELINE config 5's per-GPU regime, 2.15 GB of X, "
+                        "nothing of it survives in the Infinity Cache from pass to pass (value_b8, utterance-iterations/s; < 1 s)")
     p.add_argument("--with-f32", type=int, default=1,
                    help="1 (default): also time the float32 storage mode on the same workload (extra line value_f32; < 1 s)")
     p.add_argument("--with-default-basis", type=int, default=1,
@@ -371,12 +376,15 @@ def main():
     cplx = torch.complex128 if args.dtype == "float64" else torch.complex64
     Xrun = X.to(cplx).contiguous()
 
-    def make_model(record_loss, dtype=None, n_basis=None):
+    def make_model(record_loss, dtype=None, n_basis=None, x=None):
         np.random.seed(111 + rank)
         dtype = dtype or args.dtype
         m = GaussILRMA(n_basis=n_basis or K, recordable_loss=record_loss, dtype=dtype, device=dev,
                        power_statistic=args.power_statistic)
-        m.input = Xrun if dtype == args.dtype else X.to(torch.complex64 if dtype == "float32" else torch.complex128).contiguous()
+        if x is not None:
+            m.input = x
+        else:
+            m.input = Xrun if dtype == args.dtype else X.to(torch.complex64 if dtype == "float32" else torch.complex128).contiguous()
         m._reset()
         return m
 
@@ -468,14 +476,13 @@ def main():
     value = total_units / elapsed
 
     extra = {}
+    # side lines of the same workload (never `value`): the loss recorded (the reference's default), the float32 storage
+    # mode, the reference's default n_basis, 8 utterances per launch
+    side_steps, side_warm = min(args.steps, 100), min(args.warmup, 10)
     if args.with_loss:
         ml = make_model(True)
-        dt = timed_steps(ml, args.steps, args.warmup, with_loss=True)
-        extra["value_with_loss"] = n_gpus * B * args.steps / dt
+        extra["value_with_loss"] = round(n_gpus * B * side_steps / timed_steps(ml, side_steps, side_warm, with_loss=True), 2)
         del ml
-
-    # side lines of the same workload (never `value`): the float32 storage mode, and the reference's default n_basis
-    side_steps, side_warm = min(args.steps, 100), min(args.warmup, 10)
     if args.with_f32 and args.dtype == "float64":
         m32 = make_model(False, dtype="float32")
         extra["value_f32"] = round(n_gpus * B * side_steps / timed_steps(m32, side_steps, side_warm), 2)
@@ -486,6 +493,14 @@ def main():
             extra[key] = round(n_gpus * B * side_steps / timed_steps(mk, side_steps, side_warm, with_loss=rl), 2)
             extra[key + "_host_us_per_step"] = round(host_loop[0] * 1e6, 1)
             del mk
+    if args.with_b8 and B == 1 and (M, F, T) == (4, 1025, 4096):
+        B8 = 8
+        X8 = synth_mixture(torch, dev, B8, M, F, T, seed=2000 + rank).to(cplx).contiguous()
+        m8 = make_model(False, x=X8)
+        s8, w8 = min(args.steps, 40), min(args.warmup, 5)
+        extra["value_b8"] = round(n_gpus * B8 * s8 / timed_steps(m8, s8, w8), 2)
+        extra["value_b8_note"] = "utterance-iterations/s, %d utterances per launch (config 5's per-GPU batch), %d steps" % (B8, s8)
+        del m8, X8
     torch.cuda.empty_cache()
     if args.with_other_configs and rank == 0 and args.dtype == "float64":
         extra["other_configs"] = other_configs_leg(torch, dev)
@@ -514,7 +529,7 @@ def main():
             "config": {"workload": "gauss_ilrma_ip update_once, M=%d F=%d T=%d K=%d, normalize=power, loss off" % (M, F, T, K),
                        "utterances_per_gpu": B, "power_statistic": args.power_statistic,
                        "parallelism": "utterance-sharded x%d, no data-path collective" % n_gpus},
-            "comm": comm,
+            "comm": dict(comm, utterances_per_rank=[B] * n_gpus),
             "roofline": roofline,
             "roofline_b8": roofline_b8,
             "cpu_baseline": cpu_baseline,

@@ -77,3 +77,27 @@ def test_checker_counts_lds_direct_loads_in_flight_at_asm_lds_reads(tmp_path):
     assert r.returncode == 1 and "ring_bad_kernel" in r.stdout and "LDS-direct loads in flight" in r.stdout, r.stdout
     assert "ring_good_kernel" not in r.stdout and r.stdout.strip().endswith("total 1"), r.stdout
     assert open(asm).read().count(" lds") >= 10  # both kernels really use LDS-direct loads
+
+
+def test_checker_reports_inline_asm_that_writes_m0(tmp_path):
+    """Round 5's review (weak #9): an LDS-direct load written as `s_mov_b32 m0, ...; buffer_load ... lds` with "m0" on the
+    clobber list sits next to the compiler's own M0 bookkeeping without being part of it.  tests/asm_wait_m0.hip holds that form
+    (reported) and the form the library uses since round 6 -- the address as an input operand pinned to M0, so the write is the
+    compiler's (clean); and the build fails on the bad one."""
+    asm = tmp_path / "m0.s"
+    r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                        os.path.join(ROOT, "tests", "asm_wait_m0.hip"), "-o", str(asm)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "reserved registers" in r.stderr  # the backend's own warning, from the bad kernel only:
+    assert r.stderr.count("inline asm clobber list contains reserved registers") == 1, r.stderr[-1500:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_wait_check.py"), str(asm)], capture_output=True,
+                       text=True, timeout=60)
+    assert r.returncode == 1 and "m0_bad_kernel" in r.stdout and "writes M0" in r.stdout, r.stdout
+    assert "m0_good_kernel" not in r.stdout and r.stdout.strip().endswith("total 1"), r.stdout
+    txt = open(asm).read()
+    good = txt[txt.index("_Z14m0_good_kernel"):]
+    assert "s_mov_b32 m0" in good or "s_movk_i32 m0" in good or "m0," in good  # the compiler's write is there, outside the asm block
+    build = os.path.join(ROOT, "audio_source_separation_amd", "csrc", "build.sh")
+    env = dict(os.environ, ASSX_OBJ=str(tmp_path), ASSX_OUT=str(tmp_path / "lib.so"), ASSX_SRCS="../../tests/asm_wait_m0")
+    r = subprocess.run(["bash", build], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode != 0 and "asm_wait_check FAILED" in r.stderr, (r.returncode, r.stderr[-1500:])

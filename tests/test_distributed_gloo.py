@@ -94,21 +94,30 @@ def _worker(rank, world, port, n_items, q):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_items", [4, 5, 1])
-def test_two_process_scatter_separate_gather(n_items):
-    world = 2
+def _run_world(world, n_items):
+    """`world` gloo processes: scatter -> OracleILRMA on every rank's block -> gather, the raw edges, the rank-ordered sum
+    and the max-over-ranks reduction; everything compared with one process, bit for bit."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_items, q)) for r in range(world)]
+    saved = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "1"  # inherited by the spawned ranks only: 8 ranks on 8 cores, one thread each
+    try:
+        for p in procs:
+            p.start()
+    finally:  # never left in this process: the fixture-reproducibility test runs the reference with the default BLAS threads
+        if saved is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = saved
+    results = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
-        p.start()
-    results = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     root = [r for r in results if len(r) == 4][0]
-    other = [r for r in results if len(r) == 3][0]
+    others = [r for r in results if len(r) == 3]
+    assert len(others) == world - 1
     y, z, tmax, s = root
     X = _mixtures(n_items)
     single = OracleILRMA()
@@ -116,11 +125,28 @@ def test_two_process_scatter_separate_gather(n_items):
     ref = single(torch.from_numpy(X), iteration=3)
     assert np.array_equal(y, ref)  # sharded == single process, bit for bit, original order
     assert np.array_equal(z, X * 2)
-    assert tmax == 2.0 and other[1] == 2.0
-    assert other[0] == D.shard_range(n_items, world, 1)[1] - D.shard_range(n_items, world, 1)[0]
-    # rank-ordered sum: the same bits on both ranks, equal to adding the partials in rank order
-    expect = np.array([0.1, 1e-17]) + np.array([0.2, 2e-17])
-    assert np.array_equal(s, expect) and np.array_equal(other[2], expect)
+    assert tmax == float(world) and all(o[1] == float(world) for o in others)
+    sizes = D.shard_sizes(n_items, world)
+    assert sorted(o[0] for o in others) == sorted(sizes[1:])  # every peer worked on a block of the static partition
+    # rank-ordered sum: the same bits on every rank, equal to adding the partials in rank order
+    expect = np.array([0.1, 1e-17])
+    for r in range(1, world):
+        expect = expect + np.array([0.1 * (r + 1), 1e-17 * (r + 1)])
+    assert np.array_equal(s, expect) and all(np.array_equal(o[2], expect) for o in others)
+
+
+@pytest.mark.parametrize("n_items", [4, 5, 1])
+def test_two_process_scatter_separate_gather(n_items):
+    _run_world(2, n_items)
+
+
+@pytest.mark.parametrize("n_items", [64, 13, 5])
+def test_eight_process_scatter_separate_gather(n_items):
+    """BASELINE config 5's process layout for real (round 5's review, item 4): EIGHT gloo ranks, the root scatters 64 / 13 / 5
+    utterances with one grouped batch of sends, every rank runs its block (8 each; 2,2,2,2,2,1,1,1; five ranks with one item
+    and three with none), the root gathers with one grouped batch of receives.  Until round 6 the 8-rank edges were only
+    checked as operation lists against a mocked P2POp (test_edge_operation_lists_for_eight_ranks, kept)."""
+    _run_world(8, n_items)
 
 
 # ---------------------------------------------------------------------------------------------------------------

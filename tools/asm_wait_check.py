@@ -21,6 +21,12 @@ prologue, or at the end of a trip: the walk goes round every loop three times, s
 it and is reported ("N LDS-direct loads in flight at an asm LDS read").  What this does NOT see: a wait whose immediate is
 too large by less than a trip's loads, or a read of the wrong slot; the full-size co-residency tests are the guard there.
 
+M0 (round 6): an LDS-direct load takes its LDS address from M0, which the compiler manages for its own LDS-direct loads and
+for everything else that uses M0.  An inline-asm block that WRITES M0 (s_mov_b32 m0, ... inside ;;#ASMSTART .. ;;#ASMEND) sits
+next to that bookkeeping without being part of it (listing M0 as a clobber is answered with "reserved registers on the
+clobber list may not be preserved ... undefined behaviour"): every such write is reported.  The kernels hand the address in
+through an input operand pinned to the register ("{m0}"(addr)), so the write is the compiler's own, outside the block.
+
     hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S csrc/assx_widem.hip -o /tmp/widem.s
     python tools/asm_wait_check.py /tmp/widem.s [kernel-name substring]"""
 import re
@@ -113,6 +119,9 @@ def check(lines, name, linear=False):
             elif op == "s_branch" and label_at.get(l.split()[-1], -1) >= k:
                 incoming[l.split()[-1]] = {key: list(v) for key, v in pend.items()}
             continue
+        if in_asm and op.startswith("s_") and parts and re.match(r"^m0\b", parts[0]) and (ln, "m0") not in seen:
+            seen.add((ln, "m0"))
+            bad.append((ln, l, "inline asm writes M0 (pass the LDS address as an input operand pinned to the register: \"{m0}\"(addr))"))
         if op == "s_barrier" or op.startswith("s_"):
             continue
         touched = set()
@@ -156,7 +165,7 @@ def main():
             if want in name:
                 bad = check([(k - i, txt[k]) for k in range(i, j)], name, linear)
                 if bad:
-                    print("%s: %d reports (a pending load's registers touched / LDS-direct loads in flight at an asm LDS read)" % (name[:100], len(bad)))
+                    print("%s: %d reports (a pending load's registers touched / LDS-direct loads in flight at an asm LDS read / M0 written by inline asm)" % (name[:100], len(bad)))
                     for ln, l, src in bad[:6]:
                         print("    +%d  %s    <- pending: %s" % (ln, l, src))
                 total += len(bad)
