@@ -175,6 +175,7 @@ int assx_ctx_destroy(assx_ctx* ctx) {
 
 const char* assx_last_error(const assx_ctx* ctx) { return ctx ? ctx->err : "ctx is NULL"; }
 
-const char* assx_version(void) { return ASSX_VERSION_STRING; }
+// a laboratory build (-DASSX_LAB=1: the environment switches of the measured-and-not-kept variants are live) says so
+const char* assx_version(void) { return ASSX_LAB ? ASSX_VERSION_STRING "+lab" : ASSX_VERSION_STRING; }
 
 }  // extern "C"

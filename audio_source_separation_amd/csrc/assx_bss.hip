@@ -714,15 +714,11 @@ __global__ void __launch_bounds__(64) pb_solve_kernel(const R* __restrict__ part
 // ------------------------------------------------------------------------------------------
 // host-side launch helpers
 // ------------------------------------------------------------------------------------------
-inline int env_int(const char* name, int dflt) {
-  const char* s = getenv(name);
-  return (s && *s) ? atoi(s) : dflt;
-}
 
 // number of t-splits for the wave-per-(b,f,ts) kernels: aim at >= ~8 waves per SIMD chip-wide
 inline void t_split(int B, int F, int T, int* TS, int* tchunk) {
-  static const int target = env_int("ASSX_TARGET_WAVES", 8192);
-  static const int forced = env_int("ASSX_TS", 0);
+  static const int target = lab_int("ASSX_TARGET_WAVES", 8192);
+  static const int forced = lab_int("ASSX_TS", 0);
   (void)B;  // the split is a function of ONE utterance's geometry: batched == per-utterance, bit for bit
   int ts = forced > 0 ? forced : (int)((target + (size_t)F - 1) / ((size_t)F));
   int max_ts = (T + 255) / 256;  // at least 4 frames per lane
@@ -736,8 +732,8 @@ inline void t_split(int B, int F, int T, int* TS, int* tchunk) {
 }
 
 inline void f_split(int B, int F, int T, int* FS, int* fchunk) {
-  static const int target = env_int("ASSX_TARGET_WGS", 1024);
-  static const int forced = env_int("ASSX_FS", 0);
+  static const int target = lab_int("ASSX_TARGET_WGS", 1024);
+  static const int forced = lab_int("ASSX_FS", 0);
   const int TB = (T + WAVE - 1) / WAVE;
   (void)B;
   int fs = forced > 0 ? forced : (int)((target + (size_t)TB - 1) / ((size_t)TB));
@@ -868,8 +864,8 @@ struct WsLayout {  // carve-up of the caller's scratch; every region 256-byte al
 constexpr int CHIP_CUS = 256;
 
 inline long long g_target(int wgs_per_cu) {
-  static const int rounds = env_int("ASSX_ROUNDS", 1);
-  const int forced = env_int("ASSX_G", 0);  // read on every call: the tests shrink G to give small inputs long ranges
+  static const int rounds = lab_int("ASSX_ROUNDS", 1);
+  const int forced = knob_int("ASSX_G", 0);  // read on every call: the tests shrink G to give small inputs long ranges
   if (forced > 0) return forced;
   return (long long)CHIP_CUS * wgs_per_cu * (rounds < 1 ? 1 : rounds);
 }
@@ -900,7 +896,7 @@ inline FlatPart flat_cov_wide(int B, int F, int T, int sb = 1) {
 // (SQ counters), and the second X block in registers spills at float64 -- 124 us instead of 92.
 template <typename R>
 inline int cov_wide_sb(int NK) {
-  static const int forced = env_int("ASSX_COVW_SB", 0);
+  static const int forced = lab_int("ASSX_COVW_SB", 0);
   if (forced == 2 && CovWideGeom<R, 2>::lds_bytes(NK) <= 144 * 1024) return 2;
   return 1;
 }
@@ -1007,7 +1003,7 @@ inline unsigned blocks_for(size_t n, int bs) { return (unsigned)((n + bs - 1) / 
 // alternating from pass to pass when the launch holds more than one utterance; ASSX_UTT_ORDER=0 restores the legacy
 // order (A/B runs).  Returns the grid size.  The order decides WHEN a range runs, never what it computes.
 inline unsigned set_launch_order(FlatPart& fp, int B, int rev) {
-  static const int on = env_int("ASSX_UTT_ORDER", 1);
+  static const int on = lab_int("ASSX_UTT_ORDER", 1);
   if (!on || B < 2) {
     fp.Gp = 0;
     fp.rev = 0;
@@ -1045,16 +1041,20 @@ int run_cov_partial(assx_ctx* ctx, int wk, const void* X, const void* r, const v
       // K <= 4: activation tile through the LDS-direct ring (VTileDma), X slots refilled in place; ASSX_COV_VDMA=0
       // selects the plain vector-load form of the same kernel (kept for A/B measurements)
       if (K <= KU) {
-        static const int vdma = env_int("ASSX_COV_VDMA", 1);
         constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, M * KU>::TILE_BYTES;
-        if (vdma && d2)
+#if ASSX_LAB
+        static const int vdma = lab_int("ASSX_COV_VDMA", 1);
+        if (!vdma) {
+          if (d2) COV_LAUNCH(WK_TV, true, true, LSX, (sizeof(R) == 8 ? 2 : 4), 1, 2);
+          else COV_LAUNCH(WK_TV, true, false, LSX, 2, 1, 1);
+        } else
+#endif
+        if (d2)
           hipLaunchKernelGGL((cov_stream_kernel<R, M, WK_TV, true, true, 1, 2, 1, 2, true>), grid, dim3(64), vlds, st,
                              (const Cx<R>*)X, (const R*)r, (const R*)Tb, (const R*)V, (R*)ws, a);
-        else if (vdma)
+        else
           hipLaunchKernelGGL((cov_stream_kernel<R, M, WK_TV, true, false, 1, 2, 1, 1, true>), grid, dim3(64), vlds, st,
                              (const Cx<R>*)X, (const R*)r, (const R*)Tb, (const R*)V, (R*)ws, a);
-        else if (d2) COV_LAUNCH(WK_TV, true, true, LSX, (sizeof(R) == 8 ? 2 : 4), 1, 2);
-        else COV_LAUNCH(WK_TV, true, false, LSX, 2, 1, 1);
       }
       else if (d2) COV_LAUNCH(WK_TV, false, true, LSX, 4, 1, 1);
       else COV_LAUNCH(WK_TV, false, false, LSX, 2, 1, 1);
@@ -1082,10 +1082,11 @@ template <typename R, int M>
 int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, void* W, const void* C, double* pw,
            double thr, int32_t* status, int B, int F, hipStream_t st, double den_floor = 0.0, int wb = 1) {
   constexpr int GPW = WAVE / next_pow2_c(M * M);
-  // round 4, ASSX_IP_PAR=1: the sources of a bin side by side in one wave (assx_group_linalg.hpp: ip_par_kernel).  Parity-
-  // green on every test (tests/test_gpu_ops.py runs both forms) and SLOWER: 19.2 us against 14.9 us at config 4
-  // (profiles/r04_ip_par.txt), so the sequential sweep stays the default.  Read on every call.
-  const int par = env_int("ASSX_IP_PAR", 0);
+#if ASSX_LAB
+  // round 4, ASSX_IP_PAR=1 (laboratory builds only): the sources of a bin side by side in one wave (assx_group_linalg.hpp:
+  // ip_par_kernel).  Parity-green on every test and SLOWER: 19.2 us against 14.9 us at config 4 (profiles/r04_ip_par.txt),
+  // so the sequential sweep is the product's.  Read on every call.
+  const int par = lab_int("ASSX_IP_PAR", 0);
   if (par) {
     const dim3 gp(blocks_for((size_t)B * F, GPW / M)), bp(64);
     if (part)
@@ -1097,6 +1098,7 @@ int run_ip(assx_ctx* ctx, const void* U, const void* part, FlatPart fp, int T, v
     ASSX_LAUNCH_CHECK(ctx, "ip_par_kernel");
     return 0;
   }
+#endif
   const dim3 grid(blocks_for((size_t)B * F, GPW)), block(64);
   if (part)
     hipLaunchKernelGGL((ip_group_kernel<R, M, true>), grid, block, 0, st, (const Cx<R>*)nullptr, (const R*)part, fp,
@@ -1156,26 +1158,33 @@ int run_basis_partial(assx_ctx* ctx, const void* X, const void* W, const void* T
 #define BASIS_LAUNCH(K4V, D2V, DXV, DWV, MW) \
   hipLaunchKernelGGL((basis_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW>), gb, bb, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a)
-  static const int vdma = env_int("ASSX_BASIS_VDMA", 1);
   constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, MM * KU>::TILE_BYTES;
 #define BASIS_VD(D2V, MW, TDV) \
   hipLaunchKernelGGL((basis_stream_vd_kernel<R, MM, D2V, 2, MW, TDV>), gb, bb, vlds, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a, (double*)nullptr, 0)
+  // n_basis <= 4: the activation tile rides the LDS-direct ring (basis_stream_vd_kernel).  The plain vector-load forms of
+  // rounds 1-2 are laboratory builds' (ASSX_BASIS_VDMA=0); n_basis > 4 arrives here only where the matrix-core source
+  // model does not apply (partitioning function with n_basis > 64)
+#if ASSX_LAB
+  static const int vdma = lab_int("ASSX_BASIS_VDMA", 1);
+  if (k4 && !vdma) {
+    if (nu >= 0.0) hipLaunchKernelGGL((basis_stream_kernel<R, MM, true, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
+                                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+    else if (d2) BASIS_LAUNCH(true, true, 3, 1, 2);
+    else BASIS_LAUNCH(true, false, 2, 1, 1);
+  } else
+#endif
   if (nu >= 0.0) {
-    if (k4 && vdma) BASIS_VD(true, 2, true);
-    else if (k4) hipLaunchKernelGGL((basis_stream_kernel<R, MM, true, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
-                               (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+    if (k4) BASIS_VD(true, 2, true);
     else hipLaunchKernelGGL((basis_stream_kernel<R, MM, false, true, 3, 1, 1, true>), gb, bb, 0, st, (const Cx<R>*)X,
                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
-  } else if (k4 && vdma) {
+  } else if (k4) {
     if (d2 && lpart)
       hipLaunchKernelGGL((basis_stream_vd_kernel<R, MM, true, 2, 2, false, true>), gb, bb, vlds, st, (const Cx<R>*)X,
                          (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a, lpart, lstride);
     else if (d2) BASIS_VD(true, 2, false);
     else BASIS_VD(false, 1, false);
-  } else if (k4 && d2) BASIS_LAUNCH(true, true, 3, 1, 2);
-  else if (k4) BASIS_LAUNCH(true, false, 2, 1, 1);
-  else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
+  } else if (d2) BASIS_LAUNCH(false, true, 3, 1, 1);
   else BASIS_LAUNCH(false, false, 2, 1, 1);
 #undef BASIS_VD
 #undef BASIS_LAUNCH
@@ -1200,22 +1209,26 @@ int run_act_partial(assx_ctx* ctx, const void* X, const void* W, const void* Tb,
 #define ACT_LAUNCH(K4V, D2V, DXV, MW) \
   hipLaunchKernelGGL((act_stream_kernel<R, MM, K4V, D2V, DXV, MW>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
                      (const R*)Tb, (const R*)V, (R*)ws, a)
-  static const int vdma = env_int("ASSX_ACT_VDMA", 1);
 #define ACT_VD(D2V, DXV, MW, TDV) \
   hipLaunchKernelGGL((act_stream_vd_kernel<R, MM, D2V, DXV, MW, TDV>), ga, ba, 0, st, (const Cx<R>*)X, (const Cx<R>*)W, \
                      (const R*)Tb, (const R*)V, (R*)ws, a)
+#if ASSX_LAB
+  static const int vdma = lab_int("ASSX_ACT_VDMA", 1);  // 0: the plain vector-load forms of rounds 1-2 (A/B runs)
+  if (k4 && !vdma) {
+    if (nu >= 0.0) hipLaunchKernelGGL((act_stream_kernel<R, MM, true, true, 3, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
+                                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+    else if (d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
+    else ACT_LAUNCH(true, false, 2, 1);
+  } else
+#endif
   if (nu >= 0.0) {
-    if (k4 && vdma) ACT_VD(true, 3, 2, true);
-    else if (k4) hipLaunchKernelGGL((act_stream_kernel<R, MM, true, true, 3, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
-                               (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
+    if (k4) ACT_VD(true, 3, 2, true);
     else hipLaunchKernelGGL((act_stream_kernel<R, MM, false, true, 4, 1, true>), ga, ba, 0, st, (const Cx<R>*)X,
                             (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)ws, a);
-  } else if (k4 && vdma) {
+  } else if (k4) {
     if (d2) ACT_VD(true, 3, 2, false);
     else ACT_VD(false, 2, 1, false);
-  } else if (k4 && d2) ACT_LAUNCH(true, true, (sizeof(R) == 8 ? 3 : 4), 2);
-  else if (k4) ACT_LAUNCH(true, false, 2, 1);
-  else if (d2) ACT_LAUNCH(false, true, 4, 1);
+  } else if (d2) ACT_LAUNCH(false, true, 4, 1);
   else ACT_LAUNCH(false, false, 2, 1);
 #undef ACT_VD
 #undef ACT_LAUNCH
@@ -1231,8 +1244,8 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
                        void* ws, void* U_dense, int B, int F, int T, int dtype, hipStream_t st, FlatPart* fp_out,
                        bool* dense, int* records_wb = nullptr /* non-null: the caller's sweep reads cov_wide_kernel's
                        records itself (ip_group_kernel, wb = COVW_BINS); the dense finalize is skipped */) {
-  static const int wide = env_int("ASSX_WIDE_K", 1);
-  static const int fused = env_int("ASSX_COV_WIDE", 1);
+  static const bool wide = lab_int("ASSX_WIDE_K", 1) != 0;
+  static const bool fused = lab_int("ASSX_COV_WIDE", 1) != 0;
   *dense = false;
   if (records_wb) *records_wb = 1;
   if (K <= KU || !wide) return run_cov_partial<R, MM>(ctx, WK_TV, X, nullptr, Tb, V, K, domain, eps, ws, B, F, T, st, fp_out);
@@ -1240,7 +1253,7 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
   const PowSpec p2d = make_pow(2.0 / domain);
   // 4 < n_basis <= 16: the variance contraction on the matrix cores (assx_cov_mfma.hpp); ASSX_COV_MFMA=0 keeps round 2's
   // LDS-tile kernel for A/B runs.  Same partition, same records.
-  static const int mfma = env_int("ASSX_COV_MFMA", 1);
+  static const bool mfma = lab_int("ASSX_COV_MFMA", 1) != 0;
   if (fused && mfma && U_dense && K <= 16 && (size_t)B * MM * K * T * sizeof(R) < 0xffffffffull) {
     const FlatPart fw = flat_cov_wide(B, F, T, 1);
     const Dims d{B, F, T, K};
@@ -1295,13 +1308,14 @@ int run_cov_partial_tv(assx_ctx* ctx, const void* X, const void* Tb, const void*
     hipLaunchKernelGGL((cov_wide_kernel<R, MM, D2V, SBV>), dim3(fw.G), dim3(WAVE * COVW_BINS), lds, st,              \
                        (const Cx<R>*)X, (const R*)Tb, (const R*)V, (R*)ws, d, fw, (R)eps, p2d);                      \
   } while (0)
-    if (p2d.mode == POW_ID) {
-      if (sb == 2) COVW_LAUNCH(true, 2);
-      else COVW_LAUNCH(true, 1);
-    } else {
-      if (sb == 2) COVW_LAUNCH(false, 2);
-      else COVW_LAUNCH(false, 1);
-    }
+#if ASSX_LAB
+    if (sb == 2) {  // ASSX_COVW_SB=2: one barrier per 128 frames (measured slower; A/B runs)
+      if (p2d.mode == POW_ID) COVW_LAUNCH(true, 2);
+      else COVW_LAUNCH(false, 2);
+    } else
+#endif
+    if (p2d.mode == POW_ID) COVW_LAUNCH(true, 1);
+    else COVW_LAUNCH(false, 1);
 #undef COVW_LAUNCH
     ASSX_LAUNCH_CHECK(ctx, "cov_wide_kernel");
     if (records_wb) {
@@ -1468,10 +1482,10 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     // K <= 4, LDS-ring kernel), otherwise a pass of its own before anything is updated
     double* lpart = nullptr;
     int lstride = 0;
-    static const int wide_k = env_int("ASSX_WIDE_K", 1);
+    static const bool wide_k = lab_int("ASSX_WIDE_K", 1) != 0;
     const bool full_mask = (source_mask & ((1u << MM) - 1u)) == ((1u << MM) - 1u);
     bool have_map = false;
-    if (loss_prev && K > KU && wide_k && full_mask && domain == 2.0 && env_int("ASSX_FUSE_LOSS", 1)) {
+    if (loss_prev && K > KU && wide_k && full_mask && domain == 2.0 && (lab_int("ASSX_FUSE_LOSS", 1) != 0)) {
       // n_basis > 4 (round 4): the loss of the model at entry rides on the X-fed basis half (assx_nmf_xfed.hpp), which
       // forms the same |w^H x|^2 and Tb V -- no pass of its own, no power map
       const int ncov = nmf_xfed_loss_partials(MM, F, T, K);
@@ -1494,7 +1508,7 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
       }
     }
     if (loss_prev) {
-      const bool fusable = domain == 2.0 && K <= KU && env_int("ASSX_BASIS_VDMA", 1) && env_int("ASSX_FUSE_LOSS", 1);
+      const bool fusable = domain == 2.0 && K <= KU && (lab_int("ASSX_BASIS_VDMA", 1) != 0) && (lab_int("ASSX_FUSE_LOSS", 1) != 0);
       if (!fusable) {
         // n_basis > 4: the loss pass forms |W x|^2 anyway and leaves it behind as the map the source model needs
         void* pmap = (K > KU && wide_k) ? (void*)((char*)ws + ws_layout(B, MM, F, T, K, dtype).map) : nullptr;
@@ -1620,7 +1634,7 @@ int assx_ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const voi
     };
     FlatPart fp;
     int rc;
-    static const int wide = env_int("ASSX_WIDE_K", 1);
+    static const bool wide = lab_int("ASSX_WIDE_K", 1) != 0;
     if (K > KU && K <= 64 && wide) {
       // n_basis > 4: the three sets of per-source sums come from the NMF matrix-core kernels on P = |W x|^2 (formed
       // once: W does not move here) with the effective model, batch B*N; adapters lay them out as the records the
@@ -1898,7 +1912,7 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
     a.nu = (R)nu;
     const PowSpec p2d = make_pow(2.0 / domain);
     const bool d2 = p2d.mode == POW_ID, k4 = K <= KU;
-    static const int wide = env_int("ASSX_WIDE_K", 1);
+    static const bool wide = lab_int("ASSX_WIDE_K", 1) != 0;
     if (!k4 && wide) {  // n_basis > 4: bin-batched evaluation (ilrma_loss_wide_kernel)
       const dim3 gw(blocks_for(T, 64), blocks_for(F, WIDE_FB), B);
       const int nw = (int)(gw.x * gw.y), lsw = nw + F;
@@ -1928,20 +1942,23 @@ static int ilrma_loss_impl(assx_ctx* ctx, const char* who, const void* X, const 
 #define LOSS_LAUNCH(K4V, D2V, DXV, DWV, MW, TDV)                                                                \
   hipLaunchKernelGGL((loss_stream_kernel<R, MM, K4V, D2V, DXV, DWV, MW, TDV>), grid, blk, 0, st, (const Cx<R>*)X, \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lstride, a, p2d)
-    static const int vdma = env_int("ASSX_LOSS_VDMA", 1);
     constexpr size_t vlds = (size_t)VDMA_SLOTS * VTileDma<R, MM * KU>::TILE_BYTES;
 #define LOSS_VD(D2V, MW, TDV)                                                                                    \
   hipLaunchKernelGGL((loss_stream_vd_kernel<R, MM, D2V, 2, MW, TDV>), grid, blk, vlds, st, (const Cx<R>*)X,      \
                      (const Cx<R>*)W, (const R*)Tb, (const R*)V, lpart, lstride, a, p2d)
-    if (k4 && vdma) {
+#if ASSX_LAB
+    static const int vdma = lab_int("ASSX_LOSS_VDMA", 1);  // 0: the plain vector-load forms of rounds 1-2 (A/B runs)
+    if (k4 && !vdma) {
+      if (nu >= 0.0) LOSS_LAUNCH(true, true, 4, 1, 1, true);
+      else if (d2) LOSS_LAUNCH(true, true, 4, 1, 2, false);
+      else LOSS_LAUNCH(true, false, 2, 1, 1, false);
+    } else
+#endif
+    if (k4) {
       if (nu >= 0.0) LOSS_VD(true, 2, true);
       else if (d2) LOSS_VD(true, 2, false);
       else LOSS_VD(false, 1, false);
-    } else if (nu >= 0.0) {
-      if (k4) LOSS_LAUNCH(true, true, 4, 1, 1, true);
-      else LOSS_LAUNCH(false, true, 4, 1, 1, true);
-    } else if (k4 && d2) LOSS_LAUNCH(true, true, 4, 1, 2, false);
-    else if (k4) LOSS_LAUNCH(true, false, 2, 1, 1, false);
+    } else if (nu >= 0.0) LOSS_LAUNCH(false, true, 4, 1, 1, true);
     else if (d2) LOSS_LAUNCH(false, true, 4, 1, 2, false);
     else LOSS_LAUNCH(false, false, 2, 1, 1, false);
 #undef LOSS_VD
@@ -1982,7 +1999,7 @@ int assx_tilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void*
     constexpr int MM = decltype(mt)::value;
     const PowSpec p2 = make_pow(0.5);
     FlatPart fp;
-    static const int wide = env_int("ASSX_WIDE_K", 1);
+    static const bool wide = lab_int("ASSX_WIDE_K", 1) != 0;
     if (K > KU && wide) {  // n_basis > 4: P = |W x|^2 once, then the batched tNMF-type update on the matrix cores
       const WsLayout L = ws_layout(B, MM, F, T, K, dtype);
       R* pw = (R*)((char*)ws + L.map);
@@ -2024,7 +2041,7 @@ int assx_tilrma_spatial_update(assx_ctx* ctx, const void* X, void* W, const void
   return dispatch_rm(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MM = decltype(mt)::value;
-    static const int wide = env_int("ASSX_WIDE_K", 1);
+    static const bool wide = lab_int("ASSX_WIDE_K", 1) != 0;
     if (K > KU && wide)
       hipLaunchKernelGGL((tilrma_xi_wide_kernel<R, MM>), dim3(blocks_for(T, 64), blocks_for(F, WIDE_FB), B), dim3(64), 0,
                          st, (const Cx<R>*)X, (const Cx<R>*)W, (const R*)Tb, (const R*)V, (R*)Xi, Dims{B, F, T, K},
@@ -2137,17 +2154,19 @@ int assx_auxiva_weights(assx_ctx* ctx, const void* X, const void* W, int kind, d
     // index the separate finalize kernel used
     const int TBk = (int)blocks_for(T, WAVE), nblk = MM * TBk;
     const int lstride = nblk + F;
-    // ASSX_AUX_FOLD=1: finalize, log-det terms and loss sum inside the pass (3 launches per iteration instead of 4, 5 -> 3
+    // laboratory builds, ASSX_AUX_FOLD=1: finalize, log-det terms and loss sum inside the pass (3 launches per iteration instead of 4, 5 -> 3
     // with the loss).  OFF by default: measured SLOWER on MI355X -- config 3: 36.4 against 32.5 us per iteration, 40.6
     // against 39.1 with the loss (profiles/r04_auxiva_fold.txt) -- write-through records + ticket + read-back are three
     // memory round trips across the XCDs, more than a dependent launch (2.7 us) plus the 2 us finalize.  Read on every
     // call (tests run both forms in one process).
-    const int fold = env_int("ASSX_AUX_FOLD", 0);
     int* tickets = nullptr;
+#if ASSX_LAB
+    const int fold = lab_int("ASSX_AUX_FOLD", 0);
     if (fold && FS > 1) {
       const int trc = ensure_tickets(ctx, (size_t)B * TBk + B, st, &tickets);
       if (trc) return trc;  // the hipError_t of the allocation, message in ctx
     }
+#endif
     const bool folded = tickets != nullptr;
     hipLaunchKernelGGL((auxiva_stat_partial_kernel<R, MM>), dim3(TBk, FS, B), dim3(256), 0, st, (const Cx<R>*)X,
                        (const Cx<R>*)W, (R*)ws, Dims{B, F, T, 0}, FS, fchunk, tickets, (R*)r,

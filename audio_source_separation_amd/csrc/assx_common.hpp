@@ -70,6 +70,31 @@ struct NmfGroupScope {  // sets assx_ctx::nmf_group for the NMF calls made insid
 constexpr int WAVE = 64;
 
 // ------------------------------------------------------------------------------------------
+// Run-time knobs and laboratory switches.
+//
+// The shipped library reads SIX environment variables (include/assx.h lists them): ASSX_G, ASSX_NMF_BASIS_WGS,
+// ASSX_NMF_ACT_WGS, ASSX_NMF_XFED_WGS (work-partition sizes: the tests shrink / force them so that small inputs walk
+// every code path of a long range), ASSX_XFER_CHUNK_MB and ASSX_XFER_THREADS (the pinned staging ring) -- knob_int().
+// Everything else that rounds 1-5 could switch through the environment -- the variants that were measured and not kept
+// (sources-side-by-side IP sweep, folded AuxIVA statistic, one-wave-per-source wide-channel covariance, the pre-LDS-ring
+// forms of the streaming kernels, legacy partitions and launch orders) -- exists only in a LABORATORY build
+// (-DASSX_LAB=1: csrc/build.sh with ASSX_EXTRA_FLAGS; assx_version() then ends in "+lab"): lab_int() is a compile-time
+// constant otherwise, and the kernels behind those switches are not compiled.
+// ------------------------------------------------------------------------------------------
+#ifndef ASSX_LAB
+#define ASSX_LAB 0
+#endif
+inline int knob_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+#if ASSX_LAB
+inline int lab_int(const char* name, int dflt) { return knob_int(name, dflt); }
+#else
+constexpr int lab_int(const char*, int dflt) { return dflt; }
+#endif
+
+// ------------------------------------------------------------------------------------------
 // host side: argument checking / error reporting
 // ------------------------------------------------------------------------------------------
 inline int fail(assx_ctx* ctx, int code, const char* fmt, ...) {
@@ -314,6 +339,63 @@ __device__ __forceinline__ float fast_rcp(float x) {
   float r = __builtin_amdgcn_rcpf(x);
   float e = fmaf(-x, r, 1.0f);
   return fmaf(r, e, r);
+}
+
+// 1/x[0..N-1] from ONE hardware reciprocal chain (Montgomery's trick): the products of the inputs, one fast_rcp, and the
+// partial products back -- N = 4: 3 + 5 + 6 = 14 vector instructions and one transcendental instead of 20 and four.  Each
+// result carries three roundings more than fast_rcp's correctly rounded quotient (|rel err| < 2.5 ulp).  The product of
+// the inputs must stay a normal number: callers pass variances floored at eps > 0; where the product leaves
+// [1e-290, 1e290] (a lane-wise test, one v_cmp_class) the lane takes the individual reciprocals.
+#ifndef ASSX_BATCH_RCP
+#define ASSX_BATCH_RCP 0
+#endif
+template <int N>
+__device__ __forceinline__ void batch_rcp(const double (&x)[N], double (&inv)[N]) {
+  static_assert(N >= 1 && N <= 4, "batch_rcp: 1..4 values");
+  if (N == 1) {
+    inv[0] = fast_rcp(x[0]);
+  } else if (N == 2) {
+    const double p = x[0] * x[1];
+    if (__builtin_expect(p > 1e-290 && p < 1e290, 1)) {
+      const double r = fast_rcp(p);
+      inv[0] = r * x[1];
+      inv[1] = r * x[0];
+    } else {
+      inv[0] = fast_rcp(x[0]);
+      inv[1] = fast_rcp(x[1]);
+    }
+  } else if (N == 3) {
+    const double p01 = x[0] * x[1], p = p01 * x[2];
+    if (__builtin_expect(p > 1e-290 && p < 1e290, 1)) {
+      const double r = fast_rcp(p);
+      inv[2] = r * p01;
+      const double r01 = r * x[2];
+      inv[0] = r01 * x[1];
+      inv[1] = r01 * x[0];
+    } else {
+      inv[0] = fast_rcp(x[0]);
+      inv[1] = fast_rcp(x[1]);
+      inv[2] = fast_rcp(x[2]);
+    }
+  } else {
+    const double p01 = x[0] * x[1], p23 = x[2 % N] * x[3 % N], p = p01 * p23;
+    if (__builtin_expect(p > 1e-290 && p < 1e290, 1)) {
+      const double r = fast_rcp(p);
+      const double r01 = r * p23, r23 = r * p01;
+      inv[0] = r01 * x[1];
+      inv[1] = r01 * x[0];
+      inv[2 % N] = r23 * x[3 % N];
+      inv[3 % N] = r23 * x[2 % N];
+    } else {
+#pragma unroll
+      for (int i = 0; i < N; ++i) inv[i] = fast_rcp(x[i]);
+    }
+  }
+}
+template <int N>
+__device__ __forceinline__ void batch_rcp(const float (&x)[N], float (&inv)[N]) {  // float32: nothing to gain (3 instructions each)
+#pragma unroll
+  for (int i = 0; i < N; ++i) inv[i] = fast_rcp(x[i]);
 }
 
 template <typename R>

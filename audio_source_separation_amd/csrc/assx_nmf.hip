@@ -314,10 +314,6 @@ struct NmfWs {
 
 constexpr int NMF_MFMA_MAX_K = 64;
 
-inline int nmf_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 // split counts of the MFMA path (deterministic: no device query)
 inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ? ctx->nmf_group : 1; }
@@ -329,11 +325,11 @@ inline int nmf_group(const assx_ctx* ctx) { return (ctx && ctx->nmf_group > 0) ?
 constexpr int MFMA_WG_BUDGET = 512;  // two workgroups per CU (profiles/r04_nmf_wgs_sweep.txt)
 template <typename R>
 inline NmfPart mfma_basis_part(int group, int F, int T, int KT) {
-  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, nmf_env_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET));
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, group, knob_int("ASSX_NMF_BASIS_WGS", MFMA_WG_BUDGET));
 }
 template <typename R>
 inline NmfPart mfma_act_part(int group, int F, int T, int KT) {
-  return make_nmf_part((T + 15) / 16, (F + 15) / 16, group, nmf_env_int("ASSX_NMF_ACT_WGS", MFMA_WG_BUDGET));
+  return make_nmf_part((T + 15) / 16, (F + 15) / 16, group, knob_int("ASSX_NMF_ACT_WGS", MFMA_WG_BUDGET));
 }
 // split-F slabs of the loss kernel
 inline void mfma_loss_split(int group, int F, int T, int* FS, int* fchunk) {
@@ -371,10 +367,10 @@ inline NmfPart xfed_basis_part(int F, int T, int KT) {
   // three workgroups per CU where their LDS (tile double buffer + staging, < 54 KB at n_basis <= 16) allows it, two
   // otherwise (profiles/r04_xfed_wgs_sweep.txt: 256 / 384 / 512 / 640 / 768 / 1024 -> 0.253 / 0.263 / 0.227 / 0.248 /
   // 0.224 / 0.247 ms per n_basis = 10 iteration)
-  return make_nmf_part((F + 15) / 16, (T + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
+  return make_nmf_part((F + 15) / 16, (T + 15) / 16, 1, knob_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
 }
 inline NmfPart xfed_act_part(int F, int T, int KT) {
-  return make_nmf_part((T + 15) / 16, (F + 15) / 16, 1, nmf_env_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
+  return make_nmf_part((T + 15) / 16, (F + 15) / 16, 1, knob_int("ASSX_NMF_XFED_WGS", KT == 1 ? 768 : MFMA_WG_BUDGET));
 }
 constexpr int XFED_MAX_K = 32;
 
@@ -521,18 +517,18 @@ int nmf_update_small(assx_ctx* ctx, double eps, const void* X, void* Tb, void* V
   return nmf_update_small_kc<R, 4>(ctx, eps, X, Tb, V, ws, B, F, T, K, dtype, st);
 }
 inline int small_rank_max() {  // largest n_basis routed to the vector-ALU kernels (0 = never)
-  static const int v = getenv("ASSX_NMF_SMALL") ? atoi(getenv("ASSX_NMF_SMALL")) : 4;
+  static const int v = lab_int("ASSX_NMF_SMALL", 4);
   return v > SMALL_K ? SMALL_K : v;
 }
 
 template <typename R>
 int nmf_update_impl(assx_ctx* ctx, int kind, double domain, double param, double eps, const void* X, void* Tb, void* V, void* ws,
                     int B, int F, int T, int K, int dtype, hipStream_t st, double* loss_prev = nullptr) {
-  static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
+  static const int no_mfma = lab_int("ASSX_NMF_NO_MFMA", 0);
   if (loss_prev) {
     // loss of the model at entry: on the basis half where that kernel can (matrix-core path, domain 2, EUC / KL / IS), else
     // by the stand-alone pass first
-    static const int fuse = nmf_env_int("ASSX_NMF_FUSE_LOSS", 1);
+    static const int fuse = lab_int("ASSX_NMF_FUSE_LOSS", 1);
     const bool fits = (unsigned long long)F * T * sizeof(R) < (1ull << 32) && (unsigned long long)K * T * sizeof(R) < (1ull << 32);
     const bool small = K <= small_rank_max() && kind == ASSX_NMF_IS_MM && domain == 2.0;
     const bool fusable = fuse && !no_mfma && fits && !small && K <= NMF_MFMA_MAX_K && domain == 2.0 && kind <= ASSX_NMF_IS_ME;
@@ -654,7 +650,7 @@ static int nmf_half_launch(assx_ctx* ctx, const TermSpec& ts, int half, const vo
 }
 
 static bool xfed_applies(int kind, int M, int K) {
-  static const int on = nmf_env_int("ASSX_NMF_XFED", 1);  // 0: the power-map route of rounds 1-3 (A/B runs)
+  static const int on = lab_int("ASSX_NMF_XFED", 1);  // laboratory builds, 0: the power-map route of rounds 1-3 (A/B runs)
   return on && M >= 2 && M <= 4 && K <= XFED_MAX_K && (kind == ASSX_NMF_IS_MM || kind == ASSX_NMF_T_RAW);
 }
 
@@ -909,7 +905,7 @@ int assx_nmf_loss_ex(assx_ctx* ctx, int kind, double domain, double param, doubl
   double* lpart = (double*)((char*)ws + L.lpart);
   const PowSpec p2d = make_pow(2.0 / domain);
   const int k2 = (kind == ASSX_NMF_IS_ME) ? ASSX_NMF_IS_MM : kind;
-  static const int no_mfma = getenv("ASSX_NMF_NO_MFMA") ? atoi(getenv("ASSX_NMF_NO_MFMA")) : 0;
+  static const int no_mfma = lab_int("ASSX_NMF_NO_MFMA", 0);
   if (K <= NMF_MFMA_MAX_K && !no_mfma) {
     int FS, fchunk;
     mfma_loss_split(nmf_group(ctx), F, T, &FS, &fchunk);

@@ -177,10 +177,7 @@ inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
   p.nstep = nstep;
   const long long wt = (long long)nblk * nstep;
   long long G = target_wgs / (group < 1 ? 1 : group);
-  static const int aligned = [] {
-    const char* v = getenv("ASSX_NMF_ALIGNED");  // 0: round 4's flat partition (A/B runs)
-    return (v && *v) ? atoi(v) : 1;
-  }();
+  static const int aligned = lab_int("ASSX_NMF_ALIGNED", 1);  // laboratory builds, 0: round 4's flat partition (A/B runs)
   // Aligned only where a block gets at least two workgroups: with fewer the flat partition wastes nothing (a range is
   // then whole blocks plus one boundary) and keeps G inside the budget -- one workgroup per block would launch nblk of
   // them, a few more than fit at once when nblk is just above the budget (wide-channel source model: 65 blocks x 8

@@ -71,7 +71,7 @@ inline FlatPart make_flat(int B, long long NB, int len, long long G_target) {
   long long G = G_target < NB ? G_target : NB;
   if (G < 1) G = 1;
   const long long parts = G / p.Ju;
-  static const bool align = getenv("ASSX_ALIGN") == nullptr || atoi(getenv("ASSX_ALIGN")) != 0;  // A/B switch
+  static const bool align = lab_int("ASSX_ALIGN", 1) != 0;  // laboratory builds: A/B switch
   if (align && parts >= 1 && parts <= len && p.Ju * parts * 100 >= G * 97) {
     // L first, then only as many parts as are not empty (len = 31 into 31 parts of L = 2 would leave 15 parts
     // without an item: idle workgroups, and record / loss-partial slots nobody writes)
@@ -557,6 +557,9 @@ __global__ void __launch_bounds__(64, MINW)
         }
     }
     R wgt[SPL];
+#if ASSX_BATCH_RCP
+    R rfl[SPL];
+#endif
 #pragma unroll
     for (int q = 0; q < SPL; ++q) {
       if (WK == WK_NONE) {
@@ -577,9 +580,16 @@ __global__ void __launch_bounds__(64, MINW)
         } else {
           r = wq[j % DWT][q][0];
         }
+#if ASSX_BATCH_RCP
+        rfl[q] = floor_eps<R>(r, a.eps);
+#else
         wgt[q] = fast_rcp(floor_eps<R>(r, a.eps));
+#endif
       }
     }
+#if ASSX_BATCH_RCP
+    if (WK != WK_NONE) batch_rcp<SPL>(rfl, wgt);
+#endif
     if (ragged && cur.tb == TBk - 1) {  // wave-uniform: only the last block of a bin can hold idle lanes
 #pragma unroll
       for (int q = 0; q < SPL; ++q)
@@ -1031,6 +1041,20 @@ __global__ void __launch_bounds__(64, MINW)
     for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
     const R live = (t < T) ? (R)1 : (R)0;
     double lterm = 0.0, lprod = 1.0;
+#if ASSX_BATCH_RCP
+    R tvn[N], invn[N];  // every source's floored variance first: their reciprocals share one hardware reciprocal (batch_rcp)
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      R tv = 0;
+#pragma unroll
+      for (int kk = 0; kk < KU; kk += 2) {
+        tv = fma(tbr[n][kk], vv[(n * KU + kk) / 2].x, tv);
+        tv = fma(tbr[n][kk + 1], vv[(n * KU + kk) / 2].y, tv);
+      }
+      tvn[n] = floor_eps<R>(tv, a.eps);
+    }
+    batch_rcp<N>(tvn, invn);
+#endif
 #pragma unroll
     for (int n = 0; n < N; ++n) {
       Cx<R> y = cmake<R>(0, 0);
@@ -1043,12 +1067,18 @@ __global__ void __launch_bounds__(64, MINW)
         v[kk] = vv[(n * KU + kk) / 2].x;
         v[kk + 1] = vv[(n * KU + kk) / 2].y;
       }
+#if ASSX_BATCH_RCP
+      const R tv = tvn[n];
+      if (TD) P = t_harmonic<R>(P, tv, a.nu);
+      R inv = invn[n];
+#else
       R tv = 0;
 #pragma unroll
       for (int kk = 0; kk < KU; ++kk) tv = fma(tbr[n][kk], v[kk], tv);
       tv = floor_eps<R>(tv, a.eps);
       if (TD) P = t_harmonic<R>(P, tv, a.nu);
       R inv = fast_rcp(tv);                                 // TV_inverse
+#endif
       R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);   // division = P / TV**((d+2)/d)
       if (LOSS) {
         lterm += (double)(P * inv);
@@ -1708,6 +1738,18 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
       for (int m = 0; m < M; ++m) x[m] = tocx<R>(xq[j][m]);
       const Cx<R>* lw = reinterpret_cast<const Cx<R>*>(myring + j * ACT_RING_SLOT);
       const R* lt = reinterpret_cast<const R*>(myring + j * ACT_RING_SLOT + 256);
+#if ASSX_BATCH_RCP
+      R tvn[N], invn[N];  // every source's floored variance first: their reciprocals share one hardware reciprocal
+#pragma unroll
+      for (int n = 0; n < N; ++n) {
+        R tv = 0;
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) tv = fma(lt[n * KU + kk], v[n][kk], tv);
+        tvn[n] = floor_eps<R>(tv, a.eps);
+      }
+      batch_rcp<N>(tvn, invn);
+      asm volatile("" ::: "memory");  // the basis rows are read again below, one source at a time (not kept in 32 VGPRs)
+#endif
 #pragma unroll
       for (int n = 0; n < N; ++n) {
         Cx<R> y = cmake<R>(0, 0);
@@ -1715,6 +1757,13 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
         for (int m = 0; m < M; ++m) cfma(y, lw[n * M + m], x[m]);
         R P = cabs2(y);
         R tk[KU];
+#if ASSX_BATCH_RCP
+#pragma unroll
+        for (int kk = 0; kk < KU; ++kk) tk[kk] = lt[n * KU + kk];
+        const R tv = tvn[n];
+        if (TD) P = t_harmonic<R>(P, tv, a.nu);
+        const R inv = invn[n];
+#else
         R tv = 0;
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk) {
@@ -1724,6 +1773,7 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
         tv = floor_eps<R>(tv, a.eps);
         if (TD) P = t_harmonic<R>(P, tv, a.nu);
         const R inv = fast_rcp(tv);
+#endif
         const R D = D2 ? P * inv * inv : P / powspec<R>(tv, a.p1);
 #pragma unroll
         for (int kk = 0; kk < KU; ++kk) {

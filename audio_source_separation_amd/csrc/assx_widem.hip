@@ -19,17 +19,13 @@ struct Ws {
   size_t map0, map1, u, lpart, nmf, tmp, rec, total;
 };
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 // Flat partition of src_cov_kernel (assx_widem_cov.hpp): items = (utterance, bin, 64-frame block), two workgroups'
 // worth of ranges per CU (one or two are resident, depending on M and the precision: either way the ranges are equal,
 // so there is no tail).  A fixed function of the geometry -- never an occupancy query -- so the summation order is too.
 // ASSX_G forces the number of ranges (tests: long ranges on small inputs), read on every call.
 static FlatPart flat_src_cov(int B, int F, int T) {
   const int tbk = (T + WAVE - 1) / WAVE;
-  const int forced = env_int("ASSX_G", 0);
+  const int forced = knob_int("ASSX_G", 0);
   return make_flat(B, (long long)F * tbk, tbk, forced > 0 ? forced : 512);
 }
 static Ws layout(int B, int M, int F, int T, int K, int dtype) {
@@ -360,7 +356,7 @@ static int launch_cov(assx_ctx* ctx, int Mr, const void* X, const void* r, int r
     const int threads = np >= 256 ? 256 : (np + 63) / 64 * 64;
     // sources per workgroup: 4 up to 10 channels, 8 up to 14, 16 beyond (measured: profiles/r03_manychan_bench.txt;
     // ASSX_RT_NS overrides for A/B runs)
-    static const int ns_env = env_int("ASSX_RT_NS", 0);
+    static const int ns_env = lab_int("ASSX_RT_NS", 0);
     const int nsg = N <= 1 ? 1 : (ns_env > 0 ? ns_env : (Mr <= 10 ? 4 : (Mr <= 14 ? 8 : 16)));
     const int ncv = nsg <= 1 ? 1 : (nsg <= 2 ? 2 : (nsg <= 4 ? 4 : (nsg <= 8 ? 8 : 16)));
     const dim3 grid(F, ((np + threads - 1) / threads) * ((N + ncv - 1) / ncv), B);
@@ -387,11 +383,24 @@ static int launch_cov(assx_ctx* ctx, int Mr, const void* X, const void* r, int r
 template <typename R, int M, int WKV>
 static int launch_src_cov_as(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int K, double eps, void* rec,
                              const FlatPart& fp, int B, int F, int T, hipStream_t st) {
-  using GEO = SrcCovGeom<R, M, WKV>;
-  static const int pairs = env_int("ASSX_WIDEM_PAIRS", 1);  // 0: one wave per source (src_cov_kernel), A/B runs
   const Dims d{B, F, T, K};
-  if (pairs) {  // the Hermitian pairs split over the waves, weights exchanged through LDS
-    static const int lds_pad = env_int("ASSX_PAIR_LDS_PAD", 0);  // experiments: extra dynamic LDS
+#if ASSX_LAB
+  using GEO = SrcCovGeom<R, M, WKV>;
+  static const int pairs = lab_int("ASSX_WIDEM_PAIRS", 1);  // 0: one wave per source (src_cov_kernel, round 3's form), A/B runs
+  if (!pairs) {
+    if (GEO::lds_bytes > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(src_cov_kernel<R, M, WKV>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::lds_bytes);
+      if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(src_cov_kernel)");
+    }
+    hipLaunchKernelGGL((src_cov_kernel<R, M, WKV>), dim3(fp.G), dim3(WAVE * M), GEO::lds_bytes, st, (const Cx<R>*)X,
+                       (const R*)Tb, (const R*)V, (R*)rec, d, fp, (R)eps);
+    ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_kernel");
+    return 0;
+  }
+#endif
+  {  // the Hermitian pairs split over the waves, weights exchanged through LDS
+    static const int lds_pad = lab_int("ASSX_PAIR_LDS_PAD", 0);  // laboratory builds: extra dynamic LDS
     const size_t lds = pair_cov_lds_bytes<R, M, WKV>() + (size_t)lds_pad;
     if (lds > 64 * 1024) {  // > 64 KB of dynamic LDS needs the opt-in (per device: set on every launch)
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pair_cov_kernel<R, M, WKV>),
@@ -403,15 +412,6 @@ static int launch_src_cov_as(assx_ctx* ctx, const void* X, const void* Tb, const
     ASSX_LAUNCH_CHECK(ctx, "widem::pair_cov_kernel");
     return 0;
   }
-  if (GEO::lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(src_cov_kernel<R, M, WKV>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEO::lds_bytes);
-    if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(src_cov_kernel)");
-  }
-  hipLaunchKernelGGL((src_cov_kernel<R, M, WKV>), dim3(fp.G), dim3(WAVE * M), GEO::lds_bytes, st, (const Cx<R>*)X,
-                     (const R*)Tb, (const R*)V, (R*)rec, d, fp, (R)eps);
-  ASSX_LAUNCH_CHECK(ctx, "widem::src_cov_kernel");
-  return 0;
 }
 template <typename R, int M>
 static int launch_src_cov(assx_ctx* ctx, const void* X, const void* Tb, const void* V, int wk, int K, double domain,
@@ -436,7 +436,7 @@ static int launch_src_cov(assx_ctx* ctx, const void* X, const void* Tb, const vo
 // the streaming kernel addresses an utterance's X and weight arrays with 32-bit byte offsets; ASSX_WIDEM_COV=0 keeps
 // round 2's one-workgroup-per-bin kernel on materialised weights (A/B runs)
 static bool src_cov_ok(int M, int F, int T, size_t r) {  // M = 0: run-time channel count (> 8), not served
-  static const int on = env_int("ASSX_WIDEM_COV", 1);
+  static const int on = lab_int("ASSX_WIDEM_COV", 1);
   return M != 0 && on != 0 && (size_t)M * F * T * 2 * r < 0xffffffffull;
 }
 

@@ -119,10 +119,6 @@ class Pool {
   size_t n_elems_ = 0, ses_ = 0, des_ = 0;
 };
 
-int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
 
 }  // namespace
 
@@ -156,9 +152,9 @@ static int xfer_get(assx_ctx* ctx, Xfer** out) {
   Xfer* x = new Xfer();
   // ASSX_XFER_CHUNK_MB: staged bytes per chunk; ASSX_XFER_THREADS: host threads per transfer (default: a quarter of the
   // hardware threads, at most 16 -- a copy stops scaling once it saturates the memory controllers it can reach)
-  x->chunk_bytes = (size_t)(env_int("ASSX_XFER_CHUNK_MB", 16) > 0 ? env_int("ASSX_XFER_CHUNK_MB", 16) : 16) << 20;
+  x->chunk_bytes = (size_t)(knob_int("ASSX_XFER_CHUNK_MB", 16) > 0 ? knob_int("ASSX_XFER_CHUNK_MB", 16) : 16) << 20;
   unsigned hw = std::thread::hardware_concurrency();
-  int nt = env_int("ASSX_XFER_THREADS", (int)(hw / 4 > 16 ? 16 : (hw / 4 < 1 ? 1 : hw / 4)));
+  int nt = knob_int("ASSX_XFER_THREADS", (int)(hw / 4 > 16 ? 16 : (hw / 4 < 1 ? 1 : hw / 4)));
   if (nt < 1) nt = 1;
   if (nt > 64) nt = 64;
   hipError_t e = hipStreamCreateWithFlags(&x->copy, hipStreamNonBlocking);

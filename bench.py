@@ -131,10 +131,10 @@ def cov_contract_bytes(B, M, F, T, K, r, lds_ok=True):
     if K > 4:
         rpi = 2 if r == 8 else 4                      # rows per LDS-direct instruction (csrc/assx_cov_wide.hpp)
         lds = 2 * ((M * K + rpi - 1) // rpi * rpi) * 64 * r + 8 * M * K * r
-        if lds <= 144 * 1024 and os.environ.get("ASSX_COV_WIDE", "1") != "0":
+        if lds <= 144 * 1024:
             # still "weights rebuilt in-kernel"; n_basis <= 16 runs the matrix-core variance form since round 3
-            # (csrc/assx_cov_mfma.hpp; ASSX_COV_MFMA=0 keeps round 2's cov_wide_kernel)
-            mfma = K <= 16 and os.environ.get("ASSX_COV_MFMA", "1") != "0"
+            # (csrc/assx_cov_mfma.hpp)
+            mfma = K <= 16
             name = ("cov_mfma_kernel" if mfma else "cov_wide_kernel") + " (+ cov_wide_finalize_kernel)"
         else:
             # the source variance is materialised first (write N.F.T reals), then read back as (N,F,T) weights --
@@ -225,6 +225,20 @@ def config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K):
     U, iters = args.config5_utterances, args.config5_iterations
     cplx = torch.complex128 if args.dtype == "float64" else torch.complex64
     x_all = None
+    lo, hi = D.shard_range(U, world, rank)
+    # Footprint in HBM.  Rank 0 holds the whole batch twice (x_all for the scatter, y_all from the gather) next to its own
+    # block: config 5 in complex128 = 2 x 64 x 268.7 MB = 34.4 GB + a block of 8 (x_local 2.15 GB + y_local 2.15 GB + the
+    # model's workspace, < 1 GB) -- 39 GB of 288; a peer holds only its block.  Checked before anything is allocated, so
+    # that an oversized --config5-utterances fails with a message instead of an allocator error in the middle of a leg.
+    csize = 16 if cplx == torch.complex128 else 8
+    need = 2 * (hi - lo) * M * F * T * csize + (1 << 30)
+    if rank == 0 and comm_dev == dev:
+        need += 2 * U * M * F * T * csize
+    free_b, _total_b = torch.cuda.mem_get_info(dev)
+    short = need > free_b + torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+    if D.max_over_ranks(1.0 if short else 0.0, device=dev) > 0:  # every rank leaves together: nobody waits in a scatter
+        raise MemoryError("config-5 leg: some rank is short of HBM (rank %d needs %.1f GB -- x_all + y_all on the root, its "
+                          "own block, workspace -- and has %.1f GB free)" % (rank, need / 1e9, free_b / 1e9))
     if rank == 0:
         x_all = torch.empty((U, M, F, T), dtype=cplx, device=dev)
         for u0 in range(0, U, 8):  # utterance u has seed u ("64 utterances of cfg4 with seeds 0..63")
@@ -239,7 +253,6 @@ def config5_leg(args, torch, D, dev, comm_dev, rank, world, M, F, T, K):
     def factory():
         return GaussILRMA(n_basis=K, recordable_loss=False, dtype=args.dtype, device=dev)
 
-    lo, hi = D.shard_range(U, world, rank)
     # warm-up of the compute path at this batch size (workspace growth, clocks), outside every timed region
     if hi > lo:
         warm = factory()

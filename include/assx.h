@@ -43,6 +43,23 @@
  *     per stream.  Two calls that share a `ws` must be ordered by the caller (same stream or an event), as ever.
  *   - The library never changes the calling thread's current device.  The caller makes the context's device current
  *     (hipSetDevice) before every call; a call made with another device current is refused with ASSX_E_ARG.
+ *     (assx_ctx_create / assx_ctx_destroy switch to the context's device for their own allocation / wait and switch back.)
+ *   - Stream capture (hipStreamBeginCapture, torch.cuda.graph): every entry point may be captured.  The ticket words of a
+ *     stream the context has not seen come out of a pool made by assx_ctx_create, so a capture on a fresh stream needs no
+ *     allocation; a problem whose kernels need more than 8192 ticket words per stream (more than ~30 batched matrices
+ *     of 4096 frames) must run once on the capture stream before the capture begins, or the call is refused with
+ *     ASSX_E_UNSUPPORTED and a message saying so.
+ *
+ * Run-time knobs (environment variables read by the shipped library -- all of them; everything else that earlier rounds
+ * could switch through the environment exists only in laboratory builds, -DASSX_LAB=1, whose assx_version() ends in "+lab"):
+ *     ASSX_G               ranges of the flat work partition of the streaming kernels (default: 8 per CU x 256 CUs; the
+ *                          tests shrink it so that small inputs walk every code path of a long range).  Changes the
+ *                          summation order, never the semantics.  Read on every call.
+ *     ASSX_NMF_BASIS_WGS   workgroup budget of the matrix-core NMF basis half (default 512)   } the tests force
+ *     ASSX_NMF_ACT_WGS     ... of the activation half (default 512)                            } many-slab and
+ *     ASSX_NMF_XFED_WGS    ... of the X-fed source-model halves (default 768 / 512)            } ragged partitions
+ *     ASSX_XFER_CHUNK_MB   chunk size of the pinned staging ring of assx_upload / assx_download (default 16)
+ *     ASSX_XFER_THREADS    host threads of that ring (default: a quarter of the hardware threads, at most 16)
  */
 #ifndef ASSX_H
 #define ASSX_H

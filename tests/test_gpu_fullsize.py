@@ -439,12 +439,14 @@ def test_wide_channel_covariance_forms_agree_at_full_size(dtype):
     script = os.path.join(root, "tools", "probes", "paircov_check.py")
     with tempfile.TemporaryDirectory() as d:
         paths = {}
-        for mode in ("1", "0"):
+        from conftest import lab_build
+        lab = lab_build()  # src_cov_kernel (round 3's form) exists in laboratory builds only: the shipped library runs
+        for mode in ("1", "0"):  # pair_cov_kernel in two processes, which must then agree bit for bit
             paths[mode] = os.path.join(d, "u%s.npz" % mode)
             subprocess.run([sys.executable, script, "run", paths[mode], dtype], check=True, timeout=900,
                            env=dict(os.environ, ASSX_WIDEM_PAIRS=mode), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         a, b = np.load(paths["1"]), np.load(paths["0"])
-        tol = 1e-10 if dtype == "float64" else 1e-3
+        tol = (1e-10 if dtype == "float64" else 1e-3) if lab else 0.0
         for k in a.files:
             dd = np.abs(a[k] - b[k]).max(axis=(-1, -2)) / np.abs(b[k]).max(axis=(-1, -2))
-            assert dd.max() < tol, (k, float(dd.max()), int((dd > tol).sum()))
+            assert dd.max() <= tol, (k, float(dd.max()), int((dd > tol).sum()))

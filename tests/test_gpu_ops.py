@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import load_golden, need_lab, rel_err
 from oracle import oracle_np as orc
 
 pytestmark = pytest.mark.gpu
@@ -98,6 +98,8 @@ def test_cov_batched_matches_single(eng):
 @pytest.mark.parametrize("ip_par", ["0", "1"])
 @pytest.mark.parametrize("M,F,T", SHAPES[:3])
 def test_ip_update(eng, M, F, T, ip_par, monkeypatch):
+    if ip_par != "0":
+        need_lab("ASSX_IP_PAR")
     monkeypatch.setenv("ASSX_IP_PAR", ip_par)
     X, W = mixture(M, F, T, 7), rand_filters(M, F, 8)
     r = np.random.default_rng(9).random((M, T)) + 0.05
@@ -113,7 +115,10 @@ def test_ip_update(eng, M, F, T, ip_par, monkeypatch):
 @pytest.mark.parametrize("ip_par", ["0", "1"])
 def test_ip_cond_guard_and_singular(ip_par, monkeypatch):
     """cond(WU) >= threshold keeps the row (ilrma.py:520-528); an exactly singular WU flags LinAlgError.
-    ip_par = 1: the sources-side-by-side form of the sweep (ASSX_IP_PAR, csrc/assx_group_linalg.hpp: ip_par_kernel)."""
+    ip_par = 1 (laboratory builds): the sources-side-by-side form of the sweep (ASSX_IP_PAR, csrc/assx_group_linalg.hpp:
+    ip_par_kernel)."""
+    if ip_par != "0":
+        need_lab("ASSX_IP_PAR")
     monkeypatch.setenv("ASSX_IP_PAR", ip_par)
     from audio_source_separation_amd import _lib
     from audio_source_separation_amd.ops import Engine
@@ -426,6 +431,8 @@ def test_auxiva_weights_and_loss(eng, kind, M, F, T, fold, monkeypatch):
     """fold = 1: the statistic's finalize, the log-det terms and the loss sum inside the pass behind tickets
     (ASSX_AUX_FOLD, off by default: measured slower than the separate launches, profiles/r04_auxiva_fold.txt)."""
     from audio_source_separation_amd import _lib
+    if fold != "0":
+        need_lab("ASSX_AUX_FOLD")
     monkeypatch.setenv("ASSX_AUX_FOLD", fold)
     X, W = mixture(M, F, T, 60), rand_filters(M, F, 61)
     code = _lib.IVA_LAPLACE if kind == "laplace" else _lib.IVA_GAUSS

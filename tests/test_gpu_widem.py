@@ -297,7 +297,10 @@ def test_source_model_without_loss(eng, M, K, G):
 
 def test_pair_and_source_forms_of_the_covariance_agree():
     """The two streaming forms of the wide-channel covariance (pairs split over the waves: default; one wave per source:
-    ASSX_WIDEM_PAIRS=0, read once per process) give the same U up to the rounding of their different product order."""
+    ASSX_WIDEM_PAIRS=0, read once per process; laboratory builds only) give the same U up to the rounding of their different
+    product order."""
+    from conftest import need_lab
+    need_lab("ASSX_WIDEM_PAIRS")
     import os
     import subprocess
     import sys
