@@ -872,6 +872,11 @@ inline long long g_target(int wgs_per_cu) {
 
 inline int tblocks(int T) { return (T + WAVE - 1) / WAVE; }
 
+// Depth of the X register ring of the n_basis <= 4 covariance / basis passes: 2.  Three slots (231 / 216 VGPRs, the basis
+// pass giving up its two demixing rows in VGPRs for them) were measured in round 6 on one box, alternating libraries: one
+// utterance 5601-5641 -> 5544-5574 (covariance only) / 5444-5537 it/s (both), eight utterances per launch 5515-5530 ->
+// 5523-5538 / 5502-5532 utterance-it/s (profiles/r06_ring_depth_ab.txt): more bytes in flight buy nothing beyond the
+// Infinity Cache either -- the passes are not waiting for memory.
 // cov_stream_kernel: 1 wave per workgroup, 2 waves/SIMD; blocks of 64/LS frames
 template <typename R, int M>
 constexpr int cov_lane_split() { return 1; }

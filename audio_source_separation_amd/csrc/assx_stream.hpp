@@ -607,11 +607,11 @@ __global__ void __launch_bounds__(64, MINW)
     // each Hermitian product is formed once and fanned into every source's accumulator right away, so the
     // M*M products are never all live
     if (VD) {
-      // slot `it` was refilled DXT blocks ago; younger: per block in between one tile + one X block, plus the tile
-      // just requested
+      // slot `it` was refilled DXT blocks ago; younger: the X blocks of the DXT - 1 slots behind it and the tiles still
+      // in flight -- tile it + 1 and the tile just requested, whatever DXT is (tiles up to `it` have been waited for)
       // (first trip: the slot was filled by the prologue, followed only by the other slots' X blocks)
       if (FIRST) wait_slot<(DXT - 1) * M + VT::NI>(xq[j]);
-      else if (STEADY) wait_slot<(DXT - 1) * (VT::NI + M) + VT::NI>(xq[j]);
+      else if (STEADY) wait_slot<(DXT - 1) * M + VDMA_SLOTS * VT::NI>(xq[j]);
       else wait_slot<0>(xq[j]);
     }
     {
@@ -1033,7 +1033,7 @@ __global__ void __launch_bounds__(64, MINW)
     }
     // X slot `it` (refilled DXT blocks ago)
     if (FIRST) wait_slot<(DXT - 1) * M + VT::NI>(xq[j]);
-    else if (STEADY) wait_slot<(DXT - 1) * (VT::NI + M) + VT::NI>(xq[j]);
+    else if (STEADY) wait_slot<(DXT - 1) * M + VDMA_SLOTS * VT::NI>(xq[j]);
     else wait_slot<0>(xq[j]);
 
     Cx<R> x[M];
@@ -1439,7 +1439,7 @@ __global__ void __launch_bounds__(64, MINW)
         advance(pw, TBk, F);
       }
       if (FIRST) wait_slot<(DXT - 1) * M + VT::NI>(xq[j]);
-      else if (STEADY) wait_slot<(DXT - 1) * (VT::NI + M) + VT::NI>(xq[j]);
+      else if (STEADY) wait_slot<(DXT - 1) * M + VDMA_SLOTS * VT::NI>(xq[j]);
       else wait_slot<0>(xq[j]);
       Cx<R> x[M];
 #pragma unroll

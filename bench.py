@@ -77,6 +77,11 @@ def parse():
     p.add_argument("--prewarm-ms", type=float, default=150.0,
                    help="untimed load before the W warm-up steps: the clocks take ~100 ms of work to settle "
                         "(20 timed steps after 5 / 50 / 500 warm-up steps: 0.2025 / 0.1986 / 0.1945 ms per step)")
+    p.add_argument("--measure-traffic", type=int, default=1,
+                   help="1 (default; rank 0 at N = 1, after every timed leg): HBM traffic of the covariance kernel from two "
+                        "rocprofv3 --pmc passes of tools/microbench.py run as child processes (FETCH_SIZE, WRITE_SIZE; "
+                        "tools/pmc_traffic.py: measure_case) -> roofline.traffic of THIS run; falls back to "
+                        "profiles/cov_traffic.json when rocprofv3 is missing or fails (traffic_source says which)")
     p.add_argument("--config5", default="auto", choices=["auto", "on", "off"],
                    help="config-5 leg (64 utterances sharded over the ranks); auto = only when N > 1")
     p.add_argument("--config5-utterances", type=int, default=64)
@@ -517,6 +522,30 @@ def main():
     torch.cuda.empty_cache()
     if args.with_other_configs and rank == 0 and args.dtype == "float64":
         extra["other_configs"] = other_configs_leg(torch, dev)
+
+    # ---------------- HBM traffic of the roofline kernel, measured now (every timed leg is over: the child processes and
+    # their counters cannot disturb a figure above)
+    if (rank == 0 and n_gpus == 1 and args.measure_traffic and roofline is not None and (M, F, T) == (4, 1025, 4096)
+            and K in (4, 10) and B == 1):
+        try:
+            import importlib.util
+            import shutil
+            import tempfile
+            if shutil.which("rocprofv3") is None:
+                raise RuntimeError("rocprofv3 not on PATH")
+            spec = importlib.util.spec_from_file_location("pmc_traffic", os.path.join(ROOT, "tools", "pmc_traffic.py"))
+            pt = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(pt)
+            with tempfile.TemporaryDirectory(dir="/tmp") as wd:
+                rec = pt.measure_case("k4" if K <= 4 else "k10", args.dtype, wd)
+            if rec:
+                roofline["traffic"] = int(round(rec["traffic_bytes"]))
+                roofline["traffic_source"] = ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two "
+                                              "child processes of tools/microbench.py, %d / %d launches averaged), x1024, fetch x2 "
+                                              "(MI355X_MICROARCH.md, HBM section)" % tuple(rec["launches_averaged"]))
+                roofline["traffic_over_algorithmic"] = round(rec["traffic_bytes"] / roofline["algorithmic_bytes"], 4)
+        except Exception as exc:  # the committed figure stays, labelled as such
+            roofline["traffic_live_error"] = "%s: %s" % (type(exc).__name__, str(exc)[:200])
 
     # ---------------- CPU baseline: the NumPy oracle on the same workload (rank 0, N=1 only)
     cpu_baseline = None

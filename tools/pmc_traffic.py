@@ -25,9 +25,24 @@ OUT = os.path.join(ROOT, "gpurun_out")
 
 # (tag, n_basis, kernel-name substring, channels, microbench entry).  k10: cov_mfma_kernel since round 3 (the records'
 # finalize is a separate kernel and not part of the figure); m8: the wide-channel streaming covariance inside one spatial
-# update (pair_cov_kernel; contract bytes M F T c + (N F K + N K T) r + N F M^2 c with M = N = 8)
+# update (pair_cov_kernel; contract bytes M F T c + (N F K + N K T) r + N F M^2 c with M = N = 8); round 6: the two
+# streaming passes of the source model (n_basis <= 4), the other 52 % of the headline iteration
 CASES = (("k4", 4, "cov_stream_kernel", 4, "cov TV"), ("k10", 10, "cov_mfma_kernel", 4, "cov TV"),
-         ("m8", 4, "pair_cov_kernel", 8, "ilrma_spatial_update"))
+         ("m8", 4, "pair_cov_kernel", 8, "ilrma_spatial_update"),
+         ("basis", 4, "basis_stream_vd_kernel", 4, "ilrma_source_update"),
+         ("act", 4, "act_stream_vd_kernel", 4, "ilrma_source_update"))
+
+
+def contract_bytes(tag, M, K, r, F=1025, T=4096):
+    """Algorithmic bytes of one launch (c = 2 r): what the pass must read and write once."""
+    c, N = 2 * r, M
+    x = M * F * T * c
+    if tag in ("basis", "act"):
+        model = N * K * T * r + F * N * M * c + N * F * K * r  # activation, demixing filters, basis: each read once
+        if tag == "basis":  # records [workgroup][slot][n][k][num|den]: 2048 ranges x 2 slots at config 4
+            return x + model + 2048 * 2 * N * 2 * K * r
+        return x + model + 512 * N * 2 * K * 64 * r  # records [workgroup][n][k][num|den][64 frames], 512 aligned ranges
+    return x + (M * F * K + M * K * T) * r + M * F * M * M * c
 
 
 def collect():
@@ -40,6 +55,32 @@ def collect():
                        sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "--only", only, "--reps", "5",
                        "--dtype", dtype, "--K", str(K), "--M", str(M)]
                 subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def measure_case(tag, dtype, workdir, timeout=180):
+    """One case, both counters, into `workdir` (bench.py calls this at the end of its run so that roofline.traffic is a figure
+    of THAT run and box): {"traffic_bytes", "fetch_bytes_raw", "write_bytes_raw", ...} or None."""
+    case = [c for c in CASES if c[0] == tag][0]
+    _, K, ksub, M, only = case
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        d = os.path.join(workdir, "%s_%s_%s" % (name, tag, dtype))
+        cmd = ["rocprofv3", "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "p", "--",
+               sys.executable, os.path.join(ROOT, "tools", "microbench.py"), "--only", only, "--reps", "5",
+               "--dtype", dtype, "--K", str(K), "--M", str(M)]
+        subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                       timeout=timeout)
+        v, n = _mean_counter(d, ctr, ksub)
+        if v is None:
+            return None
+        vals[name] = (v, n)
+    fetch_raw, write_raw = vals["fetch"][0] * 1024.0, vals["write"][0] * 1024.0
+    r = 8 if dtype == "float64" else 4
+    contract = contract_bytes(tag, M, K, r)
+    return {"traffic_bytes": fetch_raw * 2.0 + write_raw, "fetch_bytes_raw": fetch_raw, "write_bytes_raw": write_raw,
+            "fetch_correction": 2.0, "launches_averaged": [vals["fetch"][1], vals["write"][1]], "kernel": ksub,
+            "contract_bytes": contract, "traffic_over_contract": round((fetch_raw * 2.0 + write_raw) / contract, 4)}
 
 
 def _mean_counter(d, counter, kernel_substr):
@@ -71,15 +112,18 @@ def report():
                 "fetch_bytes_raw": fetch_raw, "write_bytes_raw": write_raw,
                 "fetch_correction": corr,
                 "traffic_bytes": fetch_raw * corr + write_raw,
-                "collected": "%s, %s" % (os.environ.get("ASSX_ROUND", "round 5"), datetime.date.today().isoformat()),
+                "collected": "%s, %s" % (os.environ.get("ASSX_ROUND", "round 6"), datetime.date.today().isoformat()),
                 "note": "FETCH_SIZE x1024 x%g (gfx950 counts 128 B requests as 64 B on coalesced streaming reads; x2 "
                         "from MI355X_MICROARCH.md for 16 B/lane, re-calibrated on the known X byte count for 8 B/lane) "
                         "+ WRITE_SIZE x1024 (uncalibrated, <1%% of the total)" % corr,
             }
             r = 8 if dtype == "float64" else 4
-            rec["contract_bytes"] = M * 1025 * 4096 * 2 * r + (M * 1025 * K + M * K * 4096) * r + M * 1025 * M * M * 2 * r
+            rec["contract_bytes"] = contract_bytes(tag, M, K, r)
             rec["traffic_over_contract"] = round(rec["traffic_bytes"] / rec["contract_bytes"], 4)
-            if M > 4:
+            if tag in ("basis", "act"):
+                rec["workload"] = "%s (source model pass, n_basis %d), M=%d F=1025 T=4096, one launch" % (ksub, K, M)
+                out.setdefault("%s_pass" % tag, {})[dtype] = rec
+            elif M > 4:
                 out.setdefault("widem_m%d" % M, {})[dtype] = rec
             elif K <= 4:
                 out[dtype] = rec
