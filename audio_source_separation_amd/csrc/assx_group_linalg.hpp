@@ -158,6 +158,111 @@ __device__ __forceinline__ Cd group_gj_inverse(Cd a, int i, int j, bool& singula
   return group_shfl<GW>(a, i * M + jj);
 }
 
+// In-group ADJUGATE (round 6), 2 <= M <= 4: adj[i][j] = cofactor(j, i) -- every lane its own cofactor from the elements it
+// fetches in ONE round of in-group shuffles (all independent) -- and det = sum_i a[j][i] adj[i][j] by two rotations of the
+// group.  A^-1 = adj / det.  The Gauss-Jordan form above is M pivot steps of ~28 DEPENDENT float64 operations and two shuffle
+// round trips each, a complex reciprocal in every one of them; a per-bin sweep is a single dependent chain on an otherwise
+// idle SIMD (~32 cycles per dependent instruction), so its time IS that depth.  The IP step needs only the DIRECTION of
+// column n of the inverse (the new row is normalised by sqrt(w^H U w)): column n of the adjugate, ~8 operations and one round
+// trip deep, no reciprocal at all.  No pivoting, hence no a-priori error bound: ip_group_kernel checks the backward error
+// of that column a posteriori, A adj[:, n] = det e_n, and runs the pivoted elimination for the bins that fail
+// (group_adj_column_ok).
+// MEASURED in round 6 and NOT the default (profiles/r06_ip_adjugate_ab.txt): the sweep kernel is not only a dependent chain,
+// it is also ~1700 instructions issued by ONE wave per SIMD at ~8 cycles each -- the column check, the guard's inverse
+// adj / det and the phase of det that the normalised row needs (conj(x) / sqrt(x^H U x) keeps the phase of a complex scale)
+// add back most of what the elimination's four reciprocal chains cost.  Headline, alternating libraries on one box:
+// 5576-5653 it/s with the elimination, 5613-5649 with this form (float64); float32 models 8819-9020 -> 8412-8438: their
+// W U_n fail the column check in many bins, and a wave with one such bin runs BOTH forms -- the kernel ends with its
+// slowest wave.  (On the headline input kappa_F(W U_n) grows to 1e8 ... 1e11 as the model converges -- one small singular
+// value, the case the adjugate handles well -- tools/probes/ip_cond_hist.py.)  Kept for A/B builds: -DASSX_IP_ADJ=1.
+#ifndef ASSX_IP_ADJ
+#define ASSX_IP_ADJ 0
+#endif
+#if ASSX_IP_ADJ
+template <int M, int GW>
+__device__ __forceinline__ Cd group_adjugate(Cd a, int i, int j, bool active, Cd& det) {
+  static_assert(M >= 2 && M <= 4, "closed-form adjugate: 2 <= M <= 4");
+  Cd adj;
+  if constexpr (M == 2) {
+    // adj[i][j] = (-1)^(i+j) a[1-j][1-i]: lane (i, j) = 2 i + j reads lane 2 (1-j) + (1-i): quad_perm [3, 1, 2, 0]
+    const Cd p = cmake<double>(dpp_mov<3 | (1 << 2) | (2 << 4) | (0 << 6)>(a.x), dpp_mov<3 | (1 << 2) | (2 << 4) | (0 << 6)>(a.y));
+    adj = (i != j) ? cmake<double>(-p.x, -p.y) : p;
+  } else if constexpr (M == 3) {
+    // cyclic indices carry the sign: adj[i][j] = a[j+1][i+1] a[j+2][i+2] - a[j+1][i+2] a[j+2][i+1]  (indices mod 3)
+    const int r1 = (j + 1) % 3, r2 = (j + 2) % 3, c1 = (i + 1) % 3, c2 = (i + 2) % 3;
+    const Cd e11 = group_shfl<GW>(a, r1 * 3 + c1), e22 = group_shfl<GW>(a, r2 * 3 + c2);
+    const Cd e12 = group_shfl<GW>(a, r1 * 3 + c2), e21 = group_shfl<GW>(a, r2 * 3 + c1);
+    const Cd p = cmul(e11, e22), q = cmul(e12, e21);
+    adj = cmake<double>(p.x - q.x, p.y - q.y);
+  } else {
+    // the 3 x 3 minor without row j and column i, rows / columns in ascending order; sign (-1)^(i+j)
+    int r[3], c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      r[k] = k + (k >= j ? 1 : 0);
+      c[k] = k + (k >= i ? 1 : 0);
+    }
+    Cd e[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+      for (int l = 0; l < 3; ++l) e[k][l] = group_shfl<GW>(a, r[k] * 4 + c[l]);
+    auto m2 = [&](int l0, int l1) {  // rows 1, 2; columns l0, l1
+      const Cd p = cmul(e[1][l0], e[2][l1]), q = cmul(e[1][l1], e[2][l0]);
+      return cmake<double>(p.x - q.x, p.y - q.y);
+    };
+    const Cd t0 = cmul(e[0][0], m2(1, 2)), t1 = cmul(e[0][1], m2(0, 2)), t2 = cmul(e[0][2], m2(0, 1));
+    const Cd m = cmake<double>(t0.x - t1.x + t2.x, t0.y - t1.y + t2.y);
+    adj = ((i + j) & 1) ? cmake<double>(-m.x, -m.y) : m;
+  }
+  // det = sum_i a[j][i] adj[i][j] (expansion along row j), over the lanes (i, j) of this lane's column j
+  const Cd at = group_shfl<GW>(a, j * M + i);
+  Cd t = cmul(at, adj);
+  if (!active) t = cmake<double>(0.0, 0.0);
+  if constexpr (M == 4) {  // lanes i * 4 + j, i = 0..3: the lanes 4, 8, 12 further round the 16-lane row
+    t = cmake<double>(t.x + dpp_mov<DPP_ROW_ROR + 8>(t.x), t.y + dpp_mov<DPP_ROW_ROR + 8>(t.y));
+    det = cmake<double>(t.x + dpp_mov<DPP_ROW_ROR + 4>(t.x), t.y + dpp_mov<DPP_ROW_ROR + 4>(t.y));
+  } else if constexpr (M == 2) {  // lanes j and 2 + j of the quad
+    det = cmake<double>(t.x + dpp_mov<DPP_QUAD_XOR2>(t.x), t.y + dpp_mov<DPP_QUAD_XOR2>(t.y));
+  } else {
+    const Cd s0 = group_shfl<GW>(t, j), s1 = group_shfl<GW>(t, 3 + j), s2 = group_shfl<GW>(t, 6 + j);
+    det = cmake<double>(s0.x + s1.x + s2.x, s0.y + s1.y + s2.y);
+  }
+  det = group_bcast<GW, 0>(det);  // one value for the whole matrix (the M column sums differ in their last bits)
+  return adj;
+}
+// sum over the lanes (i, 0..M-1) of this lane's matrix row
+template <int M, int GW>
+__device__ __forceinline__ double group_row_sum(double v, int i) {
+  if constexpr (M == 4) {  // a row is a quad
+    v += dpp_mov<DPP_QUAD_XOR1>(v);
+    return v + dpp_mov<DPP_QUAD_XOR2>(v);
+  } else if constexpr (M == 2) {  // a row is half a quad
+    return v + dpp_mov<DPP_QUAD_XOR1>(v);
+  } else {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < M; ++k) s += __shfl(v, i * M + k, GW);
+    return s;
+  }
+}
+// Is column n of the adjugate an acceptable solution of  A x = det e_n ?  wj = adj[j][n] at lane (i, j).  Normwise backward
+// error  ||A x - det e_n||_2 <= 1e-14 ||A||_F ||x||_2  (the pivoted elimination reaches ~1e-16; a cofactor column that lost
+// digits to cancellation -- several small singular values -- fails by orders of magnitude), every quantity a finite normal
+// number.  NaN fails.
+template <int M, int GW>
+__device__ __forceinline__ bool group_adj_column_ok(Cd a, Cd wj, Cd det, int i, int n, bool active) {
+  const Cd t = active ? cmul(a, wj) : cmake<double>(0.0, 0.0);
+  Cd r = cmake<double>(group_row_sum<M, GW>(t.x, i), group_row_sum<M, GW>(t.y, i));  // (A x)[i], in every lane of row i
+  if (i == n) r = cmake<double>(r.x - det.x, r.y - det.y);
+  const double rr = group_sum<GW>(active ? cabs2(r) : 0.0);    // M ||r||^2
+  const double xx = group_sum<GW>(active ? cabs2(wj) : 0.0);   // M ||x||^2
+  const double aa = group_sum<GW>(active ? cabs2(a) : 0.0);    // ||A||_F^2
+  const double bound = 1e-28 * aa * xx;
+  return rr <= bound && bound > 1e-280 && bound < 1e280 && xx < 1e280 && aa < 1e280;
+}
+#endif  // ASSX_IP_ADJ
+
 // Largest singular value of the M x M matrix whose element (i, j) lives in lane (i, j) of the group: lambda_max of
 // the Gram matrix by repeated squaring with trace normalisation, every product made of in-group shuffles.  Same
 // arithmetic as spectral_norm_slow (assx_small_linalg.hpp) but with NO per-lane arrays: the single-thread form keeps
@@ -258,9 +363,11 @@ __device__ __forceinline__ bool group_cond_band(Cd a0, Cd ainv, int i, int j, bo
 // cond_2(A) < thr from A (a0) and its inverse (ainv), element (i, j) per lane: Frobenius bounds, exact spectral
 // norms only inside the factor-M band (rare; whole groups take the slow path together).
 template <int M, int GW>
-__device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bool singular, double thr) {
+__device__ __forceinline__ bool group_cond_below(Cd a0, Cd ainv, bool active, bool singular, double thr,
+                                                 double* frob2 = nullptr /* out: ||A||_F^2 ||A^-1||_F^2 */) {
   const double nA2 = group_sum<GW>(active ? cabs2(a0) : 0.0);
   const double nI2 = group_sum<GW>(active ? cabs2(ainv) : 0.0);
+  if (frob2) *frob2 = nA2 * nI2;
   // compared as squares: the two square roots would sit in the middle of the sweep's dependent chain
   // (outside the range where the product of the squared norms is a normal number: the square-root form)
   double c2 = nA2 * nI2, thr2 = thr * thr, m2 = (double)(M * M);
@@ -383,21 +490,73 @@ __global__ void __launch_bounds__(64)
       cfma(a, group_row_bcast<M, GW, k>(w, i), group_shfl<GW>(u, k * M + j));
     });
     const Cd a0 = a;
-    bool singular = false;
-    a = group_gj_inverse<M, GW>(a, i, j, singular);
-    // ---- w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den
-    const Cd wi = group_row_bcast_rt<M, GW>(a, i, n);
-    const Cd wj = group_shfl<GW>(a, j * M + n);
-    Cd term = cmul(cmul(cconj(wi), u), wj);
-    if (!active) term = cmake<double>(0.0, 0.0);
-    const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
-    Cd den = csqrt_fast(q);
-    if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
-    const Cd wnew = cdiv_fast(cconj(wj), den);
-    // ---- cond_2(WU) < threshold ?  LAST in program order (round 4): its two norm sums depend only on a0 and the inverse, and
-    // an in-order wave overlaps them with the chain above only if they sit in the same basic block -- i.e. ahead of the
-    // wave vote of the guard's slow path; evaluated first, they stood in front of the row's whole chain.
-    const bool ok = group_cond_below<M, GW>(a0, a, active, singular, thr);
+    bool singular = false, ok = false;
+    Cd wnew = cmake<double>(0.0, 0.0);
+    // everything behind the inverse: w = (WU)^{-1} e_n ; den = sqrt(w^H U_n w) ; W[n,:] = conj(w) / den ; the guard
+    auto finish = [&](Cd inv, bool sing, Cd& wnew_o, bool& ok_o, double* frob2) {
+      const Cd wi = group_row_bcast_rt<M, GW>(inv, i, n);
+      const Cd wj = group_shfl<GW>(inv, j * M + n);
+      Cd term = cmul(cmul(cconj(wi), u), wj);
+      if (!active) term = cmake<double>(0.0, 0.0);
+      const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
+      Cd den = csqrt_fast(q);
+      if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);  // t-ILRMA only (ilrma.py:974-975); Gauss: floor 0
+      wnew_o = cdiv_fast(cconj(wj), den);
+      // ---- cond_2(WU) < threshold ?  LAST in program order (round 4): its two norm sums depend only on a0 and the inverse,
+      // and an in-order wave overlaps them with the chain above only if they sit in the same basic block -- i.e. ahead of
+      // the wave vote of the guard's slow path; evaluated first, they stood in front of the row's whole chain.
+      ok_o = group_cond_below<M, GW>(a0, inv, active, sing, thr, frob2);
+    };
+#if ASSX_IP_ADJ
+    if constexpr (M <= 4) {
+      // Column n of the ADJUGATE gives the direction of w = (WU)^{-1} e_n at a third of the elimination's dependent depth,
+      // and the new row conj(w) / sqrt(w^H U w) does not depend on its scale: no reciprocal of the determinant on the
+      // chain (a floor on the normaliser -- t-ILRMA, FastMNMF -- does depend on it: those callers pay the reciprocal).
+      // Off the chain, in the same basic block: the backward error of the column (group_adj_column_ok) and the guard,
+      // from adj / det.  A wave with a bin that fails the check (or whose determinant is 0 / not finite: a singular W U_n)
+      // runs the pivoted elimination as well and those groups take ITS result, flag and decision -- the reference's zgesv
+      // is pivoted too, and its LinAlgError comes from there.
+      Cd det;
+      const Cd adj = group_adjugate<M, GW>(a0, i, j, active, det);
+      Cd wi = group_row_bcast_rt<M, GW>(adj, i, n);
+      Cd wj = group_shfl<GW>(adj, j * M + n);
+      const Cd idet = crcp_fast(det);
+      // x = det w: conj(x) / sqrt(x^H U x) = (conj(det) / |det|) conj(w) / sqrt(w^H U w) -- the modulus of det drops out,
+      // its PHASE does not: the row is turned back by det / |det| at the end (one product; the factor is formed off the chain)
+      const double dn2 = cabs2(det);
+      const double rdn = rsqrt(dn2);
+      const Cd phase = cmake<double>(det.x * rdn, det.y * rdn);
+      if (den_floor > 0.0) {  // wave-uniform: the floor needs w itself
+        wi = cmul(wi, idet);
+        wj = cmul(wj, idet);
+      }
+      Cd term = cmul(cmul(cconj(wi), u), wj);
+      if (!active) term = cmake<double>(0.0, 0.0);
+      const Cd q = cmake<double>(group_sum<GW>(term.x), group_sum<GW>(term.y));
+      Cd den = csqrt_fast(q);
+      if (den.x < den_floor) den = cmake<double>(den_floor, 0.0);
+      wnew = cdiv_fast(cconj(wj), den);
+      if (!(den_floor > 0.0)) wnew = cmul(wnew, phase);
+      double c2 = 0.0;
+      ok = group_cond_below<M, GW>(a0, cmul(adj, idet), active, false, thr, &c2);
+      const bool good = group_adj_column_ok<M, GW>(a0, group_shfl<GW>(adj, j * M + n), det, i, n, active) && c2 < 1e300 &&
+                        q.x > 1e-280 && q.x < 1e280 && dn2 > 1e-280 && dn2 < 1e280;  // false for NaN
+      if (__any(!good)) {
+        bool sing_g = false, ok_g = false;
+        Cd wnew_g;
+        finish(group_gj_inverse<M, GW>(a0, i, j, sing_g), sing_g, wnew_g, ok_g, nullptr);
+        if (!good) {
+          wnew = wnew_g;
+          ok = ok_g;
+          singular = sing_g;
+        }
+      }
+    } else
+#endif
+    {
+      a = group_gj_inverse<M, GW>(a, i, j, singular);
+      finish(a, singular, wnew, ok, nullptr);
+    }
     if (singular) flags |= ASSX_STATUS_SINGULAR;       // numpy.linalg.solve raises here
     else if (!ok) flags |= ASSX_STATUS_COND_REJECT;    // keep the old row (np.where(condition, ..., w_n_Hermite))
     if (ok && !singular && i == n) w = wnew;

@@ -374,7 +374,28 @@ inline NmfPart xfed_act_part(int F, int T, int KT) {
 }
 constexpr int XFED_MAX_K = 32;
 
+inline NmfWs nmf_ws_compute(int B, int F, int T, int K, int dtype);
+// The layout is a pure function of the shape and of the three partition knobs; it is asked for by every update / loss call,
+// inside the one-call loops too, and enumerates ~70 partitions: the last answer of the calling thread is kept (round 5's
+// advisor: ~3.5 us per call against ~15 us per update at config 1).  The knobs must not change between
+// assx_nmf_workspace_bytes and the calls that use the buffer it sized -- the launchers compare their slab counts with the
+// layout, not with the caller's real allocation.
 inline NmfWs nmf_ws(int B, int F, int T, int K, int dtype) {
+  struct Key {
+    int B, F, T, K, dtype, kb, ka, kx;
+  };
+  const Key key{B, F, T, K, dtype, knob_int("ASSX_NMF_BASIS_WGS", -1), knob_int("ASSX_NMF_ACT_WGS", -1),
+                knob_int("ASSX_NMF_XFED_WGS", -1)};
+  thread_local Key last{};
+  thread_local NmfWs last_ws{};
+  thread_local bool have = false;
+  if (have && memcmp(&last, &key, sizeof(Key)) == 0) return last_ws;
+  last_ws = nmf_ws_compute(B, F, T, K, dtype);
+  last = key;
+  have = true;
+  return last_ws;
+}
+inline NmfWs nmf_ws_compute(int B, int F, int T, int K, int dtype) {
   const size_t r = dtype == ASSX_F64 ? 8 : 4;
   NmfWs w;
   w.ab = 0;

@@ -206,6 +206,15 @@ inline NmfPart make_nmf_part(int nblk, int nstep, int group, int target_wgs) {
   return p;
 }
 
+// (target + eps) / (input + eps) of the divergences (criterion/divergence.py:26-27, 39-40).  The hardware reciprocal + two
+// Newton steps is the correctly rounded quotient for a normal denominator; outside that range (eps = 0 with a zero model
+// entry: a denominator of 0) the Newton step would turn the reference's inf into NaN (fma(-0, inf, 1)), so those lanes take
+// the IEEE division (round 5's advisor).
+__device__ __forceinline__ double loss_ratio(double tg, double in) {
+  if (__builtin_expect(in > 1e-290 && in < 1e290, 1)) return tg * fast_rcp(in);
+  return tg / in;
+}
+
 #ifndef NMF_TRACE
 #define NMF_TRACE 0  // 1: shader-clock stamps of the basis half (tools/probes/nmf_trace.py): every workgroup's entry / exit on the
                      // 100 MHz clock, every step of the waves of workgroup NMF_TRACE_WG on the shader clock
@@ -465,12 +474,18 @@ __global__ void __launch_bounds__(256)
             lacc = fma(xx - in, xx - in, lacc);
           } else {
             const double in_ = in + leps, tg_ = xx + leps;  // divergence.py:26-27, 39-40
-            const double ratio = tg_ * fast_rcp(in_);
+            const double ratio = loss_ratio(tg_, in_);
             if (D2K == ASSX_NMF_KL) {
               lacc += tg_ * log(ratio) + in_ - tg_;
             } else {
               lacc += ratio - 1.0;
               lprod *= ratio;
+              if (r == 1) {  // mantissa / exponent after every PAIR of ratios: four of them beyond 1e+-77 each would leave the range
+                int e2;
+                lm = frexp(lm * lprod, &e2);
+                le += e2;
+                lprod = 1.0;
+              }
             }
           }
         }
@@ -881,12 +896,18 @@ __global__ void __launch_bounds__(256)
           if (live) acc = fma(xx - in, xx - in, acc);
         } else {
           const double in_ = in + eps, tg_ = xx + eps;  // divergence.py:26-27, 39-40
-          const double ratio = live ? tg_ * fast_rcp(in_) : 1.0;
+          const double ratio = live ? loss_ratio(tg_, in_) : 1.0;
           if (D2K == ASSX_NMF_KL) {
             if (live) acc += tg_ * log(ratio) + in_ - tg_;
           } else {
             acc += ratio - 1.0;
             lprod *= ratio;
+            if (r == 1) {  // see the fused form in nmf_basis_mfma_kernel: a pair of ratios per mantissa / exponent step
+              int e2;
+              lm = frexp(lm * lprod, &e2);
+              le += e2;
+              lprod = 1.0;
+            }
           }
         }
       }

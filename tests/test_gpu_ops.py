@@ -482,6 +482,52 @@ def test_nmf_golden(eng, name):
     np.testing.assert_allclose(losses, g["loss_%d" % int(g["iters"][-1])], rtol=tol(eng, 1e-10, 2e-4))
 
 
+@pytest.mark.parametrize("K", [8, 32])
+def test_nmf_loss_edges_eps_zero_and_extreme_ratios(K):
+    """Round 5's advisor (low): with eps = 0 and a zero row of the basis the model is 0 in a whole bin; the reference divides by
+    it -- KL: +inf, IS: inf - log(inf) = nan -- and the domain-2 criterion kernels must say the same (their reciprocal + Newton
+    step used to turn the inf into nan for KL).  And ratios of 1e+-80 in four consecutive frames must not overflow the
+    mantissa product of the IS form (values that the per-element logarithm of the reference handles)."""
+    import warnings
+    from audio_source_separation_amd import _lib
+    from audio_source_separation_amd.ops import Engine
+    eng = Engine("float64")
+    F, T = 37, 80
+    rng = np.random.default_rng(97)
+    X, Tb, V = rng.random((F, T)) + 0.1, rng.random((F, K)) + 0.1, rng.random((K, T)) + 0.1
+    Tz = Tb.copy()
+    Tz[5, :] = 0.0
+    for kind, code in (("KL", _lib.NMF_KL), ("IS", _lib.NMF_IS_MM)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            with np.errstate(all="ignore"):
+                want = orc.nmf_loss(kind, X, Tz, V, eps=0.0)
+        got = eng.nmf_loss(code, dev_r(eng, X[None]), dev_r(eng, Tz[None]), dev_r(eng, V[None]), eps=0.0).item()
+        assert (np.isnan(want) and np.isnan(got)) or want == got, (kind, want, got)
+        assert np.isposinf(want) or np.isnan(want)
+    # extreme but finite ratios: the model 1e80 times too small in one bin, 1e80 times too large in another
+    Te = Tb.copy()
+    Te[3, :] *= 1e-80
+    Te[9, :] *= 1e80
+    tiny = 1e-300  # a floor that never bites: the ratios really are 1e+-80
+    want = orc.nmf_loss("IS", X, Te, V, eps=tiny)
+    got = eng.nmf_loss(_lib.NMF_IS_MM, dev_r(eng, X[None]), dev_r(eng, Te[None]), dev_r(eng, V[None]), eps=tiny).item()
+    assert np.isfinite(want) and np.isfinite(got) and want > 1e80
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    # only the logarithms (the part that travels as a mantissa product): a model 1e80 too LARGE in every bin
+    want = orc.nmf_loss("IS", X, Tb * 1e80, V, eps=tiny)
+    got = eng.nmf_loss(_lib.NMF_IS_MM, dev_r(eng, X[None]), dev_r(eng, (Tb * 1e80)[None]), dev_r(eng, V[None]), eps=tiny).item()
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    # the same criterion riding on the next update's basis half (assx_nmf_iterate: the loss of update i inside update i + 1)
+    Td, Vd = dev_r(eng, Te[None]), dev_r(eng, V[None])
+    loss = torch.zeros((2, 1), dtype=torch.float64, device=eng.dev)
+    eng.nmf_iterate(2, _lib.NMF_IS_MM, dev_r(eng, X[None]), Td, Vd, eps=tiny, loss=loss)
+    To, Vo = orc.nmf_update_once("IS", X, Te, V, eps=tiny)
+    np.testing.assert_allclose(loss[0, 0].item(), orc.nmf_loss("IS", X, To, Vo, eps=tiny), rtol=1e-9)  # fused into update 2's basis half
+    To, Vo = orc.nmf_update_once("IS", X, To, Vo, eps=tiny)
+    np.testing.assert_allclose(loss[1, 0].item(), orc.nmf_loss("IS", X, To, Vo, eps=tiny), rtol=1e-9)  # the stand-alone pass
+
+
 XNMF_CASES = ["t_nu1", "t_nu1000", "t_k20", "cauchy_naive", "cauchy_mm", "cauchy_me", "cauchy_mm_fast", "cauchy_mm_k20"]
 
 
