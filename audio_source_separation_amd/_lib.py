@@ -85,7 +85,14 @@ SIGNATURES = {
     "assx_istft": (_i, [_vp, _vp, _vp, _d, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "assx_upload": (_i, [_vp, _vp, _i, _vp, _i, _sz, _vp]),
     "assx_download": (_i, [_vp, _vp, _i, _vp, _i, _sz, _vp]),
+    "assx_shard_range": (None, [_sz, _i, _i, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "assx_comm_unique_id": (_i, [_vp]),
+    "assx_comm_init": (_i, [_vp, _i, _i, _vp, ctypes.POINTER(_vp)]),
+    "assx_comm_destroy": (_i, [_vp]),
+    "assx_scatter": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp]),
+    "assx_gather": (_i, [_vp, _i, _vp, _vp, _sz, _sz, _vp]),
 }
+COMM_ID_BYTES = 128
 
 
 class AssxError(RuntimeError):

@@ -26,7 +26,7 @@ pids=()
 built=()
 # ASSX_SRCS (tests): compile + check these sources (paths relative to csrc/, without .hip) instead of the library's own and
 # stop before the link -- tests/test_asm_waits.py feeds the build a kernel with the round-3 bug and expects it to fail.
-SRCS="${ASSX_SRCS:-assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfer assx_iterate}"
+SRCS="${ASSX_SRCS:-assx_api assx_bss assx_nmf assx_stft assx_generic assx_widem assx_xfer assx_iterate assx_comm}"
 for srcpath in $SRCS; do
   src=$(basename "$srcpath"); dir=$(dirname "$srcpath")
   stale=0
@@ -79,5 +79,5 @@ if [ "$CHECK" = 1 ]; then
   done
 fi
 [ -n "${ASSX_SRCS:-}" ] && { echo "ASSX_SRCS given: compiled and checked, not linked"; exit 0; }
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o $OBJ/assx_xfer.o $OBJ/assx_iterate.o -lpthread
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJ/assx_api.o $OBJ/assx_bss.o $OBJ/assx_nmf.o $OBJ/assx_stft.o $OBJ/assx_generic.o $OBJ/assx_widem.o $OBJ/assx_xfer.o $OBJ/assx_iterate.o $OBJ/assx_comm.o -lpthread -ldl
 echo "built $(pwd)/$OUT"

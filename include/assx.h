@@ -1,11 +1,12 @@
 /*
  * assx.h -- C-ABI of the MI355X-native iterative source-separation hot path.
  *
- * Scope of this boundary: the DEVICE side of ONE rank.  Every entry point is communication-free; multi-GPU runs are
- * one process per GPU, each with its own context, and the only inter-GPU traffic (scatter of the mixtures, gather of
- * the separated outputs -- utterances are independent, src/bss/ilrma.py:203-273) is issued by the host language
- * through its RCCL binding (audio_source_separation_amd/distributed.py).  There are
- * deliberately no assx_comm_* symbols.
+ * Scope of this boundary: the DEVICE side of ONE rank.  Every compute entry point is communication-free; multi-GPU runs
+ * are one process per GPU, each with its own context, and the only inter-GPU traffic is at the edges (scatter of the
+ * mixtures, gather of the separated outputs -- utterances are independent, src/bss/ilrma.py:203-273).  The package's own
+ * Python classes issue those edges through torch.distributed (audio_source_separation_amd/distributed.py; INTEGRATION.md
+ * section 3); a host without torch uses assx_comm_init / assx_scatter / assx_gather at the end of this header (round 6:
+ * the same grouped RCCL send / recv, RCCL loaded on first use).
  *
  * The reference (tky823/audio_source_separation) has NO plugin / FFI / operator API: its
  * boundary is the Python class surface.  This header is therefore the
@@ -419,6 +420,35 @@ int assx_istft(assx_ctx* ctx, const void* X, const void* window, double window_s
  * queued on `stream` and returns when `host` is complete.  Environment: ASSX_XFER_THREADS, ASSX_XFER_CHUNK_MB. */
 int assx_upload(assx_ctx* ctx, const void* host, int host_dtype, void* dev, int dev_dtype, size_t count, void* stream);
 int assx_download(assx_ctx* ctx, const void* dev, int dev_dtype, void* host, int host_dtype, size_t count, void* stream);
+
+/* ---- (e) multi-GPU edges: utterance sharding over the GPUs of one node ------------------------------------------- */
+/* No reference counterpart: the reference is a single-process NumPy program (src/bss/ilrma.py:203-273 -- every __call__ owns
+ * all of its state, hence utterances shard with no data-path collective; SURVEY.md 8e, 8b "assx_comm_init(ndev),
+ * assx_scatter/gather").  One process per GPU; the only traffic is root -> ranks (the mixtures) and ranks -> root (the
+ * separated outputs), each ONE grouped batch of ncclSend / ncclRecv on contiguous row blocks of the root's array: root <->
+ * 7 peers = 7 concurrent xGMI links, no ring, no staging copy, ragged blocks need no padding.  RCCL (librccl.so) is loaded
+ * by the first of these calls, libassx.so does not link it: on a machine without RCCL they return ASSX_E_UNSUPPORTED and
+ * everything else works.
+ *   assx_shard_range    the static block partition (host-side, no GPU): item i of n_items belongs to exactly one rank, block
+ *                       sizes differ by at most one, the first n_items % world ranks hold one more (64 over 8 -> 8 each);
+ *                       the same partition as audio_source_separation_amd.distributed.shard_range.
+ *   assx_comm_unique_id on ONE process: ASSX_COMM_ID_BYTES bytes (ncclGetUniqueId) that the host hands to every rank by its
+ *                       own means (MPI_Bcast, a file, a socket) before
+ *   assx_comm_init      on every rank, the context's device current: ncclCommInitRank.  A communicator belongs to the
+ *                       context it was made with (errors are reported through assx_last_error(ctx)); world = 1 is valid.
+ *   assx_scatter        root: `all` = (n_items, item_bytes) on its device; every rank (the root too) receives its own block
+ *                       into `local` ((hi - lo) * item_bytes; may alias its place in `all` on the root: then nothing moves).
+ *   assx_gather         the mirror image: every rank's `local` block lands at its place in the root's `all`.
+ * Both are asynchronous on `stream` like every other entry point; a rank with an empty block posts nothing; RCCL errors
+ * come back as 1000 + ncclResult_t with the message in the context. */
+#define ASSX_COMM_ID_BYTES 128
+typedef struct assx_comm assx_comm;
+void assx_shard_range(size_t n_items, int world, int rank, size_t* lo, size_t* hi);
+int assx_comm_unique_id(void* id);
+int assx_comm_init(assx_ctx* ctx, int world, int rank, const void* id, assx_comm** comm);
+int assx_comm_destroy(assx_comm* comm);
+int assx_scatter(assx_comm* comm, int root, const void* all, void* local, size_t n_items, size_t item_bytes, void* stream);
+int assx_gather(assx_comm* comm, int root, const void* local, void* all, size_t n_items, size_t item_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -473,3 +473,23 @@ def test_signature_is_position_dependent():
             b = a.copy()
             b[..., [0, 1], :] = b[..., [1, 0], :]
             assert _signature(b) != s, (shape, dtype, "rows")
+
+
+def test_shard_range_of_the_library_equals_the_python_partition():
+    """assx_shard_range (host-side, no GPU) is the partition `distributed.shard_range` makes: config 5's 64 over 8, ragged
+    and empty cases, every rank."""
+    from audio_source_separation_amd import distributed as D
+    import ctypes
+    from audio_source_separation_amd import _lib
+    for n in (0, 1, 5, 7, 8, 13, 63, 64, 65, 1000):
+        for world in (1, 2, 3, 8, 16):
+            seen = []
+            for rank in range(world):
+                lo, hi = ctypes.c_size_t(99), ctypes.c_size_t(99)
+                _lib.lib.assx_shard_range(n, world, rank, ctypes.byref(lo), ctypes.byref(hi))
+                assert (lo.value, hi.value) == D.shard_range(n, world, rank)
+                seen += list(range(lo.value, hi.value))
+            assert seen == list(range(n))
+    lo, hi = ctypes.c_size_t(99), ctypes.c_size_t(99)
+    _lib.lib.assx_shard_range(10, 4, 4, ctypes.byref(lo), ctypes.byref(hi))  # a rank outside the world holds nothing
+    assert (lo.value, hi.value) == (0, 0)

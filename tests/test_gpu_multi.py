@@ -132,6 +132,36 @@ def test_rccl_single_rank_group_and_bench_under_launcher():
     assert out["config5"]["utterances"] == 3 and out["config5"]["outputs_finite"] and out["config5"]["value"] > 0
 
 
+def test_cabi_comm_edges_on_a_one_rank_communicator():
+    """The multi-GPU edges through the C-ABI (include/assx.h: assx_comm_unique_id / assx_comm_init / assx_scatter /
+    assx_gather; round 5's review, missing #3: a non-Python host had no multi-GPU path).  What one GPU can run of it: a 1-rank
+    RCCL communicator made through the library (librccl.so loaded on first use), whose root sends its block to and receives it
+    from ITSELF inside the same grouped ncclSend / ncclRecv batch that root <-> 7 peers use -- complex128 and complex64, 5 ragged
+    utterances, a non-default stream; received blocks bit-identical, and the aliasing case (the block already in place) moves
+    nothing.  In its own interpreter: RCCL initialises process-wide state."""
+    code = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from audio_source_separation_amd import comm as C\n"
+        "dev = torch.device('cuda', 0)\n"
+        "assert C.shard_range(64, 8, 3) == (24, 32) and C.shard_range(13, 8, 7) == (12, 13)\n"
+        "cm = C.Comm(1, 0, C.unique_id(), device=dev)\n"
+        "g = torch.Generator(device=dev).manual_seed(3)\n"
+        "for dt, rt in ((torch.complex128, torch.float64), (torch.complex64, torch.float32)):\n"
+        "    x = torch.view_as_complex(torch.randn((5, 4, 9, 20, 2), dtype=rt, device=dev, generator=g))\n"
+        "    st = torch.cuda.Stream(device=dev)\n"
+        "    with torch.cuda.stream(st):\n"
+        "        loc = cm.scatter(x, 5, (4, 9, 20), dt)\n"
+        "        back = cm.gather(loc * 2, 5)\n"
+        "    st.synchronize()\n"
+        "    assert loc.data_ptr() != x.data_ptr() and torch.equal(loc, x) and torch.equal(back, x * 2)\n"
+        "cm.close()\n"
+        "print('cabi comm ok')\n" % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "cabi comm ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_rccl_grouped_send_recv_on_views_of_a_complex_array():
     """The edge traffic of config 5 through RCCL itself, on what one GPU can run: a 1-rank "nccl" group whose rank sends
     to and receives from ITSELF inside one grouped batch (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd -- the

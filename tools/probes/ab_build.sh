@@ -7,7 +7,7 @@ set -euo pipefail
 NAME=$1; shift
 CSRC=$(cd "$(dirname "$0")/../../audio_source_separation_amd/csrc" && pwd)
 mkdir -p $CSRC/ab_$NAME
-for o in assx_api assx_nmf assx_stft assx_generic assx_widem assx_xfer assx_iterate; do
+for o in assx_api assx_nmf assx_stft assx_generic assx_widem assx_xfer assx_iterate assx_comm; do
   cp $CSRC/$o.o $CSRC/ab_$NAME/$o.o
 done
 sleep 1; touch $CSRC/ab_$NAME/*.o
