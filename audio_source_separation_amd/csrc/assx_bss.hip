@@ -1528,9 +1528,8 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
         ASSX_REQUIRE(ctx, (size_t)B * lstride * sizeof(double) <= L.small - L.lpart, ASSX_E_UNSUPPORTED,
                      "workspace too small for the fused loss partials");
         lpart = (double*)((char*)ws + L.lpart);
-        hipLaunchKernelGGL((logdet_kernel<R, MM>), dim3(blocks_for((size_t)B * F, 64)), dim3(64), 0, st,
-                           (const Cx<R>*)W, lpart, B, F, T, lstride, ncov);
-        ASSX_LAUNCH_CHECK(ctx, "logdet_kernel");
+        // the F log-det terms and the final sum ride on the two finalize launches below (round 6: 9 -> 7 launches per
+        // iteration with the loss recorded, the reference's default)
       }
     }
     if (K > KU && wide_k && full_mask) {
@@ -1580,18 +1579,23 @@ int assx_ilrma_source_update(assx_ctx* ctx, const void* X, const void* W, void* 
     }
     rc = run_basis_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp, -1.0, lpart, lstride);
     if (rc) return rc;
-    if (lpart) {
-      hipLaunchKernelGGL(ilrma_loss_finish_kernel, dim3(B), dim3(REDUCE_THREADS), 0, st, (const double*)lpart, loss_prev,
-                         F, lstride - F, lstride);
-      ASSX_LAUNCH_CHECK(ctx, "ilrma_loss_finish_kernel");
-    }
-    hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(blocks_for((size_t)B * MM * F * K, 256)), dim3(256), 0,
-                       st, (const R*)ws, (R*)Tb, B, MM, F, K, fp, (R)eps, p2, source_mask);
+    const unsigned nb_basis = blocks_for((size_t)B * MM * F * K, 256);
+    if (lpart)  // + the log-det terms of the loss (workgroups past nb_basis)
+      hipLaunchKernelGGL((basis_stream_finalize_kernel<R, MM>), dim3(nb_basis + blocks_for((size_t)B * F, 256)), dim3(256), 0,
+                         st, (const R*)ws, (R*)Tb, B, MM, F, K, fp, (R)eps, p2, source_mask, (int)nb_basis, (const Cx<R>*)W,
+                         lpart, lstride, lstride - F, T);
+    else
+      hipLaunchKernelGGL((basis_stream_finalize_kernel<R>), dim3(nb_basis), dim3(256), 0, st, (const R*)ws, (R*)Tb, B, MM,
+                         F, K, fp, (R)eps, p2, source_mask);
     ASSX_LAUNCH_CHECK(ctx, "basis_stream_finalize_kernel");
-    rc = run_act_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fp);  // uses the new basis
+    FlatPart fpa;
+    rc = run_act_partial<R, MM>(ctx, X, W, Tb, V, domain, eps, ws, B, F, T, K, st, &fpa);  // uses the new basis
     if (rc) return rc;
-    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3((unsigned)((size_t)B * MM * K * tblocks(T))), dim3(256), 0, st,
-                       (const R*)ws, (R*)V, B, MM, F, K, T, fp, (R)eps, p2, source_mask);
+    const unsigned nb_act = (unsigned)((size_t)B * MM * K * tblocks(T));
+    // + one workgroup per utterance that completes the loss (lpart: the basis pass's data terms and the log-det terms)
+    hipLaunchKernelGGL((act_stream_finalize_kernel<R>), dim3(nb_act + (lpart ? (unsigned)B : 0u)), dim3(256), 0, st,
+                       (const R*)ws, (R*)V, B, MM, F, K, T, fpa, (R)eps, p2, source_mask, (int)nb_act, (const double*)lpart,
+                       loss_prev, lstride - F, lstride);
     ASSX_LAUNCH_CHECK(ctx, "act_stream_finalize_kernel");
     return 0;
   });

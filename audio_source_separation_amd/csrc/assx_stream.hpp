@@ -1141,11 +1141,30 @@ __global__ void __launch_bounds__(64, MINW)
     });
 }
 
+template <int M, typename R>
+__device__ __forceinline__ double neg2T_logabsdet(const Cx<R>* __restrict__ W, size_t bf, int T);  // assx_group_linalg.hpp
+
 // T *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:417-419)
-template <typename R>
+// ML > 0 (round 6; the loss folded into the basis pass): workgroups past the `nb_main` that do the update write the F
+// log-det terms -2 T log|det W_f| of the loss at lpart[b][ncov + f] (ilrma.py:675; ML = the channel count) -- what
+// logdet_kernel did in a launch of its own ahead of the pass.  W does not move between the two places; same values.
+template <typename R, int ML = 0>
 __global__ void __launch_bounds__(256) basis_stream_finalize_kernel(const R* __restrict__ part, R* __restrict__ Tb,
                                                                    int B, int N, int F, int K, FlatPart fp, R eps,
-                                                                   PowSpec p2, unsigned src_mask) {
+                                                                   PowSpec p2, unsigned src_mask, int nb_main = 0,
+                                                                   const Cx<R>* __restrict__ W = nullptr,
+                                                                   double* __restrict__ lpart = nullptr, int lstride = 0,
+                                                                   int ncov = 0, int T = 0) {
+  if constexpr (ML > 0) {
+    if ((int)blockIdx.x >= nb_main) {
+      const int i = ((int)blockIdx.x - nb_main) * (int)blockDim.x + (int)threadIdx.x;
+      if (i < B * F) {
+        const int b = i / F, f = i - b * F;
+        lpart[(size_t)b * lstride + ncov + f] = neg2T_logabsdet<ML, R>(W, (size_t)i, T);
+      }
+      return;
+    }
+  }
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t total = (size_t)B * N * F * K;
   if (idx >= total) return;
@@ -1817,10 +1836,31 @@ __global__ void __launch_bounds__(64 * ACT_NH, MINW)
 }
 
 // V *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:426-428)
+// lpart != nullptr (round 6; the loss folded into the basis pass): workgroup nb_main + b completes utterance b's loss --
+// the data-term partials the basis pass left at lpart[b][0 .. ncov) plus the F log-det terms behind them, in the order of
+// ilrma_loss_finish_kernel (the launch this replaces: same bits).
 template <typename R>
 __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __restrict__ part, R* __restrict__ V, int B,
                                                                  int N, int F, int K, int T, FlatPart fp, R eps,
-                                                                 PowSpec p2, unsigned src_mask) {
+                                                                 PowSpec p2, unsigned src_mask, int nb_main = 0,
+                                                                 const double* __restrict__ lpart = nullptr,
+                                                                 double* __restrict__ loss = nullptr, int ncov = 0,
+                                                                 int lstride = 0) {
+  if (lpart != nullptr && (int)blockIdx.x >= nb_main) {
+    __shared__ double sm[256];
+    const int b = (int)blockIdx.x - nb_main;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < ncov; i += 256) s += lpart[(size_t)b * lstride + i];
+    for (int f = threadIdx.x; f < F; f += 256) s += lpart[(size_t)b * lstride + ncov + f];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+      if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[b] = sm[0];
+    return;
+  }
   // 64 outputs (one frame block of one (b, n, k)) per workgroup, 4 strands per output over the covering records
   // (independent loads instead of a chain of ~9 L2 latencies), combined in a fixed order
   __shared__ R sn[4][WAVE], sd[4][WAVE];
