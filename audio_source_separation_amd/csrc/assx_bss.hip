@@ -602,8 +602,9 @@ __global__ void __launch_bounds__(REDUCE_THREADS) ilrma_loss_finish_kernel(const
   __shared__ double sm[REDUCE_THREADS];
   const int b = blockIdx.x;
   double s = 0.0;
-  for (int i = threadIdx.x; i < ncov; i += REDUCE_THREADS) s += lpart[(size_t)b * lstride + i];
-  for (int f = threadIdx.x; f < F; f += REDUCE_THREADS) s += lpart[(size_t)b * lstride + ncov + f];
+  static_assert(REDUCE_THREADS == 256, "strided_sum_256");
+  strided_sum_256(lpart + (size_t)b * lstride, ncov, s);
+  strided_sum_256(lpart + (size_t)b * lstride + ncov, F, s);
   sm[threadIdx.x] = s;
   __syncthreads();
   for (int off = REDUCE_THREADS / 2; off >= 1; off >>= 1) {

@@ -1144,6 +1144,22 @@ __global__ void __launch_bounds__(64, MINW)
 template <int M, typename R>
 __device__ __forceinline__ double neg2T_logabsdet(const Cx<R>* __restrict__ W, size_t bf, int T);  // assx_group_linalg.hpp
 
+// s += p[threadIdx.x], p[threadIdx.x + 256], ... (a 256-thread workgroup; ascending order per thread, as the plain loop):
+// eight loads in flight per trip instead of one round trip per element -- the loss sums are ~3000 doubles per utterance read
+// by ONE workgroup, 13 dependent L2 latencies per thread in the plain form (8.7 against 5.2 us for the launch that hosts it)
+__device__ __forceinline__ void strided_sum_256(const double* __restrict__ p, int n, double& s) {
+  for (int i0 = threadIdx.x; i0 < n; i0 += 256 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 256 * u;
+      v[u] = i < n ? p[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+}
+
 // T *= (num / max(den, eps)) ** (d/(d+2))      (ilrma.py:417-419)
 // ML > 0 (round 6; the loss folded into the basis pass): workgroups past the `nb_main` that do the update write the F
 // log-det terms -2 T log|det W_f| of the loss at lpart[b][ncov + f] (ilrma.py:675; ML = the channel count) -- what
@@ -1850,8 +1866,8 @@ __global__ void __launch_bounds__(256) act_stream_finalize_kernel(const R* __res
     __shared__ double sm[256];
     const int b = (int)blockIdx.x - nb_main;
     double s = 0.0;
-    for (int i = threadIdx.x; i < ncov; i += 256) s += lpart[(size_t)b * lstride + i];
-    for (int f = threadIdx.x; f < F; f += 256) s += lpart[(size_t)b * lstride + ncov + f];
+    strided_sum_256(lpart + (size_t)b * lstride, ncov, s);
+    strided_sum_256(lpart + (size_t)b * lstride + ncov, F, s);
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
