@@ -473,7 +473,11 @@ __global__ void __launch_bounds__(64, MINW)
   auto issue_vtile = [&](const Cursor& c, int slot) {
     // exact size in the descriptor: a tile reaching past the end of V reads zeros
     const BufRsrc rv = make_rsrc_sized(V + (size_t)c.b * N * K * T, (size_t)(a.d.B - c.b) * N * K * T * sizeof(R));
+#ifdef COV_VTILE_FIXED  // knock-out probe (tools/probes): every tile request reads frame block 0 -- the L2 traffic of the tiles goes, everything else stays
+    vt.issue(rv, vlds + slot * VT::TILE_BYTES, 0u);
+#else
     vt.issue(rv, vlds + slot * VT::TILE_BYTES, (unsigned)c.tb * (unsigned)VT::ROW_BYTES);
+#endif
   };
   R tbr[SPL][KU];
   auto load_basis_row = [&](const Cursor& c) {
