@@ -94,6 +94,51 @@ __global__ void __launch_bounds__(256) part_latent_kernel(const R* __restrict__ 
   }
 }
 
+// The same with a run-time source count (round 6; more than 8 channels: csrc/assx_widem.hip): N <= NMAX sources, the loops
+// unrolled to the bound and masked; same sums in the same order.
+template <typename R, int NMAX>
+__global__ void __launch_bounds__(256) part_latent_rt_kernel(const R* __restrict__ part, const R* __restrict__ Tb,
+                                                            R* __restrict__ Z, int F, int K, FlatPart fp, R eps, int N) {
+  __shared__ R red[4][2 * NMAX];
+  __shared__ R zl[NMAX];
+  const int k = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  R num[NMAX], den[NMAX];
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n) num[n] = den[n] = 0;
+  for (int f = threadIdx.x; f < F; f += 256) {
+    const R t = Tb[((size_t)b * F + f) * K + k];
+#pragma unroll
+    for (int n = 0; n < NMAX; ++n)
+      if (n < N) {
+        R a, d;
+        basis_records<R>(part, fp, N, K, F, b, f, n, k, a, d);
+        num[n] += t * a;
+        den[n] += t * d;
+      }
+  }
+#pragma unroll
+  for (int n = 0; n < NMAX; ++n)
+    if (n < N) {  // wave-uniform
+      const R a = wave_allreduce_sum<R>(num[n]), d = wave_allreduce_sum<R>(den[n]);
+      if (lane == 0) {
+        red[wv][2 * n] = a;
+        red[wv][2 * n + 1] = d;
+      }
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    R s = 0;
+    for (int n = 0; n < N; ++n) {
+      const R a = (red[0][2 * n] + red[1][2 * n]) + (red[2][2 * n] + red[3][2 * n]);
+      const R d = floor_eps<R>((red[0][2 * n + 1] + red[1][2 * n + 1]) + (red[2][2 * n + 1] + red[3][2 * n + 1]), eps);
+      zl[n] = sqrt(a / d);
+      s += zl[n];
+    }
+    for (int n = 0; n < N; ++n) Z[((size_t)b * N + n) * K + k] = zl[n] / s;
+  }
+}
+
 // T[f,k] *= sqrt(num/den), contributions of all sources weighted by Z     (ilrma.py:389-397)
 template <typename R>
 __global__ void __launch_bounds__(256) part_basis_kernel(const R* __restrict__ part, const R* __restrict__ Z,
@@ -214,6 +259,48 @@ __global__ void __launch_bounds__(256) part_normalize_power_kernel(Cx<R>* __rest
       for (int n = 0; n < N; ++n)
         Zout[((size_t)b * N + n) * K + k] = (Zin[((size_t)b * N + n) * K + k] / (anorm[n] * anorm[n])) / s;
     }
+  }
+  __syncthreads();
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nW = (size_t)F * N * N, nT = (size_t)F * K;
+  if (idx < nW) {
+    const int n = (idx / N) % N;
+    Cx<R>* w = W + (size_t)b * nW + idx;
+    const R a = anorm[n];
+    *w = cmake<R>(w->x / a, w->y / a);
+  } else if (idx < nW + nT) {
+    const size_t j = idx - nW;
+    R* t = Tb + (size_t)b * nT + j;
+    *t = *t * zsum[j % K];
+  }
+}
+
+// run-time source count (round 6): the statements of part_normalize_power_kernel
+template <typename R, int NMAX>
+__global__ void __launch_bounds__(256) part_normalize_power_rt_kernel(Cx<R>* __restrict__ W, R* __restrict__ Zout,
+                                                                     const R* __restrict__ Zin, R* __restrict__ Tb,
+                                                                     const double* __restrict__ pbins, int F, int K,
+                                                                     R eps, int N) {
+  __shared__ R anorm[NMAX];
+  extern __shared__ unsigned char smem_raw[];
+  R* zsum = reinterpret_cast<R*>(smem_raw);  // [K]
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+  for (int n = wv; n < N; n += 4) {
+    const double* p = pbins + ((size_t)b * N + n) * F;
+    double s = 0.0;
+    for (int f = lane; f < F; f += WAVE) s += p[f];
+    s = wave_allreduce_sum<double>(s);
+    if (lane == 0) anorm[n] = floor_eps<R>(sqrt((R)(s / (double)F)), eps);
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256) {
+    R s = 0;
+    for (int n = 0; n < N; ++n) s += Zin[((size_t)b * N + n) * K + k] / (anorm[n] * anorm[n]);
+    zsum[k] = s;
+    if (blockIdx.x == 0)
+      for (int n = 0; n < N; ++n)
+        Zout[((size_t)b * N + n) * K + k] = (Zin[((size_t)b * N + n) * K + k] / (anorm[n] * anorm[n])) / s;
   }
   __syncthreads();
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -444,9 +444,27 @@ template <typename R, int M>
 static int launch_sweep(assx_ctx* ctx, int Mr, int spatial, int pm, int pn, const void* U, void* W, const void* C, double* pw,
                         double thr, int32_t* status, int B, int F, int T, hipStream_t st, double den_floor = 0.0) {
   const dim3 grid((unsigned)((size_t)B * F)), block(64);  // 64 lanes = one bin (GW = 64 for M >= 5)
-  if constexpr (M == 0) {  // run-time channel count: IP only (one wave per bin, matrices in LDS)
-    if (spatial != ASSX_SPATIAL_IP)
-      return fail(ctx, ASSX_E_UNSUPPORTED, "more than %d channels: only the IP sweep is available (M = %d)", MMAX, Mr);
+  if constexpr (M == 0) {  // run-time channel count: IP and (round 6) ISS, one wave per bin, matrices in LDS
+    if (spatial == ASSX_SPATIAL_ISS) {
+      const size_t lds = iss_rt_lds_bytes(Mr);
+      hipLaunchKernelGGL((iss_rt_kernel<R>), grid, block, lds, st, (const Cx<R>*)U, (Cx<R>*)W, (const Cx<R>*)C, pw, (double)T,
+                         B, F, Mr);
+      ASSX_LAUNCH_CHECK(ctx, "widem::iss_rt_kernel");
+      return 0;
+    }
+    if (spatial == ASSX_SPATIAL_IP2) {
+      const size_t lds = ip2_rt_lds_bytes(Mr);
+      if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ip2_rt_kernel<R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return hip_fail(ctx, e, "hipFuncSetAttribute(ip2_rt_kernel)");
+      }
+      hipLaunchKernelGGL((ip2_rt_kernel<R>), grid, block, lds, st, (const Cx<R>*)U, (Cx<R>*)W, (const Cx<R>*)C, pw, thr, status,
+                         B, F, pm, pn, Mr);
+      ASSX_LAUNCH_CHECK(ctx, "widem::ip2_rt_kernel");
+      return 0;
+    }
+    if (spatial != ASSX_SPATIAL_IP) return fail(ctx, ASSX_E_ARG, "bad spatial algorithm %d", spatial);
     const size_t lds = ip_rt_lds_bytes(Mr);
     if (lds > 64 * 1024) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ip_rt_kernel<R>),
@@ -692,7 +710,6 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
                                     hipStream_t st) {
   const Ws L = layout(B, M, F, T, K, dtype);
   if (K > 64) return fail(ctx, ASSX_E_UNSUPPORTED, "partitioning with M = %d > 4 needs n_basis <= 64, got %d", M, K);
-  if (M > MMAX) return fail(ctx, ASSX_E_UNSUPPORTED, "the partitioning function is available for up to %d channels, got %d", MMAX, M);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MT = decltype(mt)::value;
@@ -731,8 +748,11 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
     if ((rc = expand(true))) return rc;
     if ((rc = sums(NMF_HALF_BASIS))) return rc;
     if constexpr (MT != 0)
-    hipLaunchKernelGGL((part_latent_kernel<R, MT>), dim3(K, B), dim3(256), 0, st, (const R*)rec, (const R*)Tb, (R*)Z, F, K,
-                       fpb, (R)eps);
+      hipLaunchKernelGGL((part_latent_kernel<R, MT>), dim3(K, B), dim3(256), 0, st, (const R*)rec, (const R*)Tb, (R*)Z, F, K,
+                         fpb, (R)eps);
+    else  // run-time channel count (round 6)
+      hipLaunchKernelGGL((part_latent_rt_kernel<R, RT_MMAX>), dim3(K, B), dim3(256), 0, st, (const R*)rec, (const R*)Tb,
+                         (R*)Z, F, K, fpb, (R)eps, MM);
     ASSX_LAUNCH_CHECK(ctx, "part_latent_kernel");
     if ((rc = expand(false))) return rc;
     if ((rc = sums(NMF_HALF_BASIS))) return rc;
@@ -750,15 +770,17 @@ int ilrma_source_update_partitioned(assx_ctx* ctx, const void* X, const void* W,
 
 int normalize_power_bins_partitioned(assx_ctx* ctx, void* W, void* Z, void* Tb, const double* power_bins, double eps,
                                      void* ws, int B, int M, int F, int K, int dtype, hipStream_t st) {
-  if (M > MMAX) return fail(ctx, ASSX_E_UNSUPPORTED, "the partitioning function is available for up to %d channels, got %d", MMAX, M);
   return dispatch(ctx, dtype, M, [&](auto rt, auto mt) -> int {
     using R = decltype(rt);
     constexpr int MT = decltype(mt)::value;
     const int MM = MT ? MT : M;
     const size_t per_b = (size_t)F * MM * MM + (size_t)F * K;
     if constexpr (MT != 0)
-    hipLaunchKernelGGL((part_normalize_power_kernel<R, MT>), dim3(nblk(per_b, 256), B), dim3(256), (size_t)K * sizeof(R),
-                       st, (Cx<R>*)W, (R*)ws, (const R*)Z, (R*)Tb, power_bins, F, K, (R)eps);
+      hipLaunchKernelGGL((part_normalize_power_kernel<R, MT>), dim3(nblk(per_b, 256), B), dim3(256), (size_t)K * sizeof(R),
+                         st, (Cx<R>*)W, (R*)ws, (const R*)Z, (R*)Tb, power_bins, F, K, (R)eps);
+    else  // run-time channel count (round 6)
+      hipLaunchKernelGGL((part_normalize_power_rt_kernel<R, RT_MMAX>), dim3(nblk(per_b, 256), B), dim3(256),
+                         (size_t)K * sizeof(R), st, (Cx<R>*)W, (R*)ws, (const R*)Z, (R*)Tb, power_bins, F, K, (R)eps, MM);
     ASSX_LAUNCH_CHECK(ctx, "part_normalize_power_kernel");
     hipError_t e = hipMemcpyAsync(Z, ws, (size_t)B * MM * K * sizeof(R), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return fail(ctx, (int)e, "hipMemcpyAsync(Z): %s", hipGetErrorString(e));

@@ -18,7 +18,7 @@ namespace assx {
 namespace widem {
 
 constexpr int MMIN = 5, MMAX = 8;  // compile-time channel counts (tuned kernels)
-constexpr int RT_MMAX = 32;         // run-time channel counts above MMAX (assx_widem_rt.hpp: functional, IP only)
+constexpr int RT_MMAX = 32;         // run-time channel counts above MMAX (assx_widem_rt.hpp: functional, not tuned)
 inline bool handles(int M) { return M >= MMIN && M <= RT_MMAX; }
 
 size_t workspace_bytes(int B, int M, int F, int T, int K, int dtype);

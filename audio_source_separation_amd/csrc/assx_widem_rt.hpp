@@ -338,6 +338,223 @@ __global__ void __launch_bounds__(64) ip_rt_kernel(const Cx<R>* __restrict__ U, 
   }
   if (flags && status && lane == 0) atomicOr(&status[b], flags);
 }
+// ISS sweep (ilrma.py:537-564, iva.py:525-543; round 6) of one bin per wave, run-time M: the arithmetic of iss_group_kernel
+// (assx_group_linalg.hpp) -- the rank-one updates  Y <- Y - v_n Y[n]  restated on W with the weighted covariances U_s:
+//   t_s = U_s conj(w_n),  q_s = w_s . t_s,  d_s = w_n . t_s (real),  v_s = q_s / d_s (s != n),  v_n = 1 - 1 / sqrt(T d_n),
+//   W <- W - v w_n^T  with the OLD row n -- sums, not means, as the reference (the 1 / T of the paper is absent).
+// U_s (M x M) is staged in LDS for every (n, s): M^4 multiply-adds and M^2 reads of U per bin.  FUNCTIONAL, not tuned, like
+// the rest of this file (5 <= M <= 8 runs iss_group_kernel).  Optionally the per-bin power statistic from C.
+template <typename R>
+__global__ void __launch_bounds__(64) iss_rt_kernel(const Cx<R>* __restrict__ U, Cx<R>* __restrict__ W,
+                                                   const Cx<R>* __restrict__ C, double* __restrict__ pw, double n_frames,
+                                                   int B, int F, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  const int MM = M * M, lane = threadIdx.x, N = M;
+  Cd* Wl = reinterpret_cast<Cd*>(smem_rt);  // M x M
+  Cd* Ul = Wl + MM;                         // M x M: U_s (then C)
+  Cd* tv = Ul + MM;                         // M: t_s
+  Cd* vv = tv + M;                          // M: v
+  Cd* wn = vv + M;                          // M: the old row n
+  const int bf = blockIdx.x, b = bf / F, f = bf - b * F;
+  for (int e = lane; e < MM; e += WAVE) {
+    const Cx<R> v = W[(size_t)bf * MM + e];
+    Wl[e] = cmake<double>((double)v.x, (double)v.y);
+  }
+  wave_sync_lds();
+  for (int n = 0; n < N; ++n) {
+    for (int j = lane; j < M; j += WAVE) wn[j] = Wl[n * M + j];
+    wave_sync_lds();
+    for (int s = 0; s < N; ++s) {
+      for (int e = lane; e < MM; e += WAVE) {
+        const Cx<R> v = U[(((size_t)b * N + s) * F + f) * MM + e];
+        Ul[e] = cmake<double>((double)v.x, (double)v.y);
+      }
+      wave_sync_lds();
+      for (int i = lane; i < M; i += WAVE) {  // t_s[i] = sum_j U_s[i][j] conj(w_n[j])
+        Cd a = cmake<double>(0.0, 0.0);
+        for (int j = 0; j < M; ++j) cfma(a, Ul[i * M + j], cconj(wn[j]));
+        tv[i] = a;
+      }
+      wave_sync_lds();
+      double qx = 0.0, qy = 0.0, dx = 0.0;
+      for (int i = lane; i < M; i += WAVE) {
+        const Cd tq = cmul(Wl[s * M + i], tv[i]);
+        const Cd td = cmul(wn[i], tv[i]);
+        qx += tq.x;
+        qy += tq.y;
+        dx += td.x;  // Hermitian form: real
+      }
+      const double q_re = wave_sum_d(qx), q_im = wave_sum_d(qy), d = wave_sum_d(dx);
+      if (lane == 0) vv[s] = (s == n) ? cmake<double>(1.0 - 1.0 / sqrt(n_frames * d), 0.0) : cmake<double>(q_re / d, q_im / d);
+      wave_sync_lds();
+    }
+    for (int e = lane; e < MM; e += WAVE) {  // every row uses the OLD row n
+      const int i = e / M, j = e - i * M;
+      const Cd dlt = cmul(vv[i], wn[j]);
+      Wl[e] = cmake<double>(Wl[e].x - dlt.x, Wl[e].y - dlt.y);
+    }
+    wave_sync_lds();
+  }
+  for (int e = lane; e < MM; e += WAVE) W[(size_t)bf * MM + e] = cmake<R>((R)Wl[e].x, (R)Wl[e].y);
+  if (pw) {  // per-bin share of mean|y_n|^2 = mean_f w_n^H C_f w_n
+    for (int e = lane; e < MM; e += WAVE) {
+      const Cx<R> v = C[(size_t)bf * MM + e];
+      Ul[e] = cmake<double>((double)v.x, (double)v.y);
+    }
+    wave_sync_lds();
+    for (int n = 0; n < N; ++n) {
+      double sacc = 0.0;
+      for (int e = lane; e < MM; e += WAVE) {
+        const int i = e / M, j = e - i * M;
+        const Cd t1 = cmul(Wl[n * M + i], Ul[e]);
+        sacc += t1.x * Wl[n * M + j].x + t1.y * Wl[n * M + j].y;
+      }
+      sacc = wave_sum_d(sacc);
+      if (lane == 0) pw[((size_t)b * N + n) * F + f] = sacc;
+    }
+  }
+}
+inline size_t iss_rt_lds_bytes(int M) { return ((size_t)2 * M * M + 3 * M) * sizeof(Cd); }
+
+// IP2 / pairwise update of rows (pm, pn) (ilrma.py:566-633, iva.py:544-599; round 6) of one bin per wave, run-time M: the
+// arithmetic of ip2_group_kernel (assx_group_linalg.hpp) with the matrices in LDS -- P_x = (W U_x)^{-1} [e_pm e_pn] by
+// the pivoted Gauss-Jordan inverse above, the condition guard of ip_rt_kernel, V_x = P_x^H U_x P_x (2 x 2), the eigenvectors
+// of V_pn^{-1} V_pm in LAPACK zgeev's convention sorted by descending eigenvalue, w_x = conj(P_x v_x / sqrt(v_x^H V_x v_x)).
+// Both rows use the OLD W.  The 2 x 2 part is wave-uniform and evaluated by every lane.  FUNCTIONAL, not tuned.
+template <typename R>
+__global__ void __launch_bounds__(64) ip2_rt_kernel(const Cx<R>* __restrict__ U, Cx<R>* __restrict__ W,
+                                                   const Cx<R>* __restrict__ C, double* __restrict__ pw, double thr,
+                                                   int32_t* __restrict__ status, int B, int F, int pm, int pn, int M) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_rt[];
+  const int MM = M * M, lane = threadIdx.x, N = M;
+  Cd* Wl = reinterpret_cast<Cd*>(smem_rt);
+  Cd* Ul = Wl + MM;
+  Cd* Al = Ul + MM;
+  Cd* Ix[2] = {Al + MM, Al + 2 * MM};
+  Cd* G0 = Al + 3 * MM;
+  Cd* G1 = G0 + MM;
+  Cd* G2 = G1 + MM;
+  int* piv = reinterpret_cast<int*>(G2 + MM);
+  const int bf = blockIdx.x, b = bf / F, f = bf - b * F;
+  for (int e = lane; e < MM; e += WAVE) {
+    const Cx<R> v = W[(size_t)bf * MM + e];
+    Wl[e] = cmake<double>((double)v.x, (double)v.y);
+  }
+  int flags = 0;
+  const int col[2] = {pm, pn};
+  bool okx[2];
+  Cd V[2][2][2];  // V[x][a][b], x = 0 -> source pm, 1 -> source pn
+  for (int x = 0; x < 2; ++x) {
+    for (int e = lane; e < MM; e += WAVE) {
+      const Cx<R> v = U[(((size_t)b * N + col[x]) * F + f) * MM + e];
+      Ul[e] = cmake<double>((double)v.x, (double)v.y);
+    }
+    wave_sync_lds();
+    double nA2p = 0.0;
+    for (int e = lane; e < MM; e += WAVE) {  // A = W U_x
+      const int i = e / M, j = e - i * M;
+      Cd a = cmake<double>(0.0, 0.0);
+      for (int k = 0; k < M; ++k) cfma(a, Wl[i * M + k], Ul[k * M + j]);
+      Al[e] = a;
+      Ix[x][e] = a;
+      nA2p += cabs2(a);
+    }
+    wave_sync_lds();
+    const bool singular = !wave_gj_inverse(Ix[x], piv, M, lane);
+    double nI2p = 0.0;
+    for (int e = lane; e < MM; e += WAVE) nI2p += cabs2(Ix[x][e]);
+    const double nA2 = wave_sum_d(nA2p), nI2 = wave_sum_d(nI2p);
+    double c2 = nA2 * nI2, thr2 = thr * thr, m2 = (double)M * (double)M;
+    if (!(c2 > 1e-290 && c2 < 1e290 && thr2 < 1e290)) {
+      c2 = sqrt(nA2) * sqrt(nI2);
+      thr2 = thr;
+      m2 = (double)M;
+    }
+    const bool amb = !singular && (c2 == c2) && c2 >= thr2 && c2 < thr2 * m2;
+    bool ok = !singular && (c2 == c2) && c2 < thr2;
+    if (amb) ok = wave_spectral_norm(Al, G0, G1, G2, M, lane) * wave_spectral_norm(Ix[x], G0, G1, G2, M, lane) < thr;
+    okx[x] = ok;
+    if (singular) flags |= ASSX_STATUS_SINGULAR;  // numpy.linalg.inv raises
+    else if (!ok) flags |= ASSX_STATUS_COND_REJECT;
+    for (int aa = 0; aa < 2; ++aa)
+      for (int bb = 0; bb < 2; ++bb) {
+        double sx = 0.0, sy = 0.0;
+        for (int e = lane; e < MM; e += WAVE) {
+          const int i = e / M, j = e - i * M;
+          const Cd term = cmul(cmul(cconj(Ix[x][i * M + col[aa]]), Ul[e]), Ix[x][j * M + col[bb]]);
+          sx += term.x;
+          sy += term.y;
+        }
+        V[x][aa][bb] = cmake<double>(wave_sum_d(sx), wave_sum_d(sy));
+      }
+    wave_sync_lds();
+  }
+  // ---- wave-uniform 2 x 2 part (the statements of ip2_group_kernel)
+  const Cd detn = csub(cmul(V[1][0][0], V[1][1][1]), cmul(V[1][0][1], V[1][1][0]));
+  if (detn.x == 0.0 && detn.y == 0.0) flags |= ASSX_STATUS_SINGULAR;
+  const Cd idet = cdiv(cmake<double>(1.0, 0.0), detn);
+  const Cd ni[2][2] = {{cmul(V[1][1][1], idet), cmul(cmake<double>(-V[1][0][1].x, -V[1][0][1].y), idet)},
+                       {cmul(cmake<double>(-V[1][1][0].x, -V[1][1][0].y), idet), cmul(V[1][0][0], idet)}};
+  Cd VV[2][2];
+  for (int aa = 0; aa < 2; ++aa)
+    for (int bb = 0; bb < 2; ++bb) VV[aa][bb] = cadd(cmul(ni[aa][0], V[0][0][bb]), cmul(ni[aa][1], V[0][1][bb]));
+  const Cd htr = cscale(cadd(VV[0][0], VV[1][1]), 0.5);
+  const Cd det = csub(cmul(VV[0][0], VV[1][1]), cmul(VV[0][1], VV[1][0]));
+  const Cd disc = csqrt_principal(csub(cmul(htr, htr), det));
+  Cd lam[2] = {cadd(htr, disc), csub(htr, disc)};
+  const bool first_big = (lam[0].x > lam[1].x) || (lam[0].x == lam[1].x && lam[0].y >= lam[1].y);
+  if (!first_big) {
+    const Cd t = lam[0];
+    lam[0] = lam[1];
+    lam[1] = t;
+  }
+  for (int x = 0; x < 2; ++x) {  // x = 0: eigenvector of the larger eigenvalue -> row pm; x = 1 -> row pn
+    const Cd c1[2] = {VV[0][1], csub(lam[x], VV[0][0])};
+    const Cd c2v[2] = {csub(lam[x], VV[1][1]), VV[1][0]};
+    const double n1 = cabs2(c1[0]) + cabs2(c1[1]), n2 = cabs2(c2v[0]) + cabs2(c2v[1]);
+    Cd v[2] = {n1 >= n2 ? c1[0] : c2v[0], n1 >= n2 ? c1[1] : c2v[1]};
+    const double nrm = sqrt(n1 >= n2 ? n1 : n2);
+    v[0] = cscale(v[0], 1.0 / nrm);
+    v[1] = cscale(v[1], 1.0 / nrm);
+    const int kbig = (cabs2(v[1]) > cabs2(v[0])) ? 1 : 0;  // zgeev: the component of largest modulus real
+    const double mag = sqrt(cabs2(v[kbig]));
+    const Cd rot = cscale(cconj(v[kbig]), 1.0 / mag);
+    v[0] = cmul(v[0], rot);
+    v[1] = cmul(v[1], rot);
+    v[kbig].y = 0.0;
+    Cd q = cmake<double>(0.0, 0.0);
+    for (int aa = 0; aa < 2; ++aa)
+      for (int bb = 0; bb < 2; ++bb) cfma(q, cmul(cconj(v[aa]), V[x][aa][bb]), v[bb]);
+    const Cd den = csqrt_principal(q);
+    v[0] = cdiv(v[0], den);
+    v[1] = cdiv(v[1], den);
+    if (okx[x] && !(flags & ASSX_STATUS_SINGULAR))  // w_x[c] = conj(P_x[c][0] v0 + P_x[c][1] v1)
+      for (int c = lane; c < M; c += WAVE)
+        Wl[col[x] * M + c] = cconj(cadd(cmul(Ix[x][c * M + pm], v[0]), cmul(Ix[x][c * M + pn], v[1])));
+  }
+  wave_sync_lds();
+  for (int e = lane; e < MM; e += WAVE) W[(size_t)bf * MM + e] = cmake<R>((R)Wl[e].x, (R)Wl[e].y);
+  if (pw) {
+    for (int e = lane; e < MM; e += WAVE) {
+      const Cx<R> v = C[(size_t)bf * MM + e];
+      Ul[e] = cmake<double>((double)v.x, (double)v.y);
+    }
+    wave_sync_lds();
+    for (int n = 0; n < N; ++n) {
+      double sacc = 0.0;
+      for (int e = lane; e < MM; e += WAVE) {
+        const int i = e / M, j = e - i * M;
+        const Cd t1 = cmul(Wl[n * M + i], Ul[e]);
+        sacc += t1.x * Wl[n * M + j].x + t1.y * Wl[n * M + j].y;
+      }
+      sacc = wave_sum_d(sacc);
+      if (lane == 0) pw[((size_t)b * N + n) * F + f] = sacc;
+    }
+  }
+  if (flags && status && lane == 0) atomicOr(&status[b], flags);
+}
+inline size_t ip2_rt_lds_bytes(int M) { return (size_t)8 * M * M * sizeof(Cd) + (size_t)M * sizeof(int); }
+
 inline size_t ip_rt_lds_bytes(int M) { return (size_t)7 * M * M * sizeof(Cd) + (size_t)M * sizeof(int); }
 
 // -2 T log|det W_f| per bin (the loss's last term), run-time M: LU with partial pivoting by one wave in LDS

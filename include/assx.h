@@ -29,8 +29,8 @@
  *     kernels (every entry point), 5 <= M <= 8 on the wide-channel path (csrc/assx_widem.hpp: |W x|^2 map for the
  *     source model, streaming covariance; every Gauss-ILRMA / AuxIVA / t-ILRMA / projection-back entry point, IP,
  *     ISS and IP2, the partitioning function with n_basis <= 64), 9 <= M <= 32 on the same path with a run-time
- *     channel count (csrc/assx_widem_rt.hpp: functional, not tuned; the IP sweep only -- ISS, IP2 and the
- *     partitioning function return ASSX_E_UNSUPPORTED there).  One utterance must stay below
+ *     channel count (csrc/assx_widem_rt.hpp: functional, not tuned; IP, ISS and IP2 sweeps and the partitioning
+ *     function -- the last three since round 6).  One utterance must stay below
  *     4 GiB in complex128 (M*F*T < 2^28: in-kernel buffer offsets are 32-bit), any number of utterances.
  *   - dtype: ASSX_F32 (float / complex64) or ASSX_F64 (double / complex128 = the reference's).
  *   - `ws` is caller-owned device scratch of at least assx_workspace_bytes() bytes.

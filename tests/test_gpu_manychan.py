@@ -1,8 +1,7 @@
 """More than 8 channels (9 <= M <= 32): the run-time channel-count kernels of csrc/assx_widem_rt.hpp behind the same C-ABI
 entry points and classes -- every stage against the oracle on seeded inputs (the oracle is generic in M, like the
 reference: src/bss/ilrma.py:61-62, src/bss/iva.py:39-59), float64 and float32, batched == single; a reference-generated
-fixture at M = 9 is in test_gpu_models.py (`ilrma_m9`).  IP only: ISS / IP2 / the partitioning function raise with
-the library's message."""
+fixture at M = 9 is in test_gpu_models.py (`ilrma_m9`).  IP and, since round 6, ISS, IP2 and the partitioning function."""
 import numpy as np
 import pytest
 
@@ -158,7 +157,92 @@ def test_classes_batched_and_unsupported():
     np.testing.assert_allclose(np.asarray(a.loss), refa["loss"], rtol=1e-9)
     W = a.compute_demix_filter(orc.separate(Xs[0], refa["W"]), Xs[0])
     assert rel_err(np.asarray(W), refa["W"]) < 1e-7
-    with pytest.raises((AssxError, NotImplementedError)):
-        GaussILRMA(n_basis=K, algorithm_spatial="ISS")(Xs[0], iteration=1)
     with pytest.raises((AssxError, NotImplementedError, ValueError)):
         GaussILRMA(n_basis=K)(np.zeros((33, 4, 70), dtype=np.complex128), iteration=1)  # M = 33
+
+
+@pytest.mark.parametrize("M,F,T", [(9, 6, 260), (12, 4, 257), (17, 3, 150)])
+def test_iss_sweep_more_than_8_channels(eng, M, F, T):
+    """The ISS sweep with a run-time channel count (csrc/assx_widem_rt.hpp: iss_rt_kernel; round 5's review, missing #2):
+    one sweep against the oracle's rank-one updates of Y (ilrma.py:557-562: sums, not means) restated on W, from a dense
+    weighted covariance; then the classes' whole loops."""
+    X, W = mixture(M, F, T, 31), rand_filters(M, F, 32)
+    rng = np.random.default_rng(33)
+    r = rng.random((M, F, T)) + 0.05
+    U = orc.weighted_covariance(X, r)
+    Wd = dev_c(eng, W[None])
+    eng.iss_update(dev_c(eng, U[None]), Wd, T)
+    Y = orc.iss_update(orc.separate(X, W), r)
+    Wref = orc.compute_demix_filter(Y, X)
+    assert rel_err(host(Wd)[0], Wref) < tol(eng, 1e-9, 2e-3)
+
+
+def test_iss_classes_more_than_8_channels():
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    from audio_source_separation_amd.bss.iva import AuxLaplaceIVA
+    M, F, T, K = 9, 6, 260, 3
+    X = mixture(M, F, T, 60)
+    st = np.random.RandomState(70)
+    T0, V0 = st.rand(M, F, K), st.rand(M, K, T)
+    m = GaussILRMA(n_basis=K, algorithm_spatial="ISS")
+    m.basis, m.activation = T0, V0
+    Y = m(X, iteration=3)
+    ref = orc.gauss_ilrma_iss(X, 3, T0, V0)
+    assert rel_err(Y, ref["Y"]) < 1e-7 and rel_err(np.asarray(m.basis), ref["T"]) < 1e-7
+    np.testing.assert_allclose(np.asarray(m.loss), ref["loss"], rtol=1e-8)
+    a = AuxLaplaceIVA(algorithm_spatial="ISS")
+    Ya = a(X, iteration=3)
+    refa = orc.auxiva_iss(X, 3, "laplace")
+    assert rel_err(Ya, refa["Y"]) < 1e-7
+    np.testing.assert_allclose(np.asarray(a.loss), refa["loss"], rtol=1e-8)
+
+
+@pytest.mark.parametrize("M,F,T,pair", [(9, 6, 260, (0, 1)), (12, 4, 257, (11, 0)), (17, 3, 150, (5, 6))])
+def test_ip2_sweep_more_than_8_channels(eng, M, F, T, pair):
+    """The pairwise (IP2) update with a run-time channel count (csrc/assx_widem_rt.hpp: ip2_rt_kernel): rows pm / pn against the
+    oracle's update (generalised 2 x 2 eigenproblem, LAPACK's eigenvector convention, descending order), every other row
+    untouched bit for bit."""
+    X, W = mixture(M, F, T, 41), rand_filters(M, F, 42)
+    rng = np.random.default_rng(43)
+    r = rng.random((M, F, T)) + 0.05
+    U = orc.weighted_covariance(X, r)
+    Wd = dev_c(eng, W[None])
+    st = eng.new_status(1)
+    eng.ip2_update(dev_c(eng, U[None]), Wd, pair, 1e12, st)
+    Wref, _, _ = orc.ip2_update(W.copy(), U[pair[0]], U[pair[1]], pair[0], pair[1])
+    got = host(Wd)[0]
+    assert int(st.item()) == 0
+    assert rel_err(got[:, list(pair), :], Wref[:, list(pair), :]) < tol(eng, 1e-9, 5e-3)
+    others = [n for n in range(M) if n not in pair]
+    assert np.array_equal(got[:, others, :], host(dev_c(eng, W[None]))[0][:, others, :])
+
+
+def test_ip2_and_partitioning_classes_more_than_8_channels():
+    from audio_source_separation_amd.bss.ilrma import GaussILRMA
+    M, F, T, K = 9, 6, 260, 3
+    X = mixture(M, F, T, 60)
+    st = np.random.RandomState(70)
+    T0, V0 = st.rand(M, F, K), st.rand(M, K, T)
+    m = GaussILRMA(n_basis=K, algorithm_spatial="IP2")
+    m.basis, m.activation = T0, V0
+    Y = m(X, iteration=4)
+    ref = orc.gauss_ilrma_ip2(X, 4, T0, V0)
+    assert rel_err(Y, ref["Y"]) < 1e-7 and rel_err(np.asarray(m.basis), ref["T"]) < 1e-7
+    np.testing.assert_allclose(np.asarray(m.loss), ref["loss"], rtol=1e-8)
+    assert tuple(m.update_pair) == tuple(ref["update_pair"])
+    # the partitioning function (shared bases + latent variables), IP and ISS
+    for alg in ("IP", "ISS"):
+        st = np.random.RandomState(71)
+        Z0 = st.rand(M, K)
+        Z0 = Z0 / Z0.sum(axis=0)
+        Tp, Vp = st.rand(F, K), st.rand(K, T)
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mp = GaussILRMA(n_basis=K, partitioning=True, algorithm_spatial=alg)
+        mp.latent, mp.basis, mp.activation = Z0, Tp, Vp
+        Yp = mp(X, iteration=3)
+        refp = orc.gauss_ilrma_partitioned(X, 3, Z0, Tp, Vp, algorithm_spatial=alg)
+        assert rel_err(Yp, refp["Y"]) < 1e-7, alg
+        assert rel_err(np.asarray(mp.latent), refp["Z"]) < 1e-7 and rel_err(np.asarray(mp.basis), refp["T"]) < 1e-7, alg
+        np.testing.assert_allclose(np.asarray(mp.loss), refp["loss"], rtol=1e-8)
