@@ -57,7 +57,7 @@ def collect():
                 subprocess.run(cmd, cwd="/tmp", env=env, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 
 
-def measure_case(tag, dtype, workdir, timeout=180):
+def measure_case(tag, dtype, workdir, timeout=90):
     """One case, both counters, into `workdir` (bench.py calls this at the end of its run so that roofline.traffic is a figure
     of THAT run and box): {"traffic_bytes", "fetch_bytes_raw", "write_bytes_raw", ...} or None."""
     case = [c for c in CASES if c[0] == tag][0]
