@@ -156,6 +156,13 @@ def test_cabi_comm_edges_on_a_one_rank_communicator():
         "    st.synchronize()\n"
         "    assert loc.data_ptr() != x.data_ptr() and torch.equal(loc, x) and torch.equal(back, x * 2)\n"
         "cm.close()\n"
+        "from audio_source_separation_amd._lib import AssxError\n"
+        "for world, rank in ((2, 5), (0, 0), (3, -1)):\n"
+        "    try:\n"
+        "        C.Comm(world, rank, C.unique_id(), device=dev)\n"
+        "        raise SystemExit('bad world / rank %%d / %%d accepted' %% (world, rank))\n"
+        "    except AssxError as e:\n"
+        "        assert 'bad world / rank' in str(e), e\n"
         "print('cabi comm ok')\n" % ROOT)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
